@@ -1,0 +1,151 @@
+/*
+ * yolo355 -- C ABI of the MI355X-native quantized slim-YOLOv2 inference engine.
+ *
+ * The reference (ZLkanyo009/Yolo-compression-and-deployment-in-FPGA) has no FFI boundary for
+ * this path: the hot path is the Python surface of models/slim_yolo_v2.py and
+ * utils/modules.py.  This header is the boundary the drop-in Python
+ * classes (yolo355/models/slim_yolo_v2.py, yolo355/utils/modules.py) bind with ctypes; every
+ * entry point names the reference code it replaces.  All functions return 0 on success or a
+ * negative Y355_E* code; y355_last_error() gives the message of the last failure on the
+ * calling thread.
+ *
+ * Ownership / threading: a y355_engine owns one GPU's device memory, its packed weights and
+ * its workspaces.  One handle is single-threaded; different handles are independent (one per
+ * GPU / process).  Host buffers passed in stay owned by the caller.  "dev" pointers are HIP
+ * device pointers on the engine's GPU (e.g. torch.Tensor.data_ptr()).  Every launch goes to
+ * the stream given at creation; calls are asynchronous unless stated otherwise.
+ *
+ * Data layout in HBM: activations are int8 NHWC with a one-pixel zero halo,
+ * [B][H+2][W+2][C]; the fp32 NCHW network input is read directly by the first layer.
+ */
+#ifndef YOLO355_H
+#define YOLO355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y355_MAX_ANCHORS 16
+#define Y355_NUM_LAYERS 10       /* conv1..conv7 + pred, models/slim_yolo_v2.py:59-87 */
+#define Y355_NUM_TRACKERS 11     /* a_tracker_in, a_tracker1..7, a_tracker_pred (:58-89) */
+
+#define Y355_OK 0
+#define Y355_EINVAL (-1)         /* bad argument */
+#define Y355_EHIP (-2)           /* HIP runtime error */
+#define Y355_ENOTREADY (-3)      /* weights / activation exponents missing */
+#define Y355_ERANGE (-4)         /* exponent gap does not fit the int32 epilogue */
+#define Y355_EGUARD (-5)         /* 2^15 head-room guard tripped (find=True semantics) */
+
+typedef struct y355_engine y355_engine;
+
+typedef struct y355_config {
+    int32_t device_id;
+    int32_t height, width;        /* network input size, multiples of 16 (input_size=[H,W]) */
+    int32_t num_classes;          /* models/slim_yolo_v2.py:42 */
+    int32_t num_anchors;
+    float anchors[2 * Y355_MAX_ANCHORS]; /* (w,h) in grid units, data/config.py:10-14 */
+    float conf_thresh;            /* :42, used at :189 */
+    float nms_thresh;             /* :42, used at :171 */
+    int32_t max_batch;
+    int32_t max_det;              /* per-image cap of returned detections; 0 = all anchors */
+    void *stream;                 /* hipStream_t to launch on; NULL = engine-owned stream */
+} y355_config;
+
+/* per-layer counters of the last run of that layer */
+typedef struct y355_layer_stats {
+    int64_t absmax_t;   /* max |t'| before requantisation (stats mode only) */
+    int32_t frac_bits;  /* F': value = t' / 2^F'  (max|y| of slim_yolo_v2.py:22 = absmax_t/2^F') */
+    int32_t reserved;
+    int64_t saturated;  /* outputs with |q| > 127 that were clamped (reference has no clamp, :35) */
+    int64_t guard;      /* outputs violating |y * 2^retune| < 2^15 (:222-227) */
+} y355_layer_stats;
+
+const char *y355_last_error(void);
+int y355_version(void);
+
+/* replaces SlimYOLOv2_quantize_bnfuse.__init__ / set_grid (models/slim_yolo_v2.py:42-109) */
+int y355_create(const y355_config *cfg, y355_engine **out);
+void y355_destroy(y355_engine *h);
+int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
+
+/* replaces load_state_dict of the quantized checkpoint: integer weights as produced by
+ * quantize_layers (retune_bias_quantize.py:111-119): q_w[cout][cin][3][3] int8 with value
+ * q_w / 2^e_w, q_b[cout] with value q_b / 2^e_b.  idx 0..9 = conv1..conv7, pred.  Host pointers. */
+int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const int32_t *q_b,
+                    int cout, int cin, int e_w, int e_b);
+
+/* activation exponents floor(log2(tracker.scale)) of the 11 AveragedRangeTrackers
+ * (models/slim_yolo_v2.py:33): sa[0] input, sa[1..9] conv1..conv7, sa[10] pred. */
+int y355_set_act_exponents(y355_engine *h, const int32_t *sa);
+int y355_get_act_exponents(y355_engine *h, int32_t *sa);
+int y355_set_act_exponent(y355_engine *h, int tracker, int32_t exponent);   /* one tracker */
+/* per-layer scale_retune exponents used by the find=True guard
+ * (retune_bias_quantize_findbest.py:122-141, c_embedding/yolo_forward.c:35) */
+int y355_set_retune(y355_engine *h, const int32_t *retune);
+
+/* --- calibration stepping (AveragedRangeTracker.quantize_activation, :16-38) -------------
+ * max|x| of the fp32 network input (device pointer, NCHW [B,3,H,W]); synchronous. */
+int y355_input_absmax(y355_engine *h, const float *x_dev, int batch, float *out_max);
+/* run layer idx on the engine's current feature maps.  mode 0: normal fused
+ * conv+bias+leaky+requant(+pool).  mode 1: statistics only (fills absmax_t, writes nothing).
+ * Layer 0 reads x_dev (fp32 NCHW) and quantises it with sa[0]; other layers ignore x_dev. */
+int y355_run_layer(y355_engine *h, int idx, int batch, int mode, const float *x_dev);
+/* synchronous read-back of a layer's counters */
+int y355_layer_stats_get(y355_engine *h, int idx, y355_layer_stats *out);
+/* parity tap: copy layer idx's int8 output [B][C][Ho][Wo] (NCHW, halo stripped) to host. */
+int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst_host);
+
+/* --- the hot path: replaces SlimYOLOv2_quantize_bnfuse.forward(x, quantization=True)
+ * (models/slim_yolo_v2.py:212-358) for a whole batch.  x_dev fp32 NCHW [B,3,H,W].
+ * Outputs (device pointers, caller-allocated, fixed-cap padded):
+ *   boxes  f32 [B][max_det][4]  x1y1x2y2 normalised to [0,1], anchor-index order
+ *   scores f32 [B][max_det]
+ *   cls    i32 [B][max_det]
+ *   count  i32 [B]
+ * flags: Y355_F_GUARD also evaluates the find=True head-room guard. Asynchronous. */
+#define Y355_F_GUARD 1
+#define Y355_F_TAP 2     /* also keep the per-anchor decode (y355_get_candidates) */
+int y355_forward(y355_engine *h, const float *x_dev, int batch, int flags,
+                 float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev);
+/* same, host pointers in and out (copies through engine-owned staging buffers); synchronous. */
+int y355_forward_host(y355_engine *h, const float *x_host, int batch, int flags,
+                      float *boxes, float *scores, int32_t *cls, int32_t *count);
+/* sums over layers of the counters of the last forward; synchronous. */
+int y355_forward_counters(y355_engine *h, int64_t *saturated, int64_t *guard);
+/* parity tap of the head before thresholding (slim_yolo_v2.py:348-350 for every image):
+ * boxes f32 [B][N][4], best-class scores f32 [B][N], classes i32 [B][N]; N = anchors per image.
+ * Valid after y355_head_nms or a forward with Y355_F_TAP; host pointers; synchronous. */
+int y355_get_candidates(y355_engine *h, int batch, float *boxes, float *scores, int32_t *cls);
+int y355_max_det(y355_engine *h);              /* effective per-image cap */
+int y355_num_anchors_total(y355_engine *h);    /* N = Hs*Ws*A */
+
+/* --- operator-level entry points (utils/modules.py Conv2d_fuse, unit tests) ----------------
+ * One fused int8 layer on caller data, host pointers, synchronous:
+ *   q_in  int8 [B][cin][H][W] (NCHW), q_w int8 [cout][cin][3][3], q_b int32 [cout]
+ *   out   int8 [B][cout][Ho][Wo]; flags bit0 = LeakyReLU(0.125), bit1 = 2x2 max-pool
+ * Requantisation: q_out = clamp(RNE(t' * 2^(sa_out - F'))), see DESIGN.md. */
+#define Y355_OP_LEAKY 1
+#define Y355_OP_POOL 2
+int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const int8_t *q_w, const int32_t *q_b,
+                          int batch, int cin, int cout, int height, int width,
+                          int sa_in, int e_w, int e_b, int sa_out, int flags,
+                          int8_t *out, y355_layer_stats *stats);
+/* head only: pred int8 [B][A*(5+C)][Hs][Ws] NCHW host -> detections (host), synchronous.
+ * Replaces slim_yolo_v2.py:330-358 (decode, score, threshold, per-class NMS). */
+int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred,
+                  float *boxes, float *scores, int32_t *cls, int32_t *count);
+
+/* --- measurement helpers: HIP events on the engine's stream ------------------------------ */
+int y355_sync(y355_engine *h);
+/* per-kernel device time of the last forward run with profiling enabled (ms);
+ * slots 0..9 = layers, 10 = head decode, 11 = NMS.  y355_profile(h, 1) turns recording on. */
+#define Y355_NUM_TIMERS 12
+int y355_profile(y355_engine *h, int enable);
+int y355_profile_get(y355_engine *h, float *ms /*[Y355_NUM_TIMERS]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO355_H */

@@ -1,0 +1,211 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and the golden vectors.
+
+Bit-exact for everything integer (feature maps, pred tensor, exponents, counters);
+tolerance for the fp32 head: boxes 2e-5 absolute (normalised coordinates), scores 2e-6
+absolute / 1e-5 relative; detection lists are compared tie-tolerantly (helpers.dets_match).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import yolo_oracle as O          # checker only
+from yolo355 import synth
+from yolo355.engine import Engine, conv3x3_i8_fused
+from yolo355.prep import RangeTracker
+from helpers import crc, dets_match
+from cases import E2E
+
+BOX_TOL, SCORE_TOL = 2e-5, 2e-6
+
+
+def _rand_i8(seed, shape):
+    return (synth.uniform_u8(seed, shape).astype(np.int32) - 128).clip(-127, 127)
+
+
+def _oracle_layer(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky, pool):
+    t, Fx, _ = O.conv_layer_int(q_in, q_w, q_b, sa_in, e_w, e_b, leaky)
+    q = O.rne_shift(t, Fx - sa_out)
+    nsat = int((np.abs(q) > 127).sum())
+    q = np.clip(q, -127, 127)
+    if pool:
+        q = O.maxpool2x2(q)
+    return q.astype(np.int8), int(np.abs(t).max()), Fx, nsat
+
+
+def test_single_layer_golden(golden):
+    """the reference's own Conv2d_fuse + tracker outputs (G1) through y355_conv3x3_i8_fused"""
+    n = 0
+    while "layer/%d/meta" % n in golden:
+        cin, cout, h, w, sa_in, e_w, e_b, sa_out, leaky, s0, s1, s2 = [int(v) for v in golden["layer/%d/meta" % n]]
+        q_in, q_w, q_b = _rand_i8(s0, (2, cin, h, w)), _rand_i8(s1, (cout, cin, 3, 3)), _rand_i8(s2, (cout,))
+        out, st = conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=bool(leaky))
+        ref = golden["layer/%d/q_out" % n]
+        assert np.array_equal(out.astype(np.int32), np.clip(ref, -127, 127)), n
+        assert st["saturated"] == int((np.abs(ref) > 127).sum())
+        assert np.float32(st["absmax_t"]) * np.float32(2.0 ** -st["frac_bits"]) == golden["layer/%d/ymax" % n][0]
+        n += 1
+    assert n == 6
+
+
+@pytest.mark.parametrize("cin,cout,h,w,leaky,pool", [
+    (3, 16, 10, 14, True, True), (16, 32, 16, 52, True, True), (24, 40, 9, 7, True, False),
+    (32, 64, 13, 26, True, False), (64, 64, 26, 26, True, True), (64, 128, 13, 26, True, False),
+    (128, 128, 26, 26, True, True), (128, 256, 13, 13, True, False), (256, 256, 13, 13, True, False),
+    (256, 35, 13, 13, False, False), (256, 125, 5, 3, False, False), (200, 70, 6, 10, True, True),
+    (1, 1, 1, 1, True, False), (16, 16, 2, 2, False, True),
+])
+def test_single_layer_shapes(cin, cout, h, w, leaky, pool):
+    seed = cin * 1000 + cout
+    q_in, q_w, q_b = _rand_i8(seed, (2, cin, h, w)), _rand_i8(seed + 1, (cout, cin, 3, 3)), _rand_i8(seed + 2, (cout,))
+    sa_in, e_w, e_b = 5, 8, 6
+    amax = 127 * 127 * 9 * cin
+    sa_out = int(np.floor(np.log2(127.0 / (amax / 2.0 ** (sa_in + e_w))))) + 2   # some saturation on purpose
+    ref, tmax, Fx, nsat = _oracle_layer(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky, pool)
+    out, st = conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=leaky, pool=pool)
+    assert np.array_equal(out, ref)
+    assert (st["absmax_t"], st["frac_bits"]) == (tmax, Fx)
+    if not pool:
+        assert st["saturated"] == nsat
+
+
+def _build(tag, golden, max_batch=1, max_det=0):
+    wkw, anchors, pattern = E2E[tag]
+    meta = [int(v) for v in golden[tag + "/meta"]]
+    H, W, C, calib_seed = meta[:4]
+    confs = [float(v) for v in golden[tag + "/confs"]]
+    ql = O.quantize_layers(synth.make_weights(**wkw, num_classes=C))
+    eng = Engine([H, W], C, anchors, conf_thresh=confs[0], nms_thresh=0.5, max_batch=max_batch, max_det=max_det)
+    eng.load_quantized(ql)
+    return eng, ql, (H, W, C, calib_seed, meta[4:], confs, anchors, pattern)
+
+
+@pytest.mark.parametrize("tag", list(E2E))
+def test_end_to_end(golden, tag):
+    eng, ql, (H, W, C, calib_seed, img_seeds, confs, anchors, pattern) = _build(tag, golden, max_batch=max(1, len(E2E)))
+    xc = synth.make_images(calib_seed, 1, H, W, pattern)
+    trackers = [RangeTracker() for _ in range(11)]
+    sa = eng.calibrate(xc, trackers, freeze=True)              # first-call semantics (:25-27)
+    assert sa == [int(v) for v in golden[tag + "/sa"]]
+    otr = [O.RangeTracker() for _ in range(11)]
+    r = O.detect(xc, ql, otr, [H, W], anchors, C, confs[0], 0.5, keep=True)
+    for li in range(10):
+        got = eng.get_feature(li, 1)
+        assert np.array_equal(got, r["maps"][li].astype(np.int8)), (tag, li)
+        assert crc(got) == int(golden[tag + "/calib/map_crc/%d" % (li + 1)][0]), (tag, li)
+    assert np.array_equal(eng.get_feature(9, 1), golden[tag + "/calib/pred_q"])
+    for ci, conf in enumerate(confs):
+        eng.set_thresholds(conf, 0.5)
+        dets = eng.forward(xc, find=(tag == "find"), tap=True)
+        assert eng.counters() == (0, 0)
+        cb, cs, cc = eng.candidates(1)
+        assert np.allclose(cb[0], r["box"][0], atol=BOX_TOL, rtol=0)
+        assert np.allclose(cs[0], r["cls_scores"][0].max(1), atol=SCORE_TOL, rtol=1e-5)
+        ref = (golden[tag + "/calib/det%d/boxes" % ci], golden[tag + "/calib/det%d/scores" % ci],
+               golden[tag + "/calib/det%d/cls" % ci])
+        ok, msg = dets_match(ref, dets[0], BOX_TOL, SCORE_TOL, all_scores=r["cls_scores"][0].max(1))
+        assert ok and (tag != "diverse" or msg == "exact"), (tag, conf, msg)
+        # against the oracle with the same (score desc, index asc) tie order: strict
+        ob, os_, oc, _ = O.postprocess(r["box"][0], r["cls_scores"][0], conf, 0.5, C)
+        ok, msg = dets_match((ob, os_, oc), dets[0], BOX_TOL, SCORE_TOL, all_scores=r["cls_scores"][0].max(1))
+        assert ok, (tag, conf, "vs oracle", msg)
+    # frozen trackers, whole batch at once == the reference run one image at a time (G7)
+    eng.set_thresholds(confs[0], 0.5)
+    xs = np.concatenate([synth.make_images(s, 1, H, W, pattern) for s in img_seeds])
+    dets = eng.forward(xs)
+    rb = O.detect(xs, ql, otr, [H, W], anchors, C, confs[0], 0.5, saturate=True, keep=True)
+    assert np.array_equal(eng.get_feature(9, len(img_seeds)), rb["pred_q"].astype(np.int8))
+    sat, _ = eng.counters()
+    for si in range(len(img_seeds)):
+        ref = (golden[tag + "/img%d/boxes" % si], golden[tag + "/img%d/scores" % si], golden[tag + "/img%d/cls" % si])
+        if int(golden[tag + "/img%d/nover" % si].sum()) == 0:
+            ok, msg = dets_match(ref, dets[si], BOX_TOL, SCORE_TOL, all_scores=rb["cls_scores"][si].max(1))
+            assert ok, (tag, si, msg)
+        ok, msg = dets_match(rb["dets"][si][:3], dets[si], BOX_TOL, SCORE_TOL, all_scores=rb["cls_scores"][si].max(1))
+        assert ok, (tag, si, "vs oracle", msg)
+    eng.close()
+
+
+def test_guard_trips_like_reference(golden):
+    H, W, C, seed, gain = [int(v) for v in golden["guard/meta"]]
+    ql = O.quantize_layers(synth.make_weights(seed=2, weight_gain=float(gain), num_classes=C))
+    eng = Engine([H, W], C, synth.ANCHOR_SIZE_MASK)
+    eng.load_quantized(ql)
+    x = synth.make_images(seed, 1, H, W)
+    eng.calibrate(x, [RangeTracker() for _ in range(11)])
+    eng.forward(x)                       # plain -q path does not look at the guard
+    with pytest.raises(AssertionError):
+        eng.forward(x, find=True)        # models/slim_yolo_v2.py:222-227
+    eng.close()
+
+
+def test_saturation_is_counted_not_silent():
+    """Input 1.6x the calibration range: the reference has no clamp (:35); the engine clamps to
+    +-127 like the FPGA and reports how often (SURVEY 7 'hard parts')."""
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
+    eng = Engine([96, 96], 2, synth.ANCHOR_SIZE_MASK)
+    eng.load_quantized(ql)
+    x = synth.make_images(5, 1, 96, 96)
+    tr = [RangeTracker() for _ in range(11)]
+    eng.calibrate(x, tr)
+    otr = [O.RangeTracker() for _ in range(11)]
+    O.detect(x, ql, otr, [96, 96], synth.ANCHOR_SIZE_MASK, 2)
+    x2 = x * np.float32(1.6)
+    eng.forward(x2)
+    r = O.detect(x2, ql, otr, [96, 96], synth.ANCHOR_SIZE_MASK, 2, saturate=True, keep=True)
+    assert np.array_equal(eng.get_feature(9, 1), r["pred_q"].astype(np.int8))
+    sat, _ = eng.counters()
+    assert sat > 0
+    eng.close()
+
+
+def test_head_only_matches_oracle(golden):
+    for tag in ("diverse", "sparse", "gap"):
+        wkw, anchors, pattern = E2E[tag]
+        H, W, C = [int(v) for v in golden[tag + "/meta"][:3]]
+        conf = float(golden[tag + "/confs"][0])
+        sa_pred = int(golden[tag + "/sa"][10])
+        pq = golden[tag + "/calib/pred_q"]
+        eng = Engine([H, W], C, anchors, conf_thresh=conf, max_batch=2)
+        dets = eng.head_nms(np.concatenate([pq, pq[:, :, ::-1, :]]), sa_pred)
+        cb, cs, cc = eng.candidates(2)
+        for i, p in enumerate((pq, pq[:, :, ::-1, :])):
+            box, sc = O.head_decode(p.astype(np.float32) * np.float32(2.0 ** -sa_pred), [H, W], anchors, C)
+            assert np.allclose(cb[i], box[0], atol=BOX_TOL, rtol=0)
+            assert np.allclose(cs[i], sc[0].max(1), atol=SCORE_TOL, rtol=1e-5)
+            ref = O.postprocess(box[0], sc[0], conf, 0.5, C)[:3]
+            ok, msg = dets_match(ref, dets[i], BOX_TOL, SCORE_TOL, all_scores=sc[0].max(1))
+            assert ok, (tag, i, msg)
+        eng.close()
+
+
+def test_full_batch_properties():
+    """BASELINE size (B=64, 416x416): size-independent properties.  Images repeat with period 4,
+    so detections must repeat; element 0..3 are checked against the oracle; the 64-image batch
+    equals 4 runs of 16 (batch independence)."""
+    B = 64
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
+    eng = Engine([416, 416], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+    eng.load_quantized(ql)
+    base = synth.make_images(0, 4, 416, 416)
+    xc = synth.make_images(1, 1, 416, 416)
+    eng.calibrate(xc, [RangeTracker() for _ in range(11)])
+    otr = [O.RangeTracker() for _ in range(11)]
+    O.detect(xc, ql, otr, [416, 416], synth.ANCHOR_SIZE_MASK, 2)
+    x = np.concatenate([base] * (B // 4))
+    dets = eng.forward(x)
+    pred = eng.get_feature(9, B)
+    for i in range(4, B):
+        assert np.array_equal(pred[i], pred[i % 4])
+        for a, b in zip(dets[i], dets[i % 4]):
+            assert np.array_equal(a, b)
+    r = O.detect(base, ql, otr, [416, 416], synth.ANCHOR_SIZE_MASK, 2, saturate=True)
+    assert np.array_equal(pred[:4], r["pred_q"].astype(np.int8))
+    for i in range(4):
+        ok, msg = dets_match(r["dets"][i][:3], dets[i], BOX_TOL, SCORE_TOL, all_scores=r["cls_scores"][i].max(1))
+        assert ok, (i, msg)
+    d16 = eng.forward(x[:16])
+    for i in range(16):
+        for a, b in zip(d16[i], dets[i]):
+            assert np.array_equal(a, b)
+    eng.close()

@@ -1,0 +1,84 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute calls)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from yolo355 import _ffi, prep, synth
+from helpers import crc
+
+
+def test_library_exports_every_declared_symbol():
+    names = _ffi.declared_symbols()
+    assert len(names) >= 25 and "y355_forward" in names
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libyolo355.so does not export %s" % n
+    assert set(_ffi._SIGS) <= set(names)
+    assert lib.y355_version() == 1
+
+
+def test_create_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from yolo355.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine([416, 416], 2, synth.ANCHOR_SIZE_MASK)
+    lib = _ffi.lib()
+    cfg = _ffi.Config()
+    cfg.height, cfg.width, cfg.num_classes, cfg.num_anchors, cfg.max_batch = 100, 416, 2, 5, 1
+    h = ctypes.c_void_p()
+    assert lib.y355_create(ctypes.byref(cfg), ctypes.byref(h)) == -1      # Y355_EINVAL: not a multiple of 16
+    assert b"multiple of 16" in lib.y355_last_error()
+
+
+def test_prep_quantizers_match_golden(golden):
+    for tag, kw in [("w2", dict(seed=2)), ("w3gap", dict(seed=3, bias_gain=40.0, weight_gain=3.0))]:
+        for li, (name, w, b) in enumerate(synth.make_weights(**kw, num_classes=2)):
+            g = golden["prep/%s/%d" % (tag, li)]
+            qw, ew = prep.to_int8_pow2(torch.from_numpy(w))
+            qb, eb = prep.to_int8_pow2(torch.from_numpy(b))
+            assert (ew, eb) == (g[0], g[1])
+            assert crc(qw.astype(np.int8)) == g[2] and crc(qb.astype(np.int8)) == g[3]
+            # a tensor stored as q/2^e is recognised again, raw fp32 weights are refused
+            q2, e2 = prep.as_dyadic_int8(torch.from_numpy(qw.astype(np.float32) / np.float32(2.0 ** ew)))
+            assert np.array_equal(q2.astype(np.float64) * 2.0 ** -e2, qw.astype(np.float64) * 2.0 ** -ew)
+            with pytest.raises(ValueError):
+                prep.as_dyadic_int8(torch.from_numpy(w))
+
+
+def test_fuse_conv_and_bn_matches_golden(golden):
+    for case in range(3):
+        cin, cout, with_bias = [int(v) for v in golden["fuse/%d/meta" % case]]
+        w = synth.uniform_pm1(100 + case, (cout, cin, 3, 3)) * np.float32(0.2)
+        b = synth.uniform_pm1(200 + case, (cout,)) * np.float32(0.3)
+        g, be, mu, var = synth.make_bn(300 + case, cout)
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=bool(with_bias))
+        bn = torch.nn.BatchNorm2d(cout)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(w))
+            if with_bias:
+                conv.bias.copy_(torch.from_numpy(b))
+            bn.weight.copy_(torch.from_numpy(g)); bn.bias.copy_(torch.from_numpy(be))
+            bn.running_mean.copy_(torch.from_numpy(mu)); bn.running_var.copy_(torch.from_numpy(var))
+        f = prep.fuse_conv_and_bn(conv, bn)
+        assert np.array_equal(f.weight.detach().numpy(), golden["fuse/%d/w" % case])
+        assert np.array_equal(f.bias.detach().numpy(), golden["fuse/%d/b" % case])
+        # corrected fold == eval-mode conv+bn
+        fc = prep.fuse_conv_and_bn(conv, bn, corrected=True)
+        x = torch.from_numpy(synth.uniform_pm1(7, (1, cin, 6, 6)))
+        bn.eval()
+        with torch.no_grad():
+            assert torch.allclose(fc(x), bn(conv(x)), atol=1e-5)
+
+
+def test_range_tracker_state_machine():
+    t = prep.RangeTracker()
+    assert t.update(np.float32(2.64), True) == 5          # first call calibrates even when frozen (:25-27)
+    assert t.update(np.float32(100.0), True) == 5         # frozen afterwards
+    e = t.update(np.float32(0.5), False)                  # EMA (:31)
+    s = torch.tensor([127 / np.float32(2.64)], dtype=torch.float32) * (1 - 0.1) + (127 / torch.tensor(0.5)) * 0.1
+    assert e == int(torch.floor(torch.log2(s)).item())

@@ -1,0 +1,180 @@
+// yolo355 -- first layer: fp32 NCHW input -> int8 quantise -> conv3x3(3->16) -> bias ->
+// LeakyReLU(0.125) -> requantise -> 2x2 max-pool -> int8 NHWC16 (with zero halo), one kernel.
+//
+// Replaces models/slim_yolo_v2.py:218-231 (a_tracker_in.quantize_activation, conv1,
+// a_tracker1.quantize_activation, pool1) and the FPGA driver's first_conv /
+// pixel_norm_quantize (c_embedding/yolo_forward.c:57-85, 269-418).
+//
+// The layer is HBM-bound (2.08 MB of fp32 per image in, 0.69 MB out, 74.8 MMAC): the fp32
+// planes are read coalesced along W, quantised once into an LDS patch of 4-byte pixels
+// (r,g,b,0) and the 27-deep dot products run on the matrix cores: one v_mfma_i32_16x16x64_i8
+// per 16 pixels x 16 channels with K = 3 filter rows x (4 pixels x 4 bytes), the unused K
+// slots multiplied by zero weights.  GEMM rows are ordered as 2x2 pooling windows so the
+// pool is a max over the lane's four accumulators BEFORE the (monotone) epilogue.
+#include "y355_common.h"
+
+template <int TW>
+__global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
+    constexpr int TH = 16;
+    constexpr int PW = TW + 2, PH = TH + 2;
+    constexpr int NW = (TH / 2) * (TW / 2);        // pooling windows per tile
+    constexpr int MT_TOT = TH * TW / 16;
+    __shared__ __attribute__((aligned(16))) unsigned int patch[PH * PW + 8];
+    __shared__ __attribute__((aligned(16))) unsigned char otile[NW * 16];
+
+    const int tid = threadIdx.x;
+    int bid = y355_xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int H = p.H, W = p.W;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float sc = p.in_scale;
+    unsigned int nsat_in = 0;
+
+    // ---- quantise the (TH+2)x(TW+2) input patch: q = clamp(rne(x * 2^sa0))  (:33-35)
+    const float *xb = p.x + (size_t)b * 3 * H * W;
+    const size_t plane = (size_t)H * W;
+    for (int it0 = tid; it0 < PH * PW; it0 += 256 * 4) {
+        float v[4][3];
+        bool inside[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = min(it0 + u * 256, PH * PW - 1);
+            const int py = it / PW, px = it % PW;
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            inside[u] = (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
+            const size_t o = (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = xb[c * plane + o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = min(it0 + u * 256, PH * PW - 1);
+            const int py = it / PW, px = it % PW;
+            const bool own = inside[u] && (it0 + u * 256 < PH * PW) && py >= 1 && py <= TH && px >= 1 && px <= TW;
+            unsigned int w = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float r = rintf(v[u][c] * sc);
+                const float rc = fminf(fmaxf(r, -127.f), 127.f);
+                nsat_in += (own && rc != r) ? 1u : 0u;
+                const int q = inside[u] ? (int)rc : 0;
+                w |= (unsigned int)(q & 0xff) << (8 * c);
+            }
+            patch[it] = w;
+        }
+    }
+    if (tid < 8) patch[PH * PW + tid] = 0;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const v4i bw = *(const v4i *)(p.w + lane * 16);
+    const int bias = p.bias_t[li];
+    const Requant rq = p.rq;
+    const unsigned int gthr = (!p.guard || rq.guard_log2 >= 31) ? 0xffffffffu : (1u << rq.guard_log2);
+    const int Ho = H >> 1, Wo = W >> 1;
+    unsigned int amax = 0, nsat = 0, nguard = 0;
+
+    for (int mt = wave; mt < MT_TOT; mt += 4) {
+        const int row = mt * 16 + li;
+        const int w = row >> 2, r = row & 3;
+        const int oy = 2 * (w / (TW / 2)) + (r >> 1);
+        const int ox = 2 * (w % (TW / 2)) + (r & 1);
+        const unsigned int *src = patch + (oy + min(g, 2)) * PW + ox;
+        v4i a;
+        a[0] = (int)src[0];
+        a[1] = (int)src[1];
+        a[2] = (int)src[2];
+        a[3] = (int)src[3];
+        v4i acc = {0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw, acc, 0, 0, 0);
+        // lane (g, li) now holds the four positions of window mt*4+g for channel li
+        const int wo = mt * 4 + g;
+        const int wy = wo / (TW / 2), wx = wo % (TW / 2);
+        const bool valid = ((y0 >> 1) + wy < Ho) && ((x0 >> 1) + wx < Wo);
+        const int vmax = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
+        const int vmin = min(min(acc[0], acc[1]), min(acc[2], acc[3]));
+        const int tp = y355_pre(vmax, bias, rq);
+        const int tn = y355_pre(vmin, bias, rq);
+        const unsigned int am = max((unsigned int)abs(tp), (unsigned int)abs(tn));
+        amax = max(amax, valid ? am : 0u);
+        nguard += (valid && am >= gthr) ? 1u : 0u;
+        const int qq = y355_rne_shift(tp, rq.sh);
+        const int q = y355_clamp8(qq);
+        nsat += (valid && q != qq) ? 1u : 0u;
+        otile[wo * 16 + li] = (unsigned char)(q & 0xff);
+    }
+
+    if (p.mode == 1) {
+        amax = y355_wave_max_u32(amax);
+        if (lane == 0) atomicMax(&p.ctr->absmax, amax);
+        return;
+    }
+    __syncthreads();
+    int8_t *outb = p.out + (size_t)b * (Ho + 2) * (Wo + 2) * 16;
+    for (int w = tid; w < NW; w += 256) {
+        const int wy = w / (TW / 2), wx = w % (TW / 2);
+        const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+        if (oy < Ho && ox < Wo)
+            *(v4i *)(outb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * 16) = *(const v4i *)(otile + w * 16);
+    }
+    if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
+    if (nguard) atomicAdd(&p.ctr->guard, (unsigned long long)nguard);
+    if (nsat_in) atomicAdd(&p.ctr->in_sat, nsat_in);
+}
+
+static int conv1_tw(int W) { return (W % 104 == 0) ? 104 : 32; }
+
+void y355_conv1_tiles(int H, int W, int *tx, int *ty) {
+    const int tw = conv1_tw(W);
+    *tx = (W + tw - 1) / tw;
+    *ty = (H + 15) / 16;
+}
+
+void y355_launch_conv1(const Conv1Params &p, hipStream_t s) {
+    const int n = p.tiles_x * p.tiles_y * p.B;
+    if (conv1_tw(p.W) == 104)
+        hipLaunchKernelGGL((conv1_kernel<104>), dim3(n), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv1_kernel<32>), dim3(n), dim3(256), 0, s, p);
+}
+
+// B fragment of the single k-step: lane (g = filter row, j = cout) holds k = 4*d + c for
+// pixel column d (0..3, d = 3 unused) and colour c (0..3, c = 3 unused); g = 3 unused.
+void y355_pack_conv1(const int8_t *q_w, int8_t *dst) {
+    for (int l = 0; l < 64; ++l) {
+        const int g = l >> 4, j = l & 15;
+        for (int kk = 0; kk < 16; ++kk) {
+            const int d = kk >> 2, c = kk & 3;
+            int8_t v = 0;
+            if (g < 3 && d < 3 && c < 3) v = q_w[((j * 3 + c) * 3 + g) * 3 + d];
+            dst[l * 16 + kk] = v;
+        }
+    }
+}
+
+// ---- max |x| of the network input (tracker 0, slim_yolo_v2.py:22) ------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float *x, size_t n, unsigned int *out) {
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *(const float4 *)(x + i);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        } else {
+            for (size_t k = i; k < n; ++k) m = fmaxf(m, fabsf(x[k]));
+        }
+    }
+    unsigned int u = y355_wave_max_u32(__float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, u);
+}
+
+void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStream_t s) {
+    int blocks = (int)((n / 4 + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, out_bits);
+}

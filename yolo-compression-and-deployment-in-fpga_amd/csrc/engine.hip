@@ -1,0 +1,676 @@
+// yolo355 -- C ABI (include/yolo355.h): engine object, weight packing, layer schedule.
+//
+// Layer schedule = models/slim_yolo_v2.py:212-328 / c_embedding/yolo_forward.c:1202-1262:
+//   conv1(3->16)+pool, conv2(16->32)+pool, conv3_1(32->64), conv3_2(64->64)+pool,
+//   conv4_1(64->128), conv4_2(128->128)+pool, conv5(128->256), conv6, conv7, pred (no act).
+#include "../../include/yolo355.h"
+#include "y355_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(Y355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+extern "C" const char *y355_last_error(void) { return g_err.c_str(); }
+extern "C" int y355_version(void) { return 1; }
+
+namespace {
+struct LayerDef { int cin, cout, pool, leaky, kid; };
+const LayerDef kLayers[10] = {
+    {3, 16, 1, 1, -1},
+    {16, 32, 1, 1, Y355_K_CONV2},
+    {32, 64, 0, 1, Y355_K_CONV3_1},
+    {64, 64, 1, 1, Y355_K_CONV3_2},
+    {64, 128, 0, 1, Y355_K_CONV4_1},
+    {128, 128, 1, 1, Y355_K_CONV4_2},
+    {128, 256, 0, 1, Y355_K_CONV5},
+    {256, 256, 0, 1, Y355_K_CONV67},
+    {256, 256, 0, 1, Y355_K_CONV67},
+    {256, 0, 0, 0, Y355_K_PRED},
+};
+const int kRetuneDefault[10] = {11, 10, 10, 11, 11, 10, 11, 11, 11, 10};  // yolo_forward.c:35
+
+struct Layer {
+    int cin = 0, cout = 0, cout_pad = 0, pool = 0, leaky = 0, kid = -1;
+    int Hin = 0, Win = 0, Hout = 0, Wout = 0, halo = 1;
+    int e_w = 0, e_b = 0;
+    bool loaded = false, bias_dirty = true;
+    std::vector<int32_t> q_b;
+    int8_t *w_dev = nullptr;
+    int *bias_dev = nullptr;
+    int8_t *out_dev = nullptr;
+    size_t out_bytes = 0;
+    Requant rq{};
+    int frac_bits = 0;
+};
+
+int kernels_prepared = 0;
+int prepare_kernels() {
+    if (kernels_prepared) return 0;
+    for (int i = 0; i < Y355_K_COUNT; ++i) {
+        int e = y355_conv_kernel(i)->prepare();
+        if (e) return fail(Y355_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString((hipError_t)e));
+    }
+    kernels_prepared = 1;
+    return 0;
+}
+
+// Fill the integer epilogue of one layer.  Returns Y355_ERANGE when the int32 path could
+// overflow for worst-case operands.
+int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool have_out, int leaky, int retune,
+                 const int32_t *q_b, int cout, int cout_pad, Requant *rq, int *frac_bits, std::vector<int32_t> *bias_t) {
+    const int F = std::max(sa_in + e_w, e_b);
+    const int shl = F - sa_in - e_w, bshl = F - e_b;
+    const int Fp = F + (leaky ? 3 : 0);
+    if (shl > 24 || bshl > 24) return fail(Y355_ERANGE, "exponent gap too large for the int32 epilogue");
+    long long bmax = 0;
+    bias_t->assign(cout_pad, 0);
+    for (int c = 0; c < cout; ++c) {
+        const long long v = (long long)q_b[c] * (1ll << bshl);
+        bmax = std::max(bmax, std::llabs(v));
+        (*bias_t)[c] = (int32_t)v;
+    }
+    long long tmax = ((long long)127 * 127 * 9 * cin_real) * (1ll << shl) + bmax;
+    if (leaky) tmax *= 8;
+    int sh = have_out ? Fp - sa_out : 0;
+    if (sh > 31) sh = 31;
+    long long lim = tmax;
+    if (sh > 0) lim += (1ll << (sh - 1));
+    if (sh < 0) {
+        if (-sh > 24) return fail(Y355_ERANGE, "output exponent too large");
+        lim = tmax * (1ll << (-sh));
+    }
+    if (lim >= (1ll << 30)) return fail(Y355_ERANGE, "fixed-point epilogue exceeds 30 bits");
+    rq->shl = shl;
+    rq->sh = sh;
+    rq->leaky = leaky;
+    int g = 15 + Fp - retune;
+    rq->guard_log2 = g < 0 ? 0 : (g > 31 ? 31 : g);
+    *frac_bits = Fp;
+    return 0;
+}
+}  // namespace
+
+struct y355_engine {
+    y355_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Layer L[10];
+    int sa[11];
+    bool sa_set[11];
+    int retune[10];
+    int8_t *w0_dev = nullptr;       // conv1 fragment
+    Counters *ctr_dev = nullptr;    // [10]
+    unsigned int *absmax_dev = nullptr;
+    int Hs = 0, Ws = 0, N = 0;
+    // head workspace
+    float *cbox = nullptr, *cscore = nullptr;
+    int *ccls = nullptr, *order = nullptr, *count = nullptr;
+    unsigned long long *mask = nullptr;
+    float *cand_box = nullptr, *cand_score = nullptr;
+    int *cand_cls = nullptr;
+    // host-call staging
+    float *x_stage = nullptr;
+    float *o_box = nullptr, *o_score = nullptr;
+    int *o_cls = nullptr, *o_count = nullptr;
+    int max_det = 0;
+    int profile = 0;
+    hipEvent_t ev[Y355_NUM_TIMERS + 1];
+    bool ev_ok = false;
+    std::vector<void *> allocs;
+};
+
+static int dmalloc(y355_engine *h, void **p, size_t bytes, bool zero) {
+    HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+    h->allocs.push_back(*p);
+    if (zero) HIPCHK(hipMemset(*p, 0, bytes ? bytes : 16));
+    return 0;
+}
+
+extern "C" void y355_destroy(y355_engine *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->ev_ok)
+        for (auto &e : h->ev) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
+    if (!cfg || !out) return fail(Y355_EINVAL, "null argument");
+    if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % 16 || cfg->width % 16)
+        return fail(Y355_EINVAL, "input size must be a positive multiple of 16");
+    if (cfg->num_anchors < 1 || cfg->num_anchors > Y355_MAX_ANCHORS || cfg->num_classes < 1)
+        return fail(Y355_EINVAL, "bad anchors / classes");
+    if (cfg->max_batch < 1) return fail(Y355_EINVAL, "max_batch < 1");
+    const int predc = cfg->num_anchors * (5 + cfg->num_classes);
+    if (predc > 256) return fail(Y355_EINVAL, "A*(5+C) > 256 not supported");
+    const int Hs = cfg->height / 16, Ws = cfg->width / 16, N = Hs * Ws * cfg->num_anchors;
+    if (N > Y355_NMS_CAP) return fail(Y355_EINVAL, "more than 4096 anchors per image not supported");
+    HIPCHK(hipSetDevice(cfg->device_id));
+    if (int e = prepare_kernels()) return e;
+    y355_engine *h = new y355_engine();
+    h->cfg = *cfg;
+    h->Hs = Hs;
+    h->Ws = Ws;
+    h->N = N;
+    h->max_det = (cfg->max_det <= 0 || cfg->max_det > N) ? N : cfg->max_det;
+    for (int i = 0; i < 11; ++i) { h->sa[i] = 0; h->sa_set[i] = false; }
+    for (int i = 0; i < 10; ++i) h->retune[i] = kRetuneDefault[i];
+    if (cfg->stream) {
+        h->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return fail(Y355_EHIP, "hipStreamCreate failed");
+        }
+        h->own_stream = true;
+    }
+    const int B = cfg->max_batch;
+    int Hc = cfg->height, Wc = cfg->width;
+    int rc = 0;
+    for (int k = 0; k < 10 && !rc; ++k) {
+        Layer &L = h->L[k];
+        const LayerDef &d = kLayers[k];
+        L.cin = d.cin;
+        L.cout = d.cout ? d.cout : predc;
+        L.pool = d.pool;
+        L.leaky = d.leaky;
+        L.kid = d.kid;
+        L.Hin = Hc;
+        L.Win = Wc;
+        L.Hout = d.pool ? Hc / 2 : Hc;
+        L.Wout = d.pool ? Wc / 2 : Wc;
+        L.halo = (k == 9) ? 0 : 1;
+        if (k == 0) L.cout_pad = 16;
+        else {
+            const int bn = y355_conv_kernel(L.kid)->bn;
+            L.cout_pad = (L.cout + bn - 1) / bn * bn;
+        }
+        // slack rows so that clamped / masked tile reads of the next layer stay inside
+        L.out_bytes = ((size_t)B * (L.Hout + 2 * L.halo) * (L.Wout + 2 * L.halo) + 64) * L.cout_pad;
+        rc = dmalloc(h, (void **)&L.out_dev, L.out_bytes, true);
+        if (!rc) rc = dmalloc(h, (void **)&L.bias_dev, sizeof(int) * L.cout_pad, true);
+        if (!rc && k > 0) rc = dmalloc(h, (void **)&L.w_dev, y355_packed_bytes(*y355_conv_kernel(L.kid), L.cout_pad), true);
+        Hc = L.Hout;
+        Wc = L.Wout;
+    }
+    const size_t cap = Y355_NMS_CAP;
+    if (!rc) rc = dmalloc(h, (void **)&h->w0_dev, 1024, true);
+    if (!rc) rc = dmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * 10, true);
+    if (!rc) rc = dmalloc(h, (void **)&h->absmax_dev, 16, true);
+    if (!rc) rc = dmalloc(h, (void **)&h->cbox, sizeof(float) * 4 * cap * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->cscore, sizeof(float) * cap * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->ccls, sizeof(int) * cap * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->order, sizeof(int) * cap * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->count, sizeof(int) * B, true);
+    const size_t rows = ((size_t)N + 63) / 64 * 64;
+    (void)rows;
+    if (!rc) rc = dmalloc(h, (void **)&h->mask, sizeof(unsigned long long) * 64 * cap * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->cand_cls, sizeof(int) * N * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->o_box, sizeof(float) * 4 * h->max_det * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->o_score, sizeof(float) * h->max_det * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->o_cls, sizeof(int) * h->max_det * B, false);
+    if (!rc) rc = dmalloc(h, (void **)&h->o_count, sizeof(int) * B, true);
+    if (!rc) {
+        bool ok = true;
+        for (auto &e : h->ev) ok = ok && (hipEventCreate(&e) == hipSuccess);
+        h->ev_ok = ok;
+        if (!ok) rc = fail(Y355_EHIP, "hipEventCreate failed");
+    }
+    if (rc) {
+        std::string keep = g_err;
+        y355_destroy(h);
+        g_err = keep;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int y355_set_thresholds(y355_engine *h, float conf, float nms) {
+    if (!h) return fail(Y355_EINVAL, "null engine");
+    h->cfg.conf_thresh = conf;
+    h->cfg.nms_thresh = nms;
+    return 0;
+}
+
+extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const int32_t *q_b, int cout, int cin,
+                               int e_w, int e_b) {
+    if (!h || !q_w || !q_b) return fail(Y355_EINVAL, "null argument");
+    if (idx < 0 || idx >= 10) return fail(Y355_EINVAL, "layer index out of range");
+    Layer &L = h->L[idx];
+    if (cout != L.cout || cin != L.cin) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "layer %d expects [%d,%d,3,3], got [%d,%d,3,3]", idx, L.cout, L.cin, cout, cin);
+        return fail(Y355_EINVAL, buf);
+    }
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (idx == 0) {
+        int8_t frag[1024];
+        y355_pack_conv1(q_w, frag);
+        HIPCHK(hipMemcpy(h->w0_dev, frag, 1024, hipMemcpyHostToDevice));
+    } else {
+        const ConvKernelInfo &ki = *y355_conv_kernel(L.kid);
+        std::vector<int8_t> packed(y355_packed_bytes(ki, L.cout_pad));
+        y355_pack_weights(ki, q_w, cout, cin, L.cout_pad, packed.data());
+        HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
+    L.q_b.assign(q_b, q_b + cout);
+    L.e_w = e_w;
+    L.e_b = e_b;
+    L.loaded = true;
+    L.bias_dirty = true;
+    return 0;
+}
+
+extern "C" int y355_set_act_exponents(y355_engine *h, const int32_t *sa) {
+    if (!h || !sa) return fail(Y355_EINVAL, "null argument");
+    for (int i = 0; i < 11; ++i) {
+        if (sa[i] < -64 || sa[i] > 64) return fail(Y355_EINVAL, "activation exponent out of range");
+        h->sa[i] = sa[i];
+        h->sa_set[i] = true;
+    }
+    for (auto &L : h->L) L.bias_dirty = true;
+    return 0;
+}
+
+static int set_one_exponent(y355_engine *h, int i, int v) {
+    h->sa[i] = v;
+    h->sa_set[i] = true;
+    if (i < 10) h->L[i].bias_dirty = true;
+    if (i > 0) h->L[i - 1].bias_dirty = true;
+    return 0;
+}
+
+extern "C" int y355_set_act_exponent(y355_engine *h, int i, int v) {
+    if (!h || i < 0 || i > 10 || v < -64 || v > 64) return fail(Y355_EINVAL, "bad exponent");
+    return set_one_exponent(h, i, v);
+}
+
+extern "C" int y355_get_act_exponents(y355_engine *h, int32_t *sa) {
+    if (!h || !sa) return fail(Y355_EINVAL, "null argument");
+    for (int i = 0; i < 11; ++i) sa[i] = h->sa[i];
+    return 0;
+}
+
+extern "C" int y355_set_retune(y355_engine *h, const int32_t *r) {
+    if (!h || !r) return fail(Y355_EINVAL, "null argument");
+    for (int i = 0; i < 10; ++i) h->retune[i] = r[i];
+    for (auto &L : h->L) L.bias_dirty = true;
+    return 0;
+}
+
+// (re)derive the integer epilogue of layer k and upload its pre-shifted biases
+static int refresh_layer(y355_engine *h, int k, bool need_out) {
+    Layer &L = h->L[k];
+    if (!L.loaded) return fail(Y355_ENOTREADY, "layer weights not loaded");
+    if (!h->sa_set[k]) return fail(Y355_ENOTREADY, "input activation exponent not set (calibrate first)");
+    if (need_out && !h->sa_set[k + 1]) return fail(Y355_ENOTREADY, "output activation exponent not set (calibrate first)");
+    if (!L.bias_dirty) return 0;
+    std::vector<int32_t> bt;
+    int rc = make_requant(L.cin, h->sa[k], L.e_w, L.e_b, h->sa[k + 1], h->sa_set[k + 1], L.leaky, h->retune[k],
+                          L.q_b.data(), L.cout, L.cout_pad, &L.rq, &L.frac_bits, &bt);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(L.bias_dev, bt.data(), sizeof(int) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // bt is a stack-owned vector
+    L.bias_dirty = !h->sa_set[k + 1];
+    return 0;
+}
+
+static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const float *x_dev) {
+    Layer &L = h->L[k];
+    if (k == 0) {
+        Conv1Params p{};
+        p.x = x_dev;
+        p.out = L.out_dev;
+        p.w = h->w0_dev;
+        p.bias_t = L.bias_dev;
+        p.ctr = h->ctr_dev;
+        p.B = B;
+        p.H = L.Hin;
+        p.W = L.Win;
+        y355_conv1_tiles(L.Hin, L.Win, &p.tiles_x, &p.tiles_y);
+        p.in_scale = std::ldexp(1.0f, h->sa[0]);
+        p.rq = L.rq;
+        p.mode = mode;
+        p.guard = guard;
+        y355_launch_conv1(p, h->stream);
+    } else {
+        const ConvKernelInfo &ki = *y355_conv_kernel(L.kid);
+        ConvParams p{};
+        p.in = h->L[k - 1].out_dev;
+        p.out = L.out_dev;
+        p.w = L.w_dev;
+        p.bias_t = L.bias_dev;
+        p.ctr = h->ctr_dev + k;
+        p.B = B;
+        p.H = L.Hin;
+        p.W = L.Win;
+        p.cstride = L.cout_pad;
+        p.out_halo = L.halo;
+        p.tiles_x = (L.Win + ki.tw - 1) / ki.tw;
+        p.tiles_y = (L.Hin + ki.th - 1) / ki.th;
+        p.nblk = L.cout_pad / ki.bn;
+        p.rq = L.rq;
+        p.mode = mode;
+        p.guard = guard;
+        ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int y355_input_absmax(y355_engine *h, const float *x_dev, int batch, float *out_max) {
+    if (!h || !x_dev || !out_max) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemsetAsync(h->absmax_dev, 0, 16, h->stream));
+    y355_launch_absmax(x_dev, (size_t)batch * 3 * h->cfg.height * h->cfg.width, h->absmax_dev, h->stream);
+    HIPCHK(hipGetLastError());
+    unsigned int bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, h->absmax_dev, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(out_max, &bits, 4);
+    return 0;
+}
+
+extern "C" int y355_run_layer(y355_engine *h, int idx, int batch, int mode, const float *x_dev) {
+    if (!h) return fail(Y355_EINVAL, "null engine");
+    if (idx < 0 || idx >= 10 || (mode != 0 && mode != 1)) return fail(Y355_EINVAL, "bad layer / mode");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    if (idx == 0 && !x_dev) return fail(Y355_EINVAL, "layer 0 needs the network input");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    if (int rc = refresh_layer(h, idx, mode == 0)) return rc;
+    HIPCHK(hipMemsetAsync(h->ctr_dev + idx, 0, sizeof(Counters), h->stream));
+    return launch_layer(h, idx, batch, mode, 1, x_dev);
+}
+
+extern "C" int y355_layer_stats_get(y355_engine *h, int idx, y355_layer_stats *out) {
+    if (!h || !out || idx < 0 || idx >= 10) return fail(Y355_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    Counters c;
+    HIPCHK(hipMemcpyAsync(&c, h->ctr_dev + idx, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out->absmax_t = c.absmax;
+    out->frac_bits = h->L[idx].frac_bits;
+    out->reserved = (int32_t)c.in_sat;
+    out->saturated = (int64_t)c.sat + (idx == 0 ? c.in_sat : 0);
+    out->guard = (int64_t)c.guard;
+    return 0;
+}
+
+extern "C" int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst) {
+    if (!h || !dst || idx < 0 || idx >= 10) return fail(Y355_EINVAL, "bad argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const Layer &L = h->L[idx];
+    const int Hp = L.Hout + 2 * L.halo, Wp = L.Wout + 2 * L.halo, CS = L.cout_pad;
+    std::vector<int8_t> tmp((size_t)batch * Hp * Wp * CS);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(tmp.data(), L.out_dev, tmp.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < L.cout; ++c)
+            for (int y = 0; y < L.Hout; ++y)
+                for (int x = 0; x < L.Wout; ++x)
+                    dst[(((size_t)b * L.cout + c) * L.Hout + y) * L.Wout + x] =
+                        tmp[(((size_t)b * Hp + y + L.halo) * Wp + x + L.halo) * CS + c];
+    return 0;
+}
+
+static HeadParams head_params(y355_engine *h, int sa_pred, float *ob, float *os, int *oc, int *on) {
+    HeadParams p{};
+    const Layer &L = h->L[9];
+    p.pred = L.out_dev;
+    p.cstride = L.cout_pad;
+    p.Hs = h->Hs;
+    p.Ws = h->Ws;
+    p.A = h->cfg.num_anchors;
+    p.C = h->cfg.num_classes;
+    p.dq = std::ldexp(1.0f, -sa_pred);
+    p.in_w = (float)h->cfg.width;
+    p.in_h = (float)h->cfg.height;
+    for (int i = 0; i < 2 * h->cfg.num_anchors; ++i) p.anchors[i] = h->cfg.anchors[i];
+    p.conf_thresh = h->cfg.conf_thresh;
+    p.nms_thresh = h->cfg.nms_thresh;
+    p.cand_box = h->cand_box;
+    p.cand_score = h->cand_score;
+    p.cand_cls = h->cand_cls;
+    p.max_det = h->max_det;
+    p.out_box = ob;
+    p.out_score = os;
+    p.out_cls = oc;
+    p.out_count = on;
+    return p;
+}
+
+extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev,
+                            float *scores_dev, int32_t *cls_dev, int32_t *count_dev) {
+    if (!h || !x_dev || !boxes_dev || !scores_dev || !cls_dev || !count_dev) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    for (int k = 0; k < 10; ++k)
+        if (int rc = refresh_layer(h, k, true)) return rc;
+    HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * 10, h->stream));
+    const int guard = (flags & Y355_F_GUARD) ? 1 : 0;
+    const bool prof = h->profile != 0;
+    for (int k = 0; k < 10; ++k) {
+        if (prof) HIPCHK(hipEventRecord(h->ev[k], h->stream));
+        if (int rc = launch_layer(h, k, batch, 0, guard, x_dev)) return rc;
+    }
+    if (prof) HIPCHK(hipEventRecord(h->ev[10], h->stream));
+    HeadParams hp = head_params(h, h->sa[10], boxes_dev, scores_dev, cls_dev, count_dev);
+    if (!(flags & Y355_F_TAP)) { hp.cand_box = nullptr; hp.cand_score = nullptr; hp.cand_cls = nullptr; }
+    y355_launch_head_nms(hp, batch, h->cbox, h->cscore, h->ccls, h->order, h->count, h->mask, h->stream,
+                         prof ? h->ev[11] : nullptr);
+    HIPCHK(hipGetLastError());
+    if (prof) HIPCHK(hipEventRecord(h->ev[12], h->stream));
+    return 0;
+}
+
+extern "C" int y355_forward_host(y355_engine *h, const float *x_host, int batch, int flags, float *boxes,
+                                 float *scores, int32_t *cls, int32_t *count) {
+    if (!h || !x_host || !boxes || !scores || !cls || !count) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const size_t xin = (size_t)3 * h->cfg.height * h->cfg.width;
+    if (!h->x_stage) {
+        if (int rc = dmalloc(h, (void **)&h->x_stage, sizeof(float) * xin * h->cfg.max_batch, false)) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(h->x_stage, x_host, sizeof(float) * xin * batch, hipMemcpyHostToDevice, h->stream));
+    if (int rc = y355_forward(h, h->x_stage, batch, flags, h->o_box, h->o_score, h->o_cls, h->o_count)) return rc;
+    const size_t md = h->max_det;
+    HIPCHK(hipMemcpyAsync(boxes, h->o_box, sizeof(float) * 4 * md * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(scores, h->o_score, sizeof(float) * md * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cls, h->o_cls, sizeof(int) * md * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(count, h->o_count, sizeof(int) * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int y355_forward_counters(y355_engine *h, int64_t *saturated, int64_t *guard) {
+    if (!h) return fail(Y355_EINVAL, "null engine");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    Counters c[10];
+    HIPCHK(hipMemcpyAsync(c, h->ctr_dev, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int64_t s = 0, g = 0;
+    for (int k = 0; k < 10; ++k) {
+        s += (int64_t)c[k].sat + c[k].in_sat;
+        g += (int64_t)c[k].guard;
+    }
+    if (saturated) *saturated = s;
+    if (guard) *guard = g;
+    return 0;
+}
+
+extern "C" int y355_get_candidates(y355_engine *h, int batch, float *boxes, float *scores, int32_t *cls) {
+    if (!h || !boxes || !scores || !cls) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(boxes, h->cand_box, sizeof(float) * 4 * h->N * batch, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(scores, h->cand_score, sizeof(float) * h->N * batch, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cls, h->cand_cls, sizeof(int) * h->N * batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred, float *boxes,
+                             float *scores, int32_t *cls, int32_t *count) {
+    if (!h || !pred_q || !boxes || !scores || !cls || !count) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const Layer &L = h->L[9];
+    const int CS = L.cout_pad, Hs = h->Hs, Ws = h->Ws, PC = L.cout;
+    std::vector<int8_t> tmp((size_t)batch * Hs * Ws * CS, 0);
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < PC; ++c)
+            for (int y = 0; y < Hs; ++y)
+                for (int x = 0; x < Ws; ++x)
+                    tmp[(((size_t)b * Hs + y) * Ws + x) * CS + c] = pred_q[(((size_t)b * PC + c) * Hs + y) * Ws + x];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(L.out_dev, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    HeadParams hp = head_params(h, sa_pred, h->o_box, h->o_score, h->o_cls, h->o_count);
+    y355_launch_head_nms(hp, batch, h->cbox, h->cscore, h->ccls, h->order, h->count, h->mask, h->stream, nullptr);
+    HIPCHK(hipGetLastError());
+    const size_t md = h->max_det;
+    HIPCHK(hipMemcpyAsync(boxes, h->o_box, sizeof(float) * 4 * md * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(scores, h->o_score, sizeof(float) * md * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cls, h->o_cls, sizeof(int) * md * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(count, h->o_count, sizeof(int) * batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int y355_max_det(y355_engine *h) { return h ? h->max_det : Y355_EINVAL; }
+extern "C" int y355_num_anchors_total(y355_engine *h) { return h ? h->N : Y355_EINVAL; }
+
+extern "C" int y355_sync(y355_engine *h) {
+    if (!h) return fail(Y355_EINVAL, "null engine");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int y355_profile(y355_engine *h, int enable) {
+    if (!h) return fail(Y355_EINVAL, "null engine");
+    h->profile = enable;
+    return 0;
+}
+
+extern "C" int y355_profile_get(y355_engine *h, float *ms) {
+    if (!h || !ms) return fail(Y355_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipEventSynchronize(h->ev[12]));
+    for (int i = 0; i < Y355_NUM_TIMERS; ++i) HIPCHK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Operator-level fused layer on caller data (utils/modules.py Conv2d_fuse drop-in, unit tests)
+extern "C" int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const int8_t *q_w, const int32_t *q_b,
+                                     int batch, int cin, int cout, int H, int W, int sa_in, int e_w, int e_b,
+                                     int sa_out, int flags, int8_t *out, y355_layer_stats *stats) {
+    if (!q_in || !q_w || !q_b || !out) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || cin < 1 || cin > 256 || cout < 1 || H < 1 || W < 1) return fail(Y355_EINVAL, "bad shape (cin <= 256)");
+    const int pool = (flags & Y355_OP_POOL) ? 1 : 0, leaky = (flags & Y355_OP_LEAKY) ? 1 : 0;
+    if (pool && ((H | W) & 1)) return fail(Y355_EINVAL, "pooling needs even H, W");
+    HIPCHK(hipSetDevice(device_id));
+    if (int e = prepare_kernels()) return e;
+    const int cpad = cin <= 16 ? 16 : cin <= 32 ? 32 : cin <= 64 ? 64 : cin <= 128 ? 128 : 256;
+    const int sel = cpad == 16 ? 0 : cpad == 32 ? 1 : cpad == 64 ? 2 : cpad == 128 ? 3 : 4;
+    const int kid = (pool ? Y355_K_GEN16P : Y355_K_GEN16) + sel;
+    const ConvKernelInfo &ki = *y355_conv_kernel(kid);
+    const int cout_pad = (cout + ki.bn - 1) / ki.bn * ki.bn;
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    Requant rq{};
+    int fb = 0;
+    std::vector<int32_t> bt;
+    if (int rc = make_requant(cin, sa_in, e_w, e_b, sa_out, true, leaky, 10, q_b, cout, cout_pad, &rq, &fb, &bt)) return rc;
+    // host-side layout conversion: NCHW -> NHWC with halo and zero channel padding
+    const size_t in_elems = ((size_t)batch * (H + 2) * (W + 2) + 64) * cpad;
+    std::vector<int8_t> xin(in_elems, 0);
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < cin; ++c)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x)
+                    xin[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * cpad + c] =
+                        q_in[(((size_t)b * cin + c) * H + y) * W + x];
+    std::vector<int8_t> packed(y355_packed_bytes(ki, cout_pad));
+    y355_pack_weights(ki, q_w, cout, cin, cout_pad, packed.data());
+    const size_t out_elems = (size_t)batch * Ho * Wo * cout_pad;
+    int8_t *d_in = nullptr, *d_w = nullptr, *d_out = nullptr;
+    int *d_b = nullptr;
+    Counters *d_c = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_out); (void)hipFree(d_b); (void)hipFree(d_c);
+    };
+#define OPCHK(expr)                                                                         \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            cleanup();                                                                      \
+            return fail(Y355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        }                                                                                   \
+    } while (0)
+    OPCHK(hipMalloc((void **)&d_in, in_elems));
+    OPCHK(hipMalloc((void **)&d_w, packed.size()));
+    OPCHK(hipMalloc((void **)&d_out, out_elems + 64));
+    OPCHK(hipMalloc((void **)&d_b, sizeof(int) * cout_pad));
+    OPCHK(hipMalloc((void **)&d_c, sizeof(Counters)));
+    OPCHK(hipMemcpy(d_in, xin.data(), in_elems, hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(d_b, bt.data(), sizeof(int) * cout_pad, hipMemcpyHostToDevice));
+    OPCHK(hipMemset(d_out, 0, out_elems + 64));
+    Counters cz{};
+    Counters cs{};
+    for (int mode = 1; mode >= 0; --mode) {
+        OPCHK(hipMemset(d_c, 0, sizeof(Counters)));
+        ConvParams p{};
+        p.in = d_in; p.out = d_out; p.w = d_w; p.bias_t = d_b; p.ctr = d_c;
+        p.B = batch; p.H = H; p.W = W; p.cstride = cout_pad; p.out_halo = 0;
+        p.tiles_x = (W + ki.tw - 1) / ki.tw; p.tiles_y = (H + ki.th - 1) / ki.th; p.nblk = cout_pad / ki.bn;
+        p.rq = rq; p.mode = mode; p.guard = 1;
+        ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * batch, 0);
+        OPCHK(hipGetLastError());
+        OPCHK(hipDeviceSynchronize());
+        OPCHK(hipMemcpy(mode ? &cs : &cz, d_c, sizeof(Counters), hipMemcpyDeviceToHost));
+    }
+    std::vector<int8_t> o(out_elems);
+    OPCHK(hipMemcpy(o.data(), d_out, out_elems, hipMemcpyDeviceToHost));
+    cleanup();
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < cout; ++c)
+            for (int y = 0; y < Ho; ++y)
+                for (int x = 0; x < Wo; ++x)
+                    out[(((size_t)b * cout + c) * Ho + y) * Wo + x] = o[(((size_t)b * Ho + y) * Wo + x) * cout_pad + c];
+    if (stats) {
+        stats->absmax_t = cs.absmax;
+        stats->frac_bits = fb;
+        stats->reserved = 0;
+        stats->saturated = (int64_t)cz.sat;
+        stats->guard = (int64_t)cz.guard;
+    }
+    (void)rc;
+    return 0;
+}

@@ -1,0 +1,134 @@
+// yolo355 -- shared device/host declarations (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Fixed-point epilogue of one fused layer (DESIGN.md "requantisation"):
+//   t  = (acc << shl) + bias_t[c]        bias_t = q_b << (F - e_b),  F = max(sa_in + e_w, e_b)
+//   t' = leaky ? max(t, 8 t) : t         LeakyReLU(0.125) scaled by 8, F' = F + 3
+//   q  = clamp(RNE(t' * 2^-sh), +-127)   sh = F' - sa_out
+// Restates models/slim_yolo_v2.py:220-231 + :33-38 exactly in integers;
+// shift composition as programmed by c_embedding/yolo_forward.c:233-257.
+struct Requant {
+    int shl;
+    int sh;
+    int leaky;
+    int guard_log2;   // guard trips when |t'| >= 2^guard_log2 ( >= 31: never )
+};
+
+struct Counters {
+    unsigned int absmax;      // max |t'| (stats mode)
+    unsigned int in_sat;      // layer 0 only: clamped input pixels
+    unsigned long long sat;   // clamped outputs
+    unsigned long long guard; // head-room violations
+};
+
+struct ConvParams {
+    const int8_t *in;     // int8 NHWC with halo  [B][H+2][W+2][CIN]
+    int8_t *out;          // int8 NHWC [B][Ho+2h][Wo+2h][cstride]
+    const int8_t *w;      // fragment-packed weights
+    const int *bias_t;    // [cout_pad]
+    Counters *ctr;
+    int B, H, W;          // input feature-map size (unpadded)
+    int cstride;          // channels of the output buffer
+    int out_halo;         // 1: output buffer carries a zero halo
+    int tiles_x, tiles_y, nblk;
+    Requant rq;
+    int mode;             // 0 run, 1 statistics only
+    int guard;            // evaluate the head-room guard
+};
+
+struct Conv1Params {
+    const float *x;       // fp32 NCHW [B][3][H][W]
+    int8_t *out;          // int8 NHWC16 with halo [B][H/2+2][W/2+2][16]
+    const int8_t *w;      // 64 lanes x 16 B fragment
+    const int *bias_t;    // [16]
+    Counters *ctr;
+    int B, H, W;
+    int tiles_x, tiles_y;
+    float in_scale;       // 2^sa[0]
+    Requant rq;
+    int mode;
+    int guard;
+};
+
+__device__ __forceinline__ int y355_rne_shift(int t, int sh) {
+    if (sh > 0) {
+        return (t + ((1 << (sh - 1)) - 1) + ((t >> sh) & 1)) >> sh;
+    }
+    return t * (1 << (-sh));
+}
+
+__device__ __forceinline__ int y355_pre(int acc, int bias, const Requant &rq) {
+    int t = acc * (1 << rq.shl) + bias;
+    if (rq.leaky) t = max(t, t * 8);
+    return t;
+}
+
+__device__ __forceinline__ int y355_clamp8(int q) { return min(127, max(-127, q)); }
+
+// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous chunk of tile ids
+// so neighbouring tiles (shared halo rows, same weights) hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int y355_xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ unsigned int y355_wave_max_u32(unsigned int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+// ---- host-side launch table --------------------------------------------------------------
+struct ConvKernelInfo {
+    int cin, bn, th, tw, pool, wm, wn;
+    int nt, ks;
+    size_t lds_bytes;
+    void (*launch)(const ConvParams &p, int nblocks, hipStream_t s);
+    int (*prepare)(void);     // one-time hipFuncSetAttribute
+};
+
+// pack q_w[cout][cin][3][3] into the fragment order kernel `ki` streams (host buffers).
+void y355_pack_weights(const ConvKernelInfo &ki, const int8_t *q_w, int cout, int cin,
+                       int cout_pad, int8_t *dst);
+size_t y355_packed_bytes(const ConvKernelInfo &ki, int cout_pad);
+const ConvKernelInfo *y355_conv_kernel(int id);
+enum {
+    Y355_K_CONV2 = 0, Y355_K_CONV3_1, Y355_K_CONV3_2, Y355_K_CONV4_1, Y355_K_CONV4_2,
+    Y355_K_CONV5, Y355_K_CONV67, Y355_K_PRED,
+    Y355_K_GEN16, Y355_K_GEN32, Y355_K_GEN64, Y355_K_GEN128, Y355_K_GEN256,
+    Y355_K_GEN16P, Y355_K_GEN32P, Y355_K_GEN64P, Y355_K_GEN128P, Y355_K_GEN256P,
+    Y355_K_COUNT
+};
+
+void y355_launch_conv1(const Conv1Params &p, hipStream_t s);
+void y355_conv1_tiles(int H, int W, int *tx, int *ty);
+void y355_pack_conv1(const int8_t *q_w /*[16][3][3][3]*/, int8_t *dst /*1024*/);
+
+struct HeadParams {
+    const int8_t *pred;   // [B][Hs][Ws][cstride] int8
+    int cstride;
+    int Hs, Ws, A, C;
+    float dq;             // 2^-sa_pred
+    float in_w, in_h;     // network input size in pixels
+    float anchors[32];
+    float conf_thresh, nms_thresh;
+    float *cand_box;      // [B][N][4]
+    float *cand_score;    // [B][N]
+    int *cand_cls;        // [B][N]
+    int max_det;
+    float *out_box;
+    float *out_score;
+    int *out_cls;
+    int *out_count;
+};
+#define Y355_NMS_CAP 4096   // anchors per image the NMS workspace is sized for
+// decode + compact + sort, suppression bit-matrix, ordered scan (head_nms.hip).
+// Workspace (per image): cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP], order i32[CAP],
+// count i32, mask u64[CAP][64].  `mid` (optional) is recorded between decode and NMS.
+void y355_launch_head_nms(const HeadParams &p, int batch, void *cbox, void *cscore, void *ccls, void *order,
+                          void *count, void *mask, hipStream_t s, hipEvent_t mid);
+void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStream_t s);

@@ -1,0 +1,94 @@
+"""ctypes binding of include/yolo355.h.  Fails loudly when libyolo355.so is absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo355.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "yolo355.h"))
+
+MAX_ANCHORS = 16
+NUM_TIMERS = 12
+F_GUARD, F_TAP = 1, 2
+OP_LEAKY, OP_POOL = 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("num_classes", C.c_int32), ("num_anchors", C.c_int32),
+                ("anchors", C.c_float * (2 * MAX_ANCHORS)),
+                ("conf_thresh", C.c_float), ("nms_thresh", C.c_float),
+                ("max_batch", C.c_int32), ("max_det", C.c_int32), ("stream", C.c_void_p)]
+
+
+class LayerStats(C.Structure):
+    _fields_ = [("absmax_t", C.c_int64), ("frac_bits", C.c_int32), ("reserved", C.c_int32),
+                ("saturated", C.c_int64), ("guard", C.c_int64)]
+
+
+class Y355Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("yolo355 error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+P = C.POINTER
+_SIGS = {
+    "y355_last_error": (C.c_char_p, []),
+    "y355_version": (C.c_int, []),
+    "y355_create": (C.c_int, [P(Config), P(C.c_void_p)]),
+    "y355_destroy": (None, [C.c_void_p]),
+    "y355_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "y355_load_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y355_set_act_exponents": (C.c_int, [C.c_void_p, P(C.c_int32)]),
+    "y355_get_act_exponents": (C.c_int, [C.c_void_p, P(C.c_int32)]),
+    "y355_set_act_exponent": (C.c_int, [C.c_void_p, C.c_int, C.c_int32]),
+    "y355_set_retune": (C.c_int, [C.c_void_p, P(C.c_int32)]),
+    "y355_input_absmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, P(C.c_float)]),
+    "y355_run_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "y355_layer_stats_get": (C.c_int, [C.c_void_p, C.c_int, P(LayerStats)]),
+    "y355_get_feature": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "y355_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_forward_counters": (C.c_int, [C.c_void_p, P(C.c_int64), P(C.c_int64)]),
+    "y355_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_max_det": (C.c_int, [C.c_void_p]),
+    "y355_num_anchors_total": (C.c_int, [C.c_void_p]),
+    "y355_conv3x3_i8_fused": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, P(LayerStats)]),
+    "y355_head_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_sync": (C.c_int, [C.c_void_p]),
+    "y355_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "y355_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
+}
+
+
+def lib():
+    """Load libyolo355.so (built by `make -C csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "yolo355: %s is missing -- build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Y355Error(rc, lib().y355_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def declared_symbols():
+    """Function names declared in include/yolo355.h (used by the export test)."""
+    import re
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(y355_[a-z0-9_]+)\s*\(", text)))

@@ -1,0 +1,240 @@
+"""Python handle over the C ABI (include/yolo355.h).  One Engine = one GPU + one stream.
+
+The engine is the batched, integer implementation of
+SlimYOLOv2_quantize_bnfuse.forward(x, quantization=True) (models/slim_yolo_v2.py:212-358).
+PyTorch is used only for device memory and the stream; all compute is in libyolo355.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .prep import RETUNE, RangeTracker
+
+NUM_LAYERS = 10
+LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7", "pred"]
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("yolo355 needs an MI355X (HIP) device; no GPU is visible and there is no CPU fallback")
+    dev = torch.device(device if device is not None else "cuda:0")
+    if dev.type != "cuda":
+        raise RuntimeError("yolo355 engines live on a GPU; got device %r" % (device,))
+    return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+class Engine:
+    def __init__(self, input_size, num_classes, anchors, conf_thresh=0.01, nms_thresh=0.5,
+                 max_batch=1, max_det=0, device=None):
+        self._h = None
+        lib = _ffi.lib()
+        self.device = _require_gpu(device)
+        self.input_size = [int(input_size[0]), int(input_size[1])]
+        self.num_classes = int(num_classes)
+        self.anchors = [[float(a), float(b)] for a, b in anchors]
+        self.max_batch = int(max_batch)
+        cfg = _ffi.Config()
+        cfg.device_id = self.device.index
+        cfg.height, cfg.width = self.input_size
+        cfg.num_classes = self.num_classes
+        cfg.num_anchors = len(self.anchors)
+        for i, (w, h) in enumerate(self.anchors):
+            cfg.anchors[2 * i], cfg.anchors[2 * i + 1] = w, h
+        cfg.conf_thresh, cfg.nms_thresh = float(conf_thresh), float(nms_thresh)
+        cfg.max_batch, cfg.max_det = self.max_batch, int(max_det)
+        with torch.cuda.device(self.device):
+            self._stream = torch.cuda.current_stream(self.device)
+            cfg.stream = C.c_void_p(self._stream.cuda_stream)
+            h = C.c_void_p()
+            _ffi.check(lib.y355_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.max_det = lib.y355_max_det(h)
+        self.num_anchors_total = lib.y355_num_anchors_total(h)
+        self.conf_thresh, self.nms_thresh = float(conf_thresh), float(nms_thresh)
+        self._out = None
+
+    def close(self):
+        if self._h is not None:
+            self._lib.y355_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights / exponents
+    def load_layer(self, idx, q_w, q_b, e_w, e_b):
+        qw = np.ascontiguousarray(q_w, dtype=np.int8)
+        qb = np.ascontiguousarray(q_b, dtype=np.int32)
+        if np.abs(np.asarray(q_w)).max() > 127:
+            raise ValueError("|q_w| > 127")
+        _ffi.check(self._lib.y355_load_layer(self._h, idx, qw.ctypes.data, qb.ctypes.data,
+                                             qw.shape[0], qw.shape[1], int(e_w), int(e_b)))
+
+    def load_quantized(self, qlayers):
+        """qlayers: 10 dicts with q_w [cout,cin,3,3], q_b [cout], e_w, e_b (conv1..conv7, pred)."""
+        for i, L in enumerate(qlayers):
+            self.load_layer(i, L["q_w"], L["q_b"], L["e_w"], L["e_b"])
+
+    def set_act_exponents(self, sa):
+        arr = (C.c_int32 * 11)(*[int(v) for v in sa])
+        _ffi.check(self._lib.y355_set_act_exponents(self._h, arr))
+
+    def get_act_exponents(self):
+        arr = (C.c_int32 * 11)()
+        _ffi.check(self._lib.y355_get_act_exponents(self._h, arr))
+        return list(arr)
+
+    def set_retune(self, retune=RETUNE):
+        arr = (C.c_int32 * 10)(*[int(v) for v in retune])
+        _ffi.check(self._lib.y355_set_retune(self._h, arr))
+
+    def set_thresholds(self, conf_thresh, nms_thresh):
+        self.conf_thresh, self.nms_thresh = float(conf_thresh), float(nms_thresh)
+        _ffi.check(self._lib.y355_set_thresholds(self._h, self.conf_thresh, self.nms_thresh))
+
+    # ------------------------------------------------------------------ inputs
+    def _dev_input(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        if x.dim() != 4 or x.shape[1] != 3 or list(x.shape[2:]) != self.input_size:
+            raise ValueError("expected [B,3,%d,%d], got %s" % (self.input_size[0], self.input_size[1], tuple(x.shape)))
+        if x.shape[0] > self.max_batch:
+            raise ValueError("batch %d > max_batch %d" % (x.shape[0], self.max_batch))
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ calibration
+    def calibrate(self, x, trackers, freeze=True):
+        """Run the tracker semantics of models/slim_yolo_v2.py:16-38 layer by layer on the GPU.
+        trackers: 11 prep.RangeTracker (input, conv1..conv7, pred), updated in place
+        (first call: scale = 127/max; frozen: unchanged; else EMA).  Leaves the engine's
+        feature maps and exponents as the reference's forward would.  Returns the exponents."""
+        xd = self._dev_input(x)
+        B = xd.shape[0]
+        lib, h = self._lib, self._h
+        m = C.c_float()
+        _ffi.check(lib.y355_input_absmax(h, xd.data_ptr(), B, C.byref(m)))
+        sa = [trackers[0].update(m.value, freeze)]
+        _ffi.check(lib.y355_set_act_exponent(h, 0, sa[0]))
+        st = _ffi.LayerStats()
+        for k in range(NUM_LAYERS):
+            xp = xd.data_ptr() if k == 0 else None
+            _ffi.check(lib.y355_run_layer(h, k, B, 1, xp))
+            _ffi.check(lib.y355_layer_stats_get(h, k, C.byref(st)))
+            # max|y| as the fp32 value the reference's activation.abs().max() returns
+            ymax = np.float32(st.absmax_t) * np.float32(2.0 ** (-st.frac_bits))
+            sa.append(trackers[k + 1].update(ymax, freeze))
+            _ffi.check(lib.y355_set_act_exponent(h, k + 1, sa[-1]))
+            _ffi.check(lib.y355_run_layer(h, k, B, 0, xp))
+        return sa
+
+    def layer_stats(self, idx):
+        st = _ffi.LayerStats()
+        _ffi.check(self._lib.y355_layer_stats_get(self._h, idx, C.byref(st)))
+        return dict(absmax_t=st.absmax_t, frac_bits=st.frac_bits, saturated=st.saturated, guard=st.guard)
+
+    def get_feature(self, idx, batch):
+        """int8 [B,C,Ho,Wo] output of layer idx of the last run (parity tap)."""
+        cout = [16, 32, 64, 64, 128, 128, 256, 256, 256, len(self.anchors) * (5 + self.num_classes)][idx]
+        div = [2, 4, 4, 8, 8, 16, 16, 16, 16, 16][idx]
+        out = np.empty((batch, cout, self.input_size[0] // div, self.input_size[1] // div), dtype=np.int8)
+        _ffi.check(self._lib.y355_get_feature(self._h, idx, batch, out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------ the hot path
+    def _buffers(self, B):
+        if self._out is None or self._out[0].shape[0] < B:
+            md = self.max_det
+            self._out = (torch.empty((self.max_batch, md, 4), dtype=torch.float32, device=self.device),
+                         torch.empty((self.max_batch, md), dtype=torch.float32, device=self.device),
+                         torch.empty((self.max_batch, md), dtype=torch.int32, device=self.device),
+                         torch.zeros((self.max_batch,), dtype=torch.int32, device=self.device))
+        return self._out
+
+    def forward_device(self, xd, flags=0, out=None):
+        """Asynchronous batched forward on device tensors.  xd: CUDA float32 [B,3,H,W] contiguous.
+        Returns (boxes [max_batch,max_det,4], scores, cls int32, count int32) device tensors,
+        rows >= B / entries >= count[b] undefined."""
+        B = xd.shape[0]
+        ob, os_, oc, on = out if out is not None else self._buffers(B)
+        _ffi.check(self._lib.y355_forward(self._h, xd.data_ptr(), B, int(flags), ob.data_ptr(), os_.data_ptr(),
+                                          oc.data_ptr(), on.data_ptr()))
+        return ob, os_, oc, on
+
+    def forward(self, x, find=False, tap=False):
+        """list of (bboxes float32 [n,4], scores float32 [n], cls_inds int64 [n]) per image,
+        in anchor-index order: the reference's eval-mode return for every image of the batch."""
+        xd = self._dev_input(x)
+        B = xd.shape[0]
+        flags = (_ffi.F_GUARD if find else 0) | (_ffi.F_TAP if tap else 0)
+        ob, os_, oc, on = self.forward_device(xd, flags)
+        n = on[:B].cpu().numpy()
+        if find:
+            sat, guard = self.counters()
+            if guard:
+                print("too high!!!")
+                raise AssertionError("conv output exceeds the 16-bit head-room (find=True): %d positions" % guard)
+        boxes, scores, cls = ob[:B].cpu().numpy(), os_[:B].cpu().numpy(), oc[:B].cpu().numpy()
+        return [(boxes[i, :n[i]].copy(), scores[i, :n[i]].copy(), cls[i, :n[i]].astype(np.int64))
+                for i in range(B)]
+
+    def counters(self):
+        s, g = C.c_int64(), C.c_int64()
+        _ffi.check(self._lib.y355_forward_counters(self._h, C.byref(s), C.byref(g)))
+        return s.value, g.value
+
+    def candidates(self, batch):
+        N = self.num_anchors_total
+        b = np.empty((batch, N, 4), np.float32)
+        s = np.empty((batch, N), np.float32)
+        c = np.empty((batch, N), np.int32)
+        _ffi.check(self._lib.y355_get_candidates(self._h, batch, b.ctypes.data, s.ctypes.data, c.ctypes.data))
+        return b, s, c
+
+    def head_nms(self, pred_q, sa_pred):
+        """Head only (slim_yolo_v2.py:330-358) on an int8 pred tensor [B,A*(5+C),Hs,Ws]."""
+        pq = np.ascontiguousarray(pred_q, dtype=np.int8)
+        B, md = pq.shape[0], self.max_det
+        b = np.empty((B, md, 4), np.float32)
+        s = np.empty((B, md), np.float32)
+        c = np.empty((B, md), np.int32)
+        n = np.empty((B,), np.int32)
+        _ffi.check(self._lib.y355_head_nms(self._h, pq.ctypes.data, B, int(sa_pred), b.ctypes.data, s.ctypes.data,
+                                           c.ctypes.data, n.ctypes.data))
+        return [(b[i, :n[i]].copy(), s[i, :n[i]].copy(), c[i, :n[i]].astype(np.int64)) for i in range(B)]
+
+    def sync(self):
+        _ffi.check(self._lib.y355_sync(self._h))
+
+    def profile(self, enable=True):
+        _ffi.check(self._lib.y355_profile(self._h, 1 if enable else 0))
+
+    def profile_ms(self):
+        arr = (C.c_float * _ffi.NUM_TIMERS)()
+        _ffi.check(self._lib.y355_profile_get(self._h, arr))
+        return list(arr)
+
+
+def conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=True, pool=False, device_id=0):
+    """Operator-level fused layer (y355_conv3x3_i8_fused): numpy int8 NCHW in/out."""
+    lib = _ffi.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("yolo355 needs a GPU; there is no CPU fallback")
+    qi = np.ascontiguousarray(q_in, dtype=np.int8)
+    qw = np.ascontiguousarray(q_w, dtype=np.int8)
+    qb = np.ascontiguousarray(q_b, dtype=np.int32)
+    B, cin, H, W = qi.shape
+    cout = qw.shape[0]
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = np.empty((B, cout, Ho, Wo), np.int8)
+    st = _ffi.LayerStats()
+    flags = (_ffi.OP_LEAKY if leaky else 0) | (_ffi.OP_POOL if pool else 0)
+    _ffi.check(lib.y355_conv3x3_i8_fused(int(device_id), qi.ctypes.data, qw.ctypes.data, qb.ctypes.data, B, cin, cout,
+                                         H, W, int(sa_in), int(e_w), int(e_b), int(sa_out), flags,
+                                         out.ctypes.data, C.byref(st)))
+    return out, dict(absmax_t=st.absmax_t, frac_bits=st.frac_bits, saturated=st.saturated, guard=st.guard)
