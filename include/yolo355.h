@@ -50,7 +50,8 @@ typedef struct y355_config {
     float nms_thresh;             /* :42, used at :171 */
     int32_t max_batch;
     int32_t max_det;              /* per-image cap of returned detections; 0 = all anchors */
-    void *stream;                 /* hipStream_t to launch on; NULL = engine-owned stream */
+    void *stream;                 /* hipStream_t to launch on; NULL = the default (null) stream */
+    int32_t own_stream;           /* 1: ignore `stream`, create an engine-owned non-blocking stream */
 } y355_config;
 
 /* per-layer counters of the last run of that layer */

@@ -29,10 +29,24 @@ def dets_match(ref, got, box_tol=2e-5, score_tol=2e-6, all_scores=None):
     q = max(box_tol, 1e-6)
 
     def keyset(b, s, c):
-        return {(tuple(np.round(bb / q).astype(np.int64)), int(cc)): float(ss)
-                for bb, ss, cc in zip(b, s, c)}
+        # boxes clamped to the image border can coincide: the k-th occurrence (anchor order)
+        # of a (box, class) pair is its own key
+        out, seen = {}, {}
+        for bb, ss, cc in zip(b, s, c):
+            k0 = (tuple(np.round(bb / q).astype(np.int64)), int(cc))
+            n = seen.get(k0, 0)
+            seen[k0] = n + 1
+            out[k0 + (n,)] = float(ss)
+        return out
     R, G = keyset(rb, rs, rc), keyset(gb, gs, gc)
     only = sorted([R[k] for k in R if k not in G] + [G[k] for k in G if k not in R], reverse=True)
+    if not only:
+        # same boxes and classes on both sides: the strict test failed on a score or a count
+        if len(R) != len(rs) or len(G) != len(gs):
+            return False, "duplicate boxes: ref %d/%d got %d/%d" % (len(R), len(rs), len(G), len(gs))
+        worst = max(abs(R[k] - G[k]) for k in R)
+        ok = all(abs(R[k] - G[k]) <= score_tol + 1e-5 * abs(R[k]) for k in R)
+        return ok, "same boxes, max score diff %.3g" % worst
     pool = np.sort(np.asarray(all_scores if all_scores is not None else np.concatenate([rs, gs]),
                               dtype=np.float64))
     tol = max(score_tol, 1e-9)

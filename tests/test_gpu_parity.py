@@ -69,6 +69,17 @@ def test_single_layer_shapes(cin, cout, h, w, leaky, pool):
         assert st["saturated"] == nsat
 
 
+@pytest.mark.parametrize("sa_in,e_w,e_b,sa_out", [(2, 3, 22, 5), (6, 9, 2, 3), (0, 0, 30, 20), (7, 12, 12, 30)])
+def test_single_layer_wide_epilogue(sa_in, e_w, e_b, sa_out):
+    """exponent gaps that overflow the 32-bit epilogue take the 64-bit kernels (bit-exact too)"""
+    q_in, q_w, q_b = _rand_i8(11, (1, 64, 9, 12)), _rand_i8(12, (48, 64, 3, 3)), _rand_i8(13, (48,))
+    for leaky, pool in ((True, False), (False, False)):
+        ref, tmax, Fx, nsat = _oracle_layer(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky, pool)
+        out, st = conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=leaky, pool=pool)
+        assert np.array_equal(out, ref)
+        assert (st["absmax_t"], st["frac_bits"], st["saturated"]) == (tmax, Fx, nsat)
+
+
 def _build(tag, golden, max_batch=1, max_det=0):
     wkw, anchors, pattern = E2E[tag]
     meta = [int(v) for v in golden[tag + "/meta"]]

@@ -12,9 +12,12 @@
 // slots multiplied by zero weights.  GEMM rows are ordered as 2x2 pooling windows so the
 // pool is a max over the lane's four accumulators BEFORE the (monotone) epilogue.
 #include "y355_common.h"
+#include <type_traits>
 
-template <int TW>
+template <int TW, bool WIDE>
 __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
+    using T = typename std::conditional<WIDE, long long, int>::type;
+    using U = typename UnsignedOf<T>::type;
     constexpr int TH = 16;
     constexpr int PW = TW + 2, PH = TH + 2;
     constexpr int NW = (TH / 2) * (TW / 2);        // pooling windows per tile
@@ -73,11 +76,14 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
     const v4i bw = *(const v4i *)(p.w + lane * 16);
-    const int bias = p.bias_t[li];
+    T bias;
+    if constexpr (WIDE) bias = p.bias_w[li];
+    else bias = p.bias_t[li];
     const Requant rq = p.rq;
-    const unsigned int gthr = (!p.guard || rq.guard_log2 >= 31) ? 0xffffffffu : (1u << rq.guard_log2);
+    const U gthr = (!p.guard || rq.guard_log2 >= (WIDE ? 63 : 31)) ? ~(U)0 : ((U)1 << rq.guard_log2);
     const int Ho = H >> 1, Wo = W >> 1;
-    unsigned int amax = 0, nsat = 0, nguard = 0;
+    U amax = 0;
+    unsigned int nsat = 0, nguard = 0;
 
     for (int mt = wave; mt < MT_TOT; mt += 4) {
         const int row = mt * 16 + li;
@@ -98,20 +104,20 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
         const bool valid = ((y0 >> 1) + wy < Ho) && ((x0 >> 1) + wx < Wo);
         const int vmax = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
         const int vmin = min(min(acc[0], acc[1]), min(acc[2], acc[3]));
-        const int tp = y355_pre(vmax, bias, rq);
-        const int tn = y355_pre(vmin, bias, rq);
-        const unsigned int am = max((unsigned int)abs(tp), (unsigned int)abs(tn));
-        amax = max(amax, valid ? am : 0u);
+        const T tp = y355_pre<T>(vmax, bias, rq);
+        const T tn = y355_pre<T>(vmin, bias, rq);
+        const U am = max(y355_uabs<T>(tp), y355_uabs<T>(tn));
+        amax = max(amax, valid ? am : (U)0);
         nguard += (valid && am >= gthr) ? 1u : 0u;
-        const int qq = y355_rne_shift(tp, rq.sh);
-        const int q = y355_clamp8(qq);
-        nsat += (valid && q != qq) ? 1u : 0u;
+        const T qq = y355_rne_shift<T>(tp, rq.sh);
+        const int q = y355_clamp8<T>(qq);
+        nsat += (valid && (T)q != qq) ? 1u : 0u;
         otile[wo * 16 + li] = (unsigned char)(q & 0xff);
     }
 
     if (p.mode == 1) {
-        amax = y355_wave_max_u32(amax);
-        if (lane == 0) atomicMax(&p.ctr->absmax, amax);
+        const unsigned long long wmax = y355_wave_max_u64((unsigned long long)amax);
+        if (lane == 0) atomicMax(&p.ctr->absmax, wmax);
         return;
     }
     __syncthreads();
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
     }
     if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
     if (nguard) atomicAdd(&p.ctr->guard, (unsigned long long)nguard);
-    if (nsat_in) atomicAdd(&p.ctr->in_sat, nsat_in);
+    if (nsat_in) atomicAdd(&p.ctr->in_sat, (unsigned long long)nsat_in);
 }
 
 static int conv1_tw(int W) { return (W % 104 == 0) ? 104 : 32; }
@@ -137,10 +143,14 @@ void y355_conv1_tiles(int H, int W, int *tx, int *ty) {
 
 void y355_launch_conv1(const Conv1Params &p, hipStream_t s) {
     const int n = p.tiles_x * p.tiles_y * p.B;
-    if (conv1_tw(p.W) == 104)
-        hipLaunchKernelGGL((conv1_kernel<104>), dim3(n), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((conv1_kernel<32>), dim3(n), dim3(256), 0, s, p);
+    const bool big = conv1_tw(p.W) == 104;
+    if (p.rq.wide) {
+        if (big) hipLaunchKernelGGL((conv1_kernel<104, true>), dim3(n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv1_kernel<32, true>), dim3(n), dim3(256), 0, s, p);
+    } else {
+        if (big) hipLaunchKernelGGL((conv1_kernel<104, false>), dim3(n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv1_kernel<32, false>), dim3(n), dim3(256), 0, s, p);
+    }
 }
 
 // B fragment of the single k-step: lane (g = filter row, j = cout) holds k = 4*d + c for

@@ -18,6 +18,7 @@
 //     into VGPRs (coalesced dwordx4, one k-step ahead) -- no LDS traffic and no barrier in
 //     the K loop.
 #include "y355_common.h"
+#include <type_traits>
 
 template <int CIN>
 struct KGeom {
@@ -44,7 +45,7 @@ __device__ __forceinline__ void store_bytes(int8_t *dst, const int (&q)[NT]) {
     }
 }
 
-template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool STATS>
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool STATS, bool WIDE>
 __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
     using G = KGeom<CIN>;
     constexpr int PW = TW + 2, PH = TH + 2, NPIX = PH * PW;
@@ -176,12 +177,18 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
     // ---- epilogue
     const Requant rq = p.rq;
     const int nlane = nb * BN + wn * (NT * 16) + li * NT;
-    int bias[NT];
+    using T = typename std::conditional<WIDE, long long, int>::type;
+    using U = typename UnsignedOf<T>::type;
+    T bias[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bias[t] = p.bias_t[nlane + t];
+    for (int t = 0; t < NT; ++t) {
+        if constexpr (WIDE) bias[t] = p.bias_w[nlane + t];
+        else bias[t] = p.bias_t[nlane + t];
+    }
 
-    unsigned int amax = 0, nsat = 0, nguard = 0;
-    const unsigned int gthr = (!p.guard || rq.guard_log2 >= 31) ? 0xffffffffu : (1u << rq.guard_log2);
+    U amax = 0;
+    unsigned int nsat = 0, nguard = 0;
+    const U gthr = (!p.guard || rq.guard_log2 >= (WIDE ? 63 : 31)) ? ~(U)0 : ((U)1 << rq.guard_log2);
 
     if constexpr (STATS) {
 #pragma unroll
@@ -201,13 +208,13 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
                 const bool valid = (row < BM) && (y0 + oy < H) && (x0 + ox < W);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int tp = y355_pre(acc[m][t][r], bias[t], rq);
-                    amax = max(amax, valid ? (unsigned int)abs(tp) : 0u);
+                    const T tp = y355_pre<T>(acc[m][t][r], bias[t], rq);
+                    amax = max(amax, valid ? y355_uabs<T>(tp) : (U)0);
                 }
             }
         }
-        amax = y355_wave_max_u32(amax);
-        if (lane == 0) atomicMax(&p.ctr->absmax, amax);
+        const unsigned long long wmax = y355_wave_max_u64((unsigned long long)amax);
+        if (lane == 0) atomicMax(&p.ctr->absmax, wmax);
     } else if constexpr (POOL) {
         const int halo = p.out_halo;
         const int Ho = H >> 1, Wo = W >> 1;
@@ -223,13 +230,13 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
             for (int t = 0; t < NT; ++t) {
                 const v4i a = acc[m][t];
                 const int vmax = max(max(a[0], a[1]), max(a[2], a[3]));
-                const int tp = y355_pre(vmax, bias[t], rq);
+                const T tp = y355_pre<T>(vmax, bias[t], rq);
                 const int vmin = min(min(a[0], a[1]), min(a[2], a[3]));
-                const int tn = y355_pre(vmin, bias[t], rq);
-                nguard += (valid && max((unsigned int)abs(tp), (unsigned int)abs(tn)) >= gthr) ? 1u : 0u;
-                const int qq = y355_rne_shift(tp, rq.sh);
-                q[t] = y355_clamp8(qq);
-                nsat += (valid && q[t] != qq) ? 1u : 0u;
+                const T tn = y355_pre<T>(vmin, bias[t], rq);
+                nguard += (valid && max(y355_uabs<T>(tp), y355_uabs<T>(tn)) >= gthr) ? 1u : 0u;
+                const T qq = y355_rne_shift<T>(tp, rq.sh);
+                q[t] = y355_clamp8<T>(qq);
+                nsat += (valid && (T)q[t] != qq) ? 1u : 0u;
             }
             if (valid)
                 store_bytes<NT>(outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.cstride + nlane, q);
@@ -249,11 +256,11 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
                 int q[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int tp = y355_pre(acc[m][t][r], bias[t], rq);
-                    nguard += (valid && (unsigned int)abs(tp) >= gthr) ? 1u : 0u;
-                    const int qq = y355_rne_shift(tp, rq.sh);
-                    q[t] = y355_clamp8(qq);
-                    nsat += (valid && q[t] != qq) ? 1u : 0u;
+                    const T tp = y355_pre<T>(acc[m][t][r], bias[t], rq);
+                    nguard += (valid && y355_uabs<T>(tp) >= gthr) ? 1u : 0u;
+                    const T qq = y355_rne_shift<T>(tp, rq.sh);
+                    q[t] = y355_clamp8<T>(qq);
+                    nsat += (valid && (T)q[t] != qq) ? 1u : 0u;
                 }
                 if (valid)
                     store_bytes<NT>(outb + ((size_t)(gy + halo) * (W + 2 * halo) + gx + halo) * p.cstride + nlane, q);
@@ -269,18 +276,25 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN>
 struct ConvInst {
     static constexpr size_t LDS = (size_t)(TH + 2) * (TW + 2) * KGeom<CIN>::STRIDE + 64;
+    template <bool ST, bool WD>
+    static void go(const ConvParams &p, int nblocks, hipStream_t s) {
+        hipLaunchKernelGGL((conv3x3_i8_kernel<CIN, BN, TH, TW, POOL, WM, WN, ST, WD>), dim3(nblocks), dim3(256), LDS, s, p);
+    }
     static void launch(const ConvParams &p, int nblocks, hipStream_t s) {
-        if (p.mode == 1)
-            hipLaunchKernelGGL((conv3x3_i8_kernel<CIN, BN, TH, TW, POOL, WM, WN, true>), dim3(nblocks), dim3(256), LDS, s, p);
-        else
-            hipLaunchKernelGGL((conv3x3_i8_kernel<CIN, BN, TH, TW, POOL, WM, WN, false>), dim3(nblocks), dim3(256), LDS, s, p);
+        if (p.rq.wide) { if (p.mode == 1) go<true, true>(p, nblocks, s); else go<false, true>(p, nblocks, s); }
+        else { if (p.mode == 1) go<true, false>(p, nblocks, s); else go<false, false>(p, nblocks, s); }
+    }
+    template <bool ST, bool WD>
+    static int prep1(void) {
+        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_kernel<CIN, BN, TH, TW, POOL, WM, WN, ST, WD>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     static int prepare(void) {
-        int e = (int)hipFuncSetAttribute((const void *)conv3x3_i8_kernel<CIN, BN, TH, TW, POOL, WM, WN, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        if (e) return e;
-        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_kernel<CIN, BN, TH, TW, POOL, WM, WN, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        int e = prep1<true, true>();
+        if (!e) e = prep1<false, true>();
+        if (!e) e = prep1<true, false>();
+        if (!e) e = prep1<false, false>();
+        return e;
     }
     static constexpr ConvKernelInfo info() {
         return ConvKernelInfo{CIN, BN, TH, TW, POOL ? 1 : 0, WM, WN, BN / 16 / WN, KGeom<CIN>::KS, LDS, &launch, &prepare};

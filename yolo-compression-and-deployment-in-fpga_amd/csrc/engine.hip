@@ -52,6 +52,7 @@ struct Layer {
     std::vector<int32_t> q_b;
     int8_t *w_dev = nullptr;
     int *bias_dev = nullptr;
+    long long *bias_w_dev = nullptr;
     int8_t *out_dev = nullptr;
     size_t out_bytes = 0;
     Requant rq{};
@@ -72,34 +73,38 @@ int prepare_kernels() {
 // Fill the integer epilogue of one layer.  Returns Y355_ERANGE when the int32 path could
 // overflow for worst-case operands.
 int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool have_out, int leaky, int retune,
-                 const int32_t *q_b, int cout, int cout_pad, Requant *rq, int *frac_bits, std::vector<int32_t> *bias_t) {
+                 const int32_t *q_b, int cout, int cout_pad, Requant *rq, int *frac_bits, std::vector<int32_t> *bias_t,
+                 std::vector<long long> *bias_w) {
     const int F = std::max(sa_in + e_w, e_b);
     const int shl = F - sa_in - e_w, bshl = F - e_b;
     const int Fp = F + (leaky ? 3 : 0);
-    if (shl > 24 || bshl > 24) return fail(Y355_ERANGE, "exponent gap too large for the int32 epilogue");
+    if (shl > 30 || bshl > 40) return fail(Y355_ERANGE, "exponent gap too large for the fixed-point epilogue");
     long long bmax = 0;
     bias_t->assign(cout_pad, 0);
+    bias_w->assign(cout_pad, 0);
     for (int c = 0; c < cout; ++c) {
         const long long v = (long long)q_b[c] * (1ll << bshl);
         bmax = std::max(bmax, std::llabs(v));
-        (*bias_t)[c] = (int32_t)v;
+        (*bias_w)[c] = v;
+        (*bias_t)[c] = (int32_t)v;     // only used when the 32-bit path is selected below
     }
     long long tmax = ((long long)127 * 127 * 9 * cin_real) * (1ll << shl) + bmax;
     if (leaky) tmax *= 8;
     int sh = have_out ? Fp - sa_out : 0;
-    if (sh > 31) sh = 31;
-    long long lim = tmax;
-    if (sh > 0) lim += (1ll << (sh - 1));
-    if (sh < 0) {
-        if (-sh > 24) return fail(Y355_ERANGE, "output exponent too large");
-        lim = tmax * (1ll << (-sh));
-    }
-    if (lim >= (1ll << 30)) return fail(Y355_ERANGE, "fixed-point epilogue exceeds 30 bits");
+    if (sh > 62) sh = 62;
+    if (sh < -30) return fail(Y355_ERANGE, "output exponent too large");
+    // worst-case magnitude through the rounding add / left shift
+    long double lim = (long double)tmax;
+    if (sh > 0) lim += std::ldexp(1.0L, sh - 1);
+    if (sh < 0) lim = std::ldexp((long double)tmax, -sh);
+    if (lim >= std::ldexp(1.0L, 62)) return fail(Y355_ERANGE, "fixed-point epilogue exceeds 62 bits");
+    rq->wide = lim >= std::ldexp(1.0L, 30) ? 1 : 0;
+    if (!rq->wide && sh > 31) sh = 31;
     rq->shl = shl;
     rq->sh = sh;
     rq->leaky = leaky;
     int g = 15 + Fp - retune;
-    rq->guard_log2 = g < 0 ? 0 : (g > 31 ? 31 : g);
+    rq->guard_log2 = g < 0 ? 0 : (g > 63 ? 63 : g);
     *frac_bits = Fp;
     return 0;
 }
@@ -173,8 +178,8 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     h->max_det = (cfg->max_det <= 0 || cfg->max_det > N) ? N : cfg->max_det;
     for (int i = 0; i < 11; ++i) { h->sa[i] = 0; h->sa_set[i] = false; }
     for (int i = 0; i < 10; ++i) h->retune[i] = kRetuneDefault[i];
-    if (cfg->stream) {
-        h->stream = (hipStream_t)cfg->stream;
+    if (!cfg->own_stream) {
+        h->stream = (hipStream_t)cfg->stream;      // NULL = default stream (torch's default on ROCm)
     } else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
             delete h;
@@ -207,6 +212,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
         L.out_bytes = ((size_t)B * (L.Hout + 2 * L.halo) * (L.Wout + 2 * L.halo) + 64) * L.cout_pad;
         rc = dmalloc(h, (void **)&L.out_dev, L.out_bytes, true);
         if (!rc) rc = dmalloc(h, (void **)&L.bias_dev, sizeof(int) * L.cout_pad, true);
+        if (!rc) rc = dmalloc(h, (void **)&L.bias_w_dev, sizeof(long long) * L.cout_pad, true);
         if (!rc && k > 0) rc = dmalloc(h, (void **)&L.w_dev, y355_packed_bytes(*y355_conv_kernel(L.kid), L.cout_pad), true);
         Hc = L.Hout;
         Wc = L.Wout;
@@ -328,10 +334,12 @@ static int refresh_layer(y355_engine *h, int k, bool need_out) {
     if (need_out && !h->sa_set[k + 1]) return fail(Y355_ENOTREADY, "output activation exponent not set (calibrate first)");
     if (!L.bias_dirty) return 0;
     std::vector<int32_t> bt;
+    std::vector<long long> bw;
     int rc = make_requant(L.cin, h->sa[k], L.e_w, L.e_b, h->sa[k + 1], h->sa_set[k + 1], L.leaky, h->retune[k],
-                          L.q_b.data(), L.cout, L.cout_pad, &L.rq, &L.frac_bits, &bt);
+                          L.q_b.data(), L.cout, L.cout_pad, &L.rq, &L.frac_bits, &bt, &bw);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(L.bias_dev, bt.data(), sizeof(int) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(L.bias_w_dev, bw.data(), sizeof(long long) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));   // bt is a stack-owned vector
     L.bias_dirty = !h->sa_set[k + 1];
     return 0;
@@ -345,6 +353,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.out = L.out_dev;
         p.w = h->w0_dev;
         p.bias_t = L.bias_dev;
+        p.bias_w = L.bias_w_dev;
         p.ctr = h->ctr_dev;
         p.B = B;
         p.H = L.Hin;
@@ -362,6 +371,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.out = L.out_dev;
         p.w = L.w_dev;
         p.bias_t = L.bias_dev;
+        p.bias_w = L.bias_w_dev;
         p.ctr = h->ctr_dev + k;
         p.B = B;
         p.H = L.Hin;
@@ -411,7 +421,7 @@ extern "C" int y355_layer_stats_get(y355_engine *h, int idx, y355_layer_stats *o
     Counters c;
     HIPCHK(hipMemcpyAsync(&c, h->ctr_dev + idx, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    out->absmax_t = c.absmax;
+    out->absmax_t = (int64_t)c.absmax;
     out->frac_bits = h->L[idx].frac_bits;
     out->reserved = (int32_t)c.in_sat;
     out->saturated = (int64_t)c.sat + (idx == 0 ? c.in_sat : 0);
@@ -605,7 +615,8 @@ extern "C" int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const in
     Requant rq{};
     int fb = 0;
     std::vector<int32_t> bt;
-    if (int rc = make_requant(cin, sa_in, e_w, e_b, sa_out, true, leaky, 10, q_b, cout, cout_pad, &rq, &fb, &bt)) return rc;
+    std::vector<long long> bw;
+    if (int rc = make_requant(cin, sa_in, e_w, e_b, sa_out, true, leaky, 10, q_b, cout, cout_pad, &rq, &fb, &bt, &bw)) return rc;
     // host-side layout conversion: NCHW -> NHWC with halo and zero channel padding
     const size_t in_elems = ((size_t)batch * (H + 2) * (W + 2) + 64) * cpad;
     std::vector<int8_t> xin(in_elems, 0);
@@ -620,10 +631,11 @@ extern "C" int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const in
     const size_t out_elems = (size_t)batch * Ho * Wo * cout_pad;
     int8_t *d_in = nullptr, *d_w = nullptr, *d_out = nullptr;
     int *d_b = nullptr;
+    long long *d_bw = nullptr;
     Counters *d_c = nullptr;
     int rc = 0;
     auto cleanup = [&]() {
-        (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_out); (void)hipFree(d_b); (void)hipFree(d_c);
+        (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_out); (void)hipFree(d_b); (void)hipFree(d_bw); (void)hipFree(d_c);
     };
 #define OPCHK(expr)                                                                         \
     do {                                                                                    \
@@ -637,17 +649,19 @@ extern "C" int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const in
     OPCHK(hipMalloc((void **)&d_w, packed.size()));
     OPCHK(hipMalloc((void **)&d_out, out_elems + 64));
     OPCHK(hipMalloc((void **)&d_b, sizeof(int) * cout_pad));
+    OPCHK(hipMalloc((void **)&d_bw, sizeof(long long) * cout_pad));
     OPCHK(hipMalloc((void **)&d_c, sizeof(Counters)));
     OPCHK(hipMemcpy(d_in, xin.data(), in_elems, hipMemcpyHostToDevice));
     OPCHK(hipMemcpy(d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
     OPCHK(hipMemcpy(d_b, bt.data(), sizeof(int) * cout_pad, hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(d_bw, bw.data(), sizeof(long long) * cout_pad, hipMemcpyHostToDevice));
     OPCHK(hipMemset(d_out, 0, out_elems + 64));
     Counters cz{};
     Counters cs{};
     for (int mode = 1; mode >= 0; --mode) {
         OPCHK(hipMemset(d_c, 0, sizeof(Counters)));
         ConvParams p{};
-        p.in = d_in; p.out = d_out; p.w = d_w; p.bias_t = d_b; p.ctr = d_c;
+        p.in = d_in; p.out = d_out; p.w = d_w; p.bias_t = d_b; p.bias_w = d_bw; p.ctr = d_c;
         p.B = batch; p.H = H; p.W = W; p.cstride = cout_pad; p.out_halo = 0;
         p.tiles_x = (W + ki.tw - 1) / ki.tw; p.tiles_y = (H + ki.th - 1) / ki.th; p.nblk = cout_pad / ki.bn;
         p.rq = rq; p.mode = mode; p.guard = 1;
@@ -665,7 +679,7 @@ extern "C" int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const in
                 for (int x = 0; x < Wo; ++x)
                     out[(((size_t)b * cout + c) * Ho + y) * Wo + x] = o[(((size_t)b * Ho + y) * Wo + x) * cout_pad + c];
     if (stats) {
-        stats->absmax_t = cs.absmax;
+        stats->absmax_t = (int64_t)cs.absmax;
         stats->frac_bits = fb;
         stats->reserved = 0;
         stats->saturated = (int64_t)cz.sat;

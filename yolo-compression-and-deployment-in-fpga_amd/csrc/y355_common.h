@@ -15,12 +15,13 @@ struct Requant {
     int shl;
     int sh;
     int leaky;
-    int guard_log2;   // guard trips when |t'| >= 2^guard_log2 ( >= 31: never )
+    int guard_log2;   // guard trips when |t'| >= 2^guard_log2 ( >= 63: never )
+    int wide;         // 1: worst-case |t'| does not fit 30 bits -> 64-bit epilogue kernels
 };
 
 struct Counters {
-    unsigned int absmax;      // max |t'| (stats mode)
-    unsigned int in_sat;      // layer 0 only: clamped input pixels
+    unsigned long long absmax;   // max |t'| (stats mode)
+    unsigned long long in_sat;   // layer 0 only: clamped input pixels
     unsigned long long sat;   // clamped outputs
     unsigned long long guard; // head-room violations
 };
@@ -30,6 +31,7 @@ struct ConvParams {
     int8_t *out;          // int8 NHWC [B][Ho+2h][Wo+2h][cstride]
     const int8_t *w;      // fragment-packed weights
     const int *bias_t;    // [cout_pad]
+    const long long *bias_w;  // [cout_pad] 64-bit copy for the wide epilogue
     Counters *ctr;
     int B, H, W;          // input feature-map size (unpadded)
     int cstride;          // channels of the output buffer
@@ -45,6 +47,7 @@ struct Conv1Params {
     int8_t *out;          // int8 NHWC16 with halo [B][H/2+2][W/2+2][16]
     const int8_t *w;      // 64 lanes x 16 B fragment
     const int *bias_t;    // [16]
+    const long long *bias_w;
     Counters *ctr;
     int B, H, W;
     int tiles_x, tiles_y;
@@ -54,20 +57,30 @@ struct Conv1Params {
     int guard;
 };
 
-__device__ __forceinline__ int y355_rne_shift(int t, int sh) {
+template <typename T>
+__device__ __forceinline__ T y355_rne_shift(T t, int sh) {
     if (sh > 0) {
-        return (t + ((1 << (sh - 1)) - 1) + ((t >> sh) & 1)) >> sh;
+        return (t + (((T)1 << (sh - 1)) - 1) + ((t >> sh) & 1)) >> sh;
     }
-    return t * (1 << (-sh));
+    return t * ((T)1 << (-sh));
 }
 
-__device__ __forceinline__ int y355_pre(int acc, int bias, const Requant &rq) {
-    int t = acc * (1 << rq.shl) + bias;
+template <typename T>
+__device__ __forceinline__ T y355_pre(int acc, T bias, const Requant &rq) {
+    T t = (T)acc * ((T)1 << rq.shl) + bias;
     if (rq.leaky) t = max(t, t * 8);
     return t;
 }
 
-__device__ __forceinline__ int y355_clamp8(int q) { return min(127, max(-127, q)); }
+template <typename T> struct UnsignedOf { using type = unsigned int; };
+template <> struct UnsignedOf<long long> { using type = unsigned long long; };
+template <typename T>
+__device__ __forceinline__ typename UnsignedOf<T>::type y355_uabs(T v) {
+    return (typename UnsignedOf<T>::type)(v < 0 ? -v : v);
+}
+
+template <typename T>
+__device__ __forceinline__ int y355_clamp8(T q) { return (int)min((T)127, max((T)-127, q)); }
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous chunk of tile ids
 // so neighbouring tiles (shared halo rows, same weights) hit the same L2.  Bijective for any n.
@@ -79,6 +92,16 @@ __device__ __forceinline__ int y355_xcd_remap(int bid, int n) {
 __device__ __forceinline__ unsigned int y355_wave_max_u32(unsigned int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long y355_wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v, o, 64);
+        const unsigned int hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), o, 64);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w > v ? w : v;
+    }
     return v;
 }
 

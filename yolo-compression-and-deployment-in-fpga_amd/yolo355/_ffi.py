@@ -2,6 +2,11 @@
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  It must be in the process
+# BEFORE libyolo355.so is loaded so that the loader binds both to ONE HIP runtime; loaded the
+# other way round the process ends up with two runtimes and the second sees no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo355.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "yolo355.h"))
@@ -17,7 +22,8 @@ class Config(C.Structure):
                 ("num_classes", C.c_int32), ("num_anchors", C.c_int32),
                 ("anchors", C.c_float * (2 * MAX_ANCHORS)),
                 ("conf_thresh", C.c_float), ("nms_thresh", C.c_float),
-                ("max_batch", C.c_int32), ("max_det", C.c_int32), ("stream", C.c_void_p)]
+                ("max_batch", C.c_int32), ("max_det", C.c_int32), ("stream", C.c_void_p),
+                ("own_stream", C.c_int32)]
 
 
 class LayerStats(C.Structure):

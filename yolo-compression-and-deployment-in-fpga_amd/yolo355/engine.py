@@ -46,7 +46,10 @@ class Engine:
         cfg.max_batch, cfg.max_det = self.max_batch, int(max_det)
         with torch.cuda.device(self.device):
             self._stream = torch.cuda.current_stream(self.device)
+            # launch on torch's current stream (handle 0 = the default stream) so that torch
+            # copies / allocations and the engine's kernels are ordered without extra syncs
             cfg.stream = C.c_void_p(self._stream.cuda_stream)
+            cfg.own_stream = 0
             h = C.c_void_p()
             _ffi.check(lib.y355_create(C.byref(cfg), C.byref(h)))
         self._h = h
