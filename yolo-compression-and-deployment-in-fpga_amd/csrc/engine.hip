@@ -123,9 +123,7 @@ struct y355_engine {
     unsigned int *absmax_dev = nullptr;
     int Hs = 0, Ws = 0, N = 0;
     // head workspace
-    float *cbox = nullptr, *cscore = nullptr;
-    int *ccls = nullptr, *order = nullptr, *count = nullptr;
-    unsigned long long *mask = nullptr;
+    y355_head_ws ws{};
     float *cand_box = nullptr, *cand_score = nullptr;
     int *cand_cls = nullptr;
     // host-call staging
@@ -221,14 +219,15 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, (void **)&h->w0_dev, 1024, true);
     if (!rc) rc = dmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * 10, true);
     if (!rc) rc = dmalloc(h, (void **)&h->absmax_dev, 16, true);
-    if (!rc) rc = dmalloc(h, (void **)&h->cbox, sizeof(float) * 4 * cap * B, false);
-    if (!rc) rc = dmalloc(h, (void **)&h->cscore, sizeof(float) * cap * B, false);
-    if (!rc) rc = dmalloc(h, (void **)&h->ccls, sizeof(int) * cap * B, false);
-    if (!rc) rc = dmalloc(h, (void **)&h->order, sizeof(int) * cap * B, false);
-    if (!rc) rc = dmalloc(h, (void **)&h->count, sizeof(int) * B, true);
-    const size_t rows = ((size_t)N + 63) / 64 * 64;
-    (void)rows;
-    if (!rc) rc = dmalloc(h, (void **)&h->mask, sizeof(unsigned long long) * 64 * cap * B, false);
+    if (!rc) rc = dmalloc(h, &h->ws.cbox, sizeof(float) * 4 * cap * B, false);
+    if (!rc) rc = dmalloc(h, &h->ws.cscore, sizeof(float) * cap * B, false);
+    if (!rc) rc = dmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
+    if (!rc) rc = dmalloc(h, &h->ws.corig, sizeof(int) * cap * B, false);
+    if (!rc) rc = dmalloc(h, &h->ws.count, sizeof(int) * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.mask, sizeof(unsigned long long) * 64 * cap * B, false);
+    if (!rc) rc = dmalloc(h, &h->ws.bstat, 32 * 64 * (size_t)B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.tilemap, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.confl, 8 * 64 * (size_t)B, true);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_cls, sizeof(int) * N * B, false);
@@ -490,8 +489,7 @@ extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int f
     if (prof) HIPCHK(hipEventRecord(h->ev[10], h->stream));
     HeadParams hp = head_params(h, h->sa[10], boxes_dev, scores_dev, cls_dev, count_dev);
     if (!(flags & Y355_F_TAP)) { hp.cand_box = nullptr; hp.cand_score = nullptr; hp.cand_cls = nullptr; }
-    y355_launch_head_nms(hp, batch, h->cbox, h->cscore, h->ccls, h->order, h->count, h->mask, h->stream,
-                         prof ? h->ev[11] : nullptr);
+    y355_launch_head_nms(hp, batch, h->ws, h->stream, prof ? h->ev[11] : nullptr);
     HIPCHK(hipGetLastError());
     if (prof) HIPCHK(hipEventRecord(h->ev[12], h->stream));
     return 0;
@@ -560,7 +558,7 @@ extern "C" int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, in
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(L.out_dev, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
     HeadParams hp = head_params(h, sa_pred, h->o_box, h->o_score, h->o_cls, h->o_count);
-    y355_launch_head_nms(hp, batch, h->cbox, h->cscore, h->ccls, h->order, h->count, h->mask, h->stream, nullptr);
+    y355_launch_head_nms(hp, batch, h->ws, h->stream, nullptr);
     HIPCHK(hipGetLastError());
     const size_t md = h->max_det;
     HIPCHK(hipMemcpyAsync(boxes, h->o_box, sizeof(float) * 4 * md * batch, hipMemcpyDeviceToHost, h->stream));

@@ -1,5 +1,5 @@
-// yolo355 -- detection head on the GPU: decode + score + threshold + sort + per-class greedy
-// NMS, batched (the reference post-processes image 0 only, on the CPU, in Python).
+// yolo355 -- detection head on the GPU: decode + score + threshold + per-class greedy NMS,
+// batched (the reference post-processes image 0 only, on the CPU, in Python).
 //
 // Replaces models/slim_yolo_v2.py:330-358:
 //   head split :330-341   (channel layout [A obj | A*C cls | A*4 txtytwth], anchor-major)
@@ -10,49 +10,72 @@
 // and the C head of c_embedding/yolo_forward.c:965-1147 (get_boxes / conf_sort / NMS).
 //
 // Tie order (undefined in the reference: unstable argsort): (score desc, anchor index asc).
-// Three kernels per batch:
-//   head_kernel  one workgroup per image: decode, compact candidates in anchor order,
-//                bitonic-sort their (score, position) keys in LDS;
-//   mask_kernel  all-pairs "j suppresses/is suppressed by i" bit matrix, 64x64 blocks, upper
-//                triangle only (the transposed block falls out of the wave ballots);
-//   scan_kernel  one wave per image walks candidates in score order holding the "removed"
-//                bit-set one word per lane, rows prefetched 16 ranks ahead; then compacts the
-//                survivors in anchor-index order into the padded outputs.
+//
+// Greedy NMS is a walk over the "i suppresses j" relation in score order.  The relation is
+// sparse (a box only interacts with boxes of similar size whose centre is close), so:
+//   head_kernel  one workgroup per image: decode, threshold, compact the candidates in
+//                (anchor, cell) order -- 64 consecutive candidates then share their anchor and
+//                2-3 grid rows -- and reduce per-64-block extents (centre range, max w/h,
+//                min/max area);
+//   mask_kernel  persistent waves over (image, row-block, col-block >= row-block): a block
+//                pair whose extents prove IoU <= thr for every pair is skipped; otherwise a
+//                64x64 bit tile (+ its transpose, from the wave ballots) is written, with a
+//                per-pair early-out on the same bounds.  Sets a "computed" bit per tile and a
+//                "has conflicts" bit per candidate;
+//   scan_kernel  one workgroup per image: candidates without conflicts are kept outright;
+//                the others are sorted by (score desc, index asc) and resolved serially by one
+//                wave holding the "removed" bit-set one word per lane; survivors are emitted in
+//                anchor-index order into the padded outputs.
+// The early-outs are exact: a pair is skipped only when real IoU < 0.999*thr and the areas are
+// not degenerate, where the fp32 formula of the reference cannot exceed thr.
 #include "y355_common.h"
+#include <cstdlib>
 
 #define NMS_CAP Y355_NMS_CAP   // max anchors per image handled by this head (416x416: 3380)
+#define NBLK (NMS_CAP / 64)
+
+struct BlockStat { float cx0, cx1, cy0, cy1, wmax, hmax, amin, amax; };
 
 struct HeadWork {
-    float *cbox;          // [B][CAP][4]  compacted candidates, anchor order
+    float *cbox;          // [B][CAP][4]  compacted candidates, (anchor, cell) order
     float *cscore;        // [B][CAP]
     int *ccls;            // [B][CAP]
-    int *order;           // [B][CAP]     compact position by descending (score, -pos)
+    int *corig;           // [B][CAP]     anchor index n = cell*A + a of compact position p
     int *count;           // [B]          candidates per image
-    unsigned long long *mask;  // [B][CAP][64]
+    unsigned long long *mask;    // [B][CAP][64]
+    BlockStat *bstat;            // [B][64]
+    unsigned long long *tilemap; // [B][64]  bit cb of word rb: tile (rb,cb) was computed
+    unsigned long long *confl;   // [B][64]  bit per compact position: has a nonzero row
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const HeadWork wk) {
-    __shared__ unsigned long long keys[NMS_CAP];
     __shared__ int wsum[16];
     __shared__ int total;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int A = p.A, C = p.C;
-    const int N = p.Hs * p.Ws * A;
+    const int HW = p.Hs * p.Ws;
+    const int N = HW * A;
+    if (tid < 64) {
+        wk.tilemap[(size_t)b * 64 + tid] = 0ull;
+        wk.confl[(size_t)b * 64 + tid] = 0ull;
+    }
 
     float box[4][4], score[4];
-    int cls[4];
+    int cls[4], orig[4];
     bool valid[4];
     int nvalid = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int n = tid * 4 + u;
+        const int np = tid * 4 + u;          // position in (anchor, cell) order
         valid[u] = false;
         score[u] = 0.f;
         cls[u] = 0;
-        if (n < N) {
-            const int cell = n / A, a = n % A;
+        orig[u] = 0;
+        if (np < N) {
+            const int a = np / HW, cell = np % HW;
+            const int n = cell * A + a;      // the reference's anchor index (:337-341)
             const int gy = cell / p.Ws, gx = cell % p.Ws;
             const int8_t *pp = p.pred + ((size_t)(b * p.Hs + gy) * p.Ws + gx) * p.cstride;
             const float conf = (float)pp[a] * p.dq;
@@ -81,6 +104,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             box[u][3] = fminf(fmaxf((cy + bh / 2) / p.in_h, 0.f), 1.f);
             score[u] = best;
             cls[u] = bc;
+            orig[u] = n;
             valid[u] = best >= p.conf_thresh;
             nvalid += valid[u] ? 1 : 0;
             if (p.cand_score) {      // full per-anchor tap (parity tests)
@@ -112,20 +136,210 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
     float *cs = wk.cscore + (size_t)b * NMS_CAP;
     int *cc = wk.ccls + (size_t)b * NMS_CAP;
+    int *co = wk.corig + (size_t)b * NMS_CAP;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (valid[u]) {
             *(float4 *)(cb + (size_t)pos * 4) = make_float4(box[u][0], box[u][1], box[u][2], box[u][3]);
             cs[pos] = score[u];
             cc[pos] = cls[u];
-            keys[pos] = ((unsigned long long)(~__float_as_uint(score[u])) << 32) | (unsigned int)pos;
+            co[pos] = orig[u];
             ++pos;
         }
     }
-    int P2 = 64;
-    while (P2 < M) P2 <<= 1;
+    if (tid == 0) wk.count[b] = M;
+    __syncthreads();     // the block's global stores are visible to the block after the barrier
+    // ---- per-64-block extents of the compacted list
+    const int nblk = (M + 63) >> 6;
+    for (int k = wave; k < nblk; k += 16) {
+        const int i = k * 64 + lane;
+        const bool v = i < M;
+        const float4 q = v ? *(const float4 *)(cb + (size_t)i * 4) : make_float4(0, 0, 0, 0);
+        const float w = q.z - q.x, h = q.w - q.y;
+        const float cx = 0.5f * (q.x + q.z), cy = 0.5f * (q.y + q.w), ar = w * h;
+        float cx0 = v ? cx : 3e38f, cx1 = v ? cx : -3e38f, cy0 = v ? cy : 3e38f, cy1 = v ? cy : -3e38f;
+        float wm = v ? w : 0.f, hm = v ? h : 0.f, a0 = v ? ar : 3e38f, a1 = v ? ar : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cx0 = fminf(cx0, __shfl_xor(cx0, o, 64));
+            cx1 = fmaxf(cx1, __shfl_xor(cx1, o, 64));
+            cy0 = fminf(cy0, __shfl_xor(cy0, o, 64));
+            cy1 = fmaxf(cy1, __shfl_xor(cy1, o, 64));
+            wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+            hm = fmaxf(hm, __shfl_xor(hm, o, 64));
+            a0 = fminf(a0, __shfl_xor(a0, o, 64));
+            a1 = fmaxf(a1, __shfl_xor(a1, o, 64));
+        }
+        if (lane == 0) {
+            BlockStat s;
+            s.cx0 = cx0; s.cx1 = cx1; s.cy0 = cy0; s.cy1 = cy1;
+            s.wmax = wm; s.hmax = hm; s.amin = a0; s.amax = a1;
+            wk.bstat[(size_t)b * 64 + k] = s;
+        }
+    }
+}
+
+// ---- the reference's suppression test (slim_yolo_v2.py:159-171), same class assumed
+__device__ __forceinline__ bool suppresses_exact(const float4 a, float area_a, const float4 c, float area_c, float thr) {
+    const float xx1 = fmaxf(a.x, c.x), yy1 = fmaxf(a.y, c.y);
+    const float xx2 = fminf(a.z, c.z), yy2 = fminf(a.w, c.w);
+    const float w = fmaxf(1e-28f, xx2 - xx1), h = fmaxf(1e-28f, yy2 - yy1);
+    const float inter = w * h;
+    const float ovr = inter / (area_a + area_c - inter);
+    return !(ovr <= thr);
+}
+// same predicate; the correctly rounded division is only issued when the reciprocal estimate
+// lands within 8 ulp-ish of the threshold (or the union is degenerate)
+__device__ __forceinline__ bool suppresses(const float4 a, float area_a, const float4 c, float area_c, float thr,
+                                           float thr_hi, float thr_lo) {
+    const float xx1 = fmaxf(a.x, c.x), yy1 = fmaxf(a.y, c.y);
+    const float xx2 = fminf(a.z, c.z), yy2 = fminf(a.w, c.w);
+    const float w = fmaxf(1e-28f, xx2 - xx1), h = fmaxf(1e-28f, yy2 - yy1);
+    const float inter = w * h;
+    const float den = area_a + area_c - inter;
+    const float q = inter * __builtin_amdgcn_rcpf(den);
+    const bool normal = den > 1e-30f && den < 1e30f;
+    const bool hi = normal && q > thr_hi, lo = normal && q < thr_lo;
+    bool r = hi;
+    if (__any(!hi && !lo)) {
+        const bool ex = !(inter / den <= thr);
+        r = (hi || lo) ? hi : ex;
+    }
+    return r;
+}
+
+// Exact pruning bounds.  For boxes with IoU > thr:  overlap_x > thr*max(w) hence
+// |dcx| < (wi+wj)/2 - thr*max(wi,wj) <= (1-thr)*(wi+wj)/2 (same in y), and min(area)/max(area) > thr.
+// With a 0.1% margin the fp32 evaluation of the reference formula cannot land above thr either,
+// provided the union is not degenerate (area sum >= 1e-10) and thr >= 1e-4.
+#define PRUNE_MARGIN 1.001f
+#define PRUNE_EPS 1e-6f
+#define AREA_MIN 1e-10f
+
+// grid (NBLK, batch): one workgroup per (image, row-block); its 4 waves walk the column
+// blocks cb >= rb, skipping tiles by the block extents.
+__global__ __launch_bounds__(256) void mask_kernel(const HeadWork wk, float thr, int dbg) {
+    __shared__ BlockStat sstat[64];
+    __shared__ float4 sbox[4][64];
+    __shared__ int scls[4][64];
+    const int b = blockIdx.y, rb = blockIdx.x;
+    const int M = wk.count[b];
+    const int nblk = (M + 63) >> 6;
+    if (rb >= nblk) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < nblk) sstat[threadIdx.x] = wk.bstat[(size_t)b * 64 + threadIdx.x];
+    const bool fast = thr >= 1e-4f && thr < 1e4f;
+    const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
+    const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
+    const float *cbx = wk.cbox + (size_t)b * NMS_CAP * 4;
+    const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
+    const int i = rb * 64 + lane;
+    const bool vi = i < M;
+    const float4 bi = vi ? *(const float4 *)(cbx + (size_t)i * 4) : make_float4(0, 0, 0, 0);
+    const int ci = vi ? ccl[i] : -1;
+    const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
+    const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
+    unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
+    unsigned long long *tm = wk.tilemap + (size_t)b * 64, *cf = wk.confl + (size_t)b * 64;
     __syncthreads();
-    for (int i = M + tid; i < P2; i += 1024) keys[i] = ~0ull;
+    const BlockStat sa = sstat[rb];
+    unsigned long long tiles_done = 0, row_any = 0;
+    if (dbg == 1) return;
+    for (int cb = rb + wave; cb < nblk; cb += 4) {
+        const BlockStat sb = sstat[cb];
+        if (fast && sa.amin + sb.amin >= AREA_MIN) {
+            const float dx = fmaxf(0.f, fmaxf(sb.cx0 - sa.cx1, sa.cx0 - sb.cx1));
+            const float dy = fmaxf(0.f, fmaxf(sb.cy0 - sa.cy1, sa.cy0 - sb.cy1));
+            if (dx >= kr * (sa.wmax + sb.wmax) + PRUNE_EPS || dy >= kr * (sa.hmax + sb.hmax) + PRUNE_EPS ||
+                sa.amax <= thr_lo * sb.amin || sb.amax <= thr_lo * sa.amin)
+                continue;                      // no pair of this tile can exceed thr
+        }
+        if (dbg == 2) continue;
+        const int jg = cb * 64 + lane;
+        __builtin_amdgcn_wave_barrier();
+        sbox[wave][lane] = (jg < M) ? *(const float4 *)(cbx + (size_t)jg * 4) : make_float4(0, 0, 0, 0);
+        scls[wave][lane] = (jg < M) ? ccl[jg] : -2;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long rowbits = 0, mycol = 0;
+        const int jn = min(64, M - cb * 64);
+        for (int j = 0; j < jn; ++j) {
+            const float4 bj = sbox[wave][j];
+            const int cj = scls[wave][j];
+            const float wj = bj.z - bj.x, hj = bj.w - bj.y, aj = wj * hj;
+            bool cand = (ci == cj) && (i != cb * 64 + j);
+            if (fast) {
+                const float dx = fabsf(cxi - 0.5f * (bj.x + bj.z)), dy = fabsf(cyi - 0.5f * (bj.y + bj.w));
+                const bool far = dx >= kr * (wi + wj) + PRUNE_EPS || dy >= kr * (hi + hj) + PRUNE_EPS ||
+                                 fminf(ai, aj) <= thr_lo * fmaxf(ai, aj);
+                cand = cand && !(far && (ai + aj >= AREA_MIN));
+            }
+            bool s = false;
+            if (__any(cand)) {
+                s = fast ? suppresses(bi, ai, bj, aj, thr, q_hi, q_lo) : suppresses_exact(bi, ai, bj, aj, thr);
+                s = s && cand;
+            }
+            rowbits |= s ? (1ull << j) : 0ull;
+            const unsigned long long colbits = __ballot(s);   // bits over i for column j
+            if (lane == j) mycol = colbits;
+        }
+        if (vi) mk[(size_t)i * 64 + cb] = rowbits;
+        if (cb != rb && jg < M) mk[(size_t)jg * 64 + rb] = mycol;
+        tiles_done |= 1ull << cb;
+        row_any |= rowbits;
+        const unsigned long long cnz = __ballot(mycol != 0ull);
+        if (lane == 0 && cb != rb) {
+            atomicOr(&tm[cb], 1ull << rb);
+            if (cnz) atomicOr(&cf[cb], cnz);
+        }
+    }
+    const unsigned long long rnz = __ballot(row_any != 0ull);
+    if (lane == 0) {
+        if (tiles_done) atomicOr(&tm[rb], tiles_done);
+        if (rnz) atomicOr(&cf[rb], rnz);
+    }
+}
+
+__global__ __launch_bounds__(1024) void scan_kernel(const HeadParams p, const HeadWork wk, int dbg) {
+    __shared__ unsigned long long keys[NMS_CAP];    // conflicted candidates, sorted
+    __shared__ unsigned long long stg[2][64][64];   // staged mask rows of 64 consecutive ranks
+    __shared__ unsigned long long stile[64];
+    __shared__ unsigned long long keepw[64];        // by compact position
+    __shared__ unsigned long long keepn[64];        // by anchor index
+    __shared__ int wbase[64];
+    __shared__ int nconf_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = wk.count[b];
+    const int nw = (M + 63) >> 6;
+    const float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
+    const float *cs = wk.cscore + (size_t)b * NMS_CAP;
+    const int *cc = wk.ccls + (size_t)b * NMS_CAP;
+    const int *co = wk.corig + (size_t)b * NMS_CAP;
+    const unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
+    const unsigned long long *cf = wk.confl + (size_t)b * 64;
+    if (tid == 0) nconf_s = 0;
+    if (tid < 64) {
+        const unsigned long long vm = tid < nw ? ((tid == nw - 1 && (M & 63)) ? ((1ull << (M & 63)) - 1ull) : ~0ull) : 0ull;
+        keepw[tid] = vm & ~(tid < nw ? cf[tid] : 0ull);      // conflict-free candidates survive
+        keepn[tid] = 0ull;
+        stile[tid] = wk.tilemap[(size_t)b * 64 + tid];
+    }
+    __syncthreads();
+    // ---- conflicted candidates -> keys (score desc, anchor index asc)
+    for (int pos = tid; pos < M; pos += 1024) {
+        if ((cf[pos >> 6] >> (pos & 63)) & 1ull) {
+            const int k = atomicAdd(&nconf_s, 1);
+            // anchor index in bits 12..31 orders ties; compact position in bits 0..11
+            keys[k] = ((unsigned long long)(~__float_as_uint(cs[pos])) << 32) |
+                      ((unsigned long long)(unsigned int)co[pos] << 12) | (unsigned int)pos;
+        }
+    }
+    __syncthreads();
+    const int nconf = nconf_s;
+    if (dbg == 11) return;
+    int P2 = 1;
+    while (P2 < nconf) P2 <<= 1;
+    for (int i = nconf + tid; i < P2; i += 1024) keys[i] = ~0ull;
     __syncthreads();
     for (int k = 2; k <= P2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -140,141 +354,117 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             __syncthreads();
         }
     }
-    int *ord = wk.order + (size_t)b * NMS_CAP;
-    for (int i = tid; i < M; i += 1024) ord[i] = (int)(keys[i] & 0xffffffffu);
-    if (tid == 0) wk.count[b] = M;
-}
-
-// suppression relation of slim_yolo_v2.py:159-171 between two boxes of the same class
-__device__ __forceinline__ bool suppresses(const float4 a, float area_a, const float4 c, float area_c, float thr) {
-    const float xx1 = fmaxf(a.x, c.x), yy1 = fmaxf(a.y, c.y);
-    const float xx2 = fminf(a.z, c.z), yy2 = fminf(a.w, c.w);
-    const float w = fmaxf(1e-28f, xx2 - xx1), h = fmaxf(1e-28f, yy2 - yy1);
-    const float inter = w * h;
-    const float ovr = inter / (area_a + area_c - inter);
-    return !(ovr <= thr);
-}
-
-__global__ __launch_bounds__(256) void mask_kernel(const HeadWork wk, float thr) {
-    __shared__ float4 sbox[4][64];
-    __shared__ int scls[4][64];
-    const int b = blockIdx.y;
-    const int M = wk.count[b];
-    const int nblk = (M + 63) >> 6;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rb = blockIdx.x / (NMS_CAP / 64 / 4);
-    const int cb = (blockIdx.x % (NMS_CAP / 64 / 4)) * 4 + wave;
-    if (rb >= nblk || cb >= nblk || cb < rb) return;   // whole-wave exit, no barrier below
-    const float *cbx = wk.cbox + (size_t)b * NMS_CAP * 4;
-    const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
-    const int i = rb * 64 + lane, jg = cb * 64 + lane;
-    const bool vi = i < M;
-    const float4 bi = vi ? *(const float4 *)(cbx + (size_t)i * 4) : make_float4(0, 0, 0, 0);
-    const int ci = vi ? ccl[i] : -1;
-    const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-    sbox[wave][lane] = (jg < M) ? *(const float4 *)(cbx + (size_t)jg * 4) : make_float4(0, 0, 0, 0);
-    scls[wave][lane] = (jg < M) ? ccl[jg] : -2;
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own-wave LDS writes visible to own-wave reads
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long rowbits = 0, mycol = 0;
-    for (int j = 0; j < 64; ++j) {
-        const float4 bj = sbox[wave][j];
-        const int cj = scls[wave][j];
-        const float aj = (bj.z - bj.x) * (bj.w - bj.y);
-        const bool s = (ci == cj) && (i != cb * 64 + j) && suppresses(bi, ai, bj, aj, thr);
-        rowbits |= s ? (1ull << j) : 0ull;
-        const unsigned long long colbits = __ballot(s);   // bits over i for column j
-        if (lane == j) mycol = colbits;
-    }
-    unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
-    if (vi) mk[(size_t)i * 64 + cb] = rowbits;
-    if (cb != rb && jg < M) mk[(size_t)jg * 64 + rb] = mycol;
-}
-
-__global__ __launch_bounds__(64) void scan_kernel(const HeadParams p, const HeadWork wk) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int M = wk.count[b];
-    const int nw = (M + 63) >> 6;
-    const int *ord = wk.order + (size_t)b * NMS_CAP;
-    const unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
-    constexpr int CH = 16;
-    unsigned long long removed = 0, keep = 0;
-    unsigned long long rows[CH], nrows[CH];
-    int idx[CH], nidx[CH];
+    // ---- serial resolution: waves 1..15 stage the rows of the next 64 ranks into LDS while
+    //      wave 0 (lane w = word w of the "removed" set) walks the current 64
+    if (dbg == 12) return;
+    const int nchunks = (nconf + 63) >> 6;
+    auto stage = [&](int c, int buf) {
+        // 15 staging waves x up to 5 rows each: issue all global loads, then the LDS stores
+        unsigned long long word[5];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        idx[k] = (k < M) ? ord[k] : 0;
-        rows[k] = (k < M && lane < nw) ? mk[(size_t)idx[k] * 64 + lane] : 0ull;
-    }
-    for (int r0 = 0; r0 < M; r0 += CH) {
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int r = r0 + CH + k;
-            nidx[k] = (r < M) ? ord[r] : 0;
-            nrows[k] = (r < M && lane < nw) ? mk[(size_t)nidx[k] * 64 + lane] : 0ull;
+        for (int u = 0; u < 5; ++u) {
+            const int k = wave - 1 + 15 * u;
+            const int r = c * 64 + k;
+            word[u] = 0ull;
+            if (k < 64 && r < nconf) {
+                const int ix = (int)(keys[r] & 0xfffu);
+                if (lane < nw && ((stile[ix >> 6] >> lane) & 1ull)) word[u] = mk[(size_t)ix * 64 + lane];
+            }
         }
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            if (r0 + k < M) {
-                const int i = __builtin_amdgcn_readfirstlane(idx[k]);
-                const int w = i >> 6, bit = i & 63;
-                const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)removed, w);
-                const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(removed >> 32), w);
-                const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
-                if (!((rw >> bit) & 1ull)) {
-                    if (lane == w) keep |= 1ull << bit;
-                    removed |= rows[k];
+        for (int u = 0; u < 5; ++u) {
+            const int k = wave - 1 + 15 * u;
+            if (k < 64) stg[buf][k][lane] = word[u];
+        }
+    };
+    if (wave != 0 && nchunks > 0) stage(0, 0);
+    __syncthreads();
+    unsigned long long removed = 0, keep = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        if (wave != 0) {
+            if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+        } else {
+            const int kn = min(64, nconf - c * 64);
+            for (int k0 = 0; k0 < kn; k0 += 8) {
+                // the 8 ranks' indices and rows do not depend on the decisions: fetch them first
+                int ii[8];
+                unsigned long long rr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ii[u] = (int)(keys[c * 64 + k0 + u] & 0xfffu);
+                    rr[u] = stg[c & 1][k0 + u][lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u < kn) {
+                        const int i = __builtin_amdgcn_readfirstlane(ii[u]);
+                        const int w = i >> 6, bit = i & 63;
+                        const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)removed, w);
+                        const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(removed >> 32), w);
+                        const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
+                        const bool kept = !((rw >> bit) & 1ull);
+                        if (kept && lane == w) keep |= 1ull << bit;
+                        removed |= kept ? rr[u] : 0ull;
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < CH; ++k) { idx[k] = nidx[k]; rows[k] = nrows[k]; }
+        __syncthreads();
     }
-    // ---- survivors, in anchor-index (= compact) order
-    const int cnt = __popcll(keep);
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
+    if (wave == 0) keepw[lane] |= keep;
+    __syncthreads();
+    if (dbg == 13) return;
+    // ---- survivors -> bit-set over anchor indices, then emit in that order
+    for (int pos = tid; pos < M; pos += 1024) {
+        if ((keepw[pos >> 6] >> (pos & 63)) & 1ull) {
+            const int n = co[pos];
+            atomicOr(&keepn[n >> 6], 1ull << (n & 63));
+        }
     }
-    const int tot = __shfl(incl, 63, 64);
-    const int excl = incl - cnt;
-    const float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
-    const float *cs = wk.cscore + (size_t)b * NMS_CAP;
-    const int *cc = wk.ccls + (size_t)b * NMS_CAP;
+    __syncthreads();
+    if (tid < 64) {
+        const int cnt = __popcll(keepn[tid]);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        wbase[tid] = incl - cnt;
+        if (tid == 63) p.out_count[b] = incl < p.max_det ? incl : p.max_det;
+    }
+    __syncthreads();
     float *ob = p.out_box + (size_t)b * p.max_det * 4;
     float *os = p.out_score + (size_t)b * p.max_det;
     int *oc = p.out_cls + (size_t)b * p.max_det;
-    for (int w = 0; w < nw; ++w) {
-        const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)keep, w);
-        const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(keep >> 32), w);
-        const unsigned long long bits = ((unsigned long long)hi << 32) | lo;
-        const int base = __builtin_amdgcn_readlane(excl, w);
-        if ((bits >> lane) & 1ull) {
-            const int dst = base + __popcll(bits & ((1ull << lane) - 1ull));
-            const int src = w * 64 + lane;
+    for (int pos = tid; pos < M; pos += 1024) {
+        if ((keepw[pos >> 6] >> (pos & 63)) & 1ull) {
+            const int n = co[pos];
+            const unsigned long long bits = keepn[n >> 6];
+            const int dst = wbase[n >> 6] + __popcll(bits & ((1ull << (n & 63)) - 1ull));
             if (dst < p.max_det) {
-                *(float4 *)(ob + (size_t)dst * 4) = *(const float4 *)(cb + (size_t)src * 4);
-                os[dst] = cs[src];
-                oc[dst] = cc[src];
+                *(float4 *)(ob + (size_t)dst * 4) = *(const float4 *)(cb + (size_t)pos * 4);
+                os[dst] = cs[pos];
+                oc[dst] = cc[pos];
             }
         }
     }
-    if (lane == 0) p.out_count[b] = tot < p.max_det ? tot : p.max_det;
 }
 
-void y355_launch_head_nms(const HeadParams &p, int batch, void *cbox, void *cscore, void *ccls, void *order,
-                          void *count, void *mask, hipStream_t s, hipEvent_t mid) {
+void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid) {
     HeadWork wk;
-    wk.cbox = (float *)cbox;
-    wk.cscore = (float *)cscore;
-    wk.ccls = (int *)ccls;
-    wk.order = (int *)order;
-    wk.count = (int *)count;
-    wk.mask = (unsigned long long *)mask;
+    wk.cbox = (float *)ws.cbox;
+    wk.cscore = (float *)ws.cscore;
+    wk.ccls = (int *)ws.ccls;
+    wk.corig = (int *)ws.corig;
+    wk.count = (int *)ws.count;
+    wk.mask = (unsigned long long *)ws.mask;
+    wk.bstat = (BlockStat *)ws.bstat;
+    wk.tilemap = (unsigned long long *)ws.tilemap;
+    wk.confl = (unsigned long long *)ws.confl;
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
-    if (mid) hipEventRecord(mid, s);
-    hipLaunchKernelGGL(mask_kernel, dim3((NMS_CAP / 64) * (NMS_CAP / 64 / 4), batch), dim3(256), 0, s, wk, p.nms_thresh);
-    hipLaunchKernelGGL(scan_kernel, dim3(batch), dim3(64), 0, s, p, wk);
+    if (mid) (void)hipEventRecord(mid, s);
+    static int dbg = getenv("Y355_NMS_DBG") ? atoi(getenv("Y355_NMS_DBG")) : 0;
+    hipLaunchKernelGGL(mask_kernel, dim3(NBLK, batch), dim3(256), 0, s, wk, p.nms_thresh, dbg);
+    hipLaunchKernelGGL(scan_kernel, dim3(batch), dim3(1024), 0, s, p, wk, dbg);
 }

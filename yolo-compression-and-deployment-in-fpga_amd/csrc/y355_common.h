@@ -149,9 +149,10 @@ struct HeadParams {
     int *out_count;
 };
 #define Y355_NMS_CAP 4096   // anchors per image the NMS workspace is sized for
-// decode + compact + sort, suppression bit-matrix, ordered scan (head_nms.hip).
-// Workspace (per image): cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP], order i32[CAP],
-// count i32, mask u64[CAP][64].  `mid` (optional) is recorded between decode and NMS.
-void y355_launch_head_nms(const HeadParams &p, int batch, void *cbox, void *cscore, void *ccls, void *order,
-                          void *count, void *mask, hipStream_t s, hipEvent_t mid);
+// head_nms.hip workspace, per image: cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP],
+// corig i32[CAP], count i32, mask u64[CAP][64], bstat 8 x f32[64], tilemap u64[64], confl u64[64].
+struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *mask, *bstat, *tilemap, *confl; };
+// decode + compact, pruned suppression bit-matrix, ordered scan.  `mid` (optional) is recorded
+// between decode and NMS.
+void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid);
 void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStream_t s);
