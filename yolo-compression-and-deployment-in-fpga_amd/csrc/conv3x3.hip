@@ -167,10 +167,9 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
         for (int ks = 0; ks < KS; ++ks) kstep(ks, kofs[ks]);
     } else {
         constexpr int NCH = CIN / 64;
-        for (int tap = 0; tap < 9; ++tap) {
-            const int tofs = ((tap / 3) * PW + tap % 3) * STRIDE;
+        for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) kstep(tap * NCH + ch, tofs + ch * 64);
+            for (int tap = 0; tap < 9; ++tap) kstep(ch * 9 + tap, ((tap / 3) * PW + tap % 3) * STRIDE + ch * 64);
         }
     }
 
@@ -335,7 +334,7 @@ size_t y355_packed_bytes(const ConvKernelInfo &ki, int cout_pad) {
 // B-fragment order: frag(nb, ks, wn, t) = ((nb*KS + ks)*WN + wn)*NT + t, 1 KiB each;
 // inside a fragment lane l = (g = l>>4, j = l&15) holds 16 consecutive k of output channel
 //   n = nb*BN + wn*NT*16 + j*NT + t      (so that a lane's NT outputs are adjacent bytes)
-// with k -> (tap, cin) as the kernel's A side walks the patch.
+// with k -> (tap, cin) as the kernel's A side walks the patch (64-channel chunk major).
 void y355_pack_weights(const ConvKernelInfo &ki, const int8_t *q_w, int cout, int cin, int cout_pad, int8_t *dst) {
     const int CIN = ki.cin, KS = ki.ks, NT = ki.nt, WN = ki.wn, BN = ki.bn;
     const int nblk = cout_pad / BN;
@@ -351,7 +350,7 @@ void y355_pack_weights(const ConvKernelInfo &ki, const int8_t *q_w, int cout, in
                             int tap, ci;
                             if (CIN == 16) { tap = 4 * ks + g; ci = kk; }
                             else if (CIN == 32) { tap = 2 * ks + (g >> 1); ci = 16 * (g & 1) + kk; }
-                            else { const int nch = CIN / 64; tap = ks / nch; ci = 64 * (ks % nch) + 16 * g + kk; }
+                            else { tap = ks % 9; ci = 64 * (ks / 9) + 16 * g + kk; }
                             int8_t v = 0;
                             if (tap < 9 && n < cout && ci < cin) v = q_w[((size_t)n * cin + ci) * 9 + tap];
                             f[l * 16 + kk] = v;

@@ -1,0 +1,374 @@
+// yolo355 -- fused int8 3x3 convolution, production variant (persistent + LDS-DMA rings).
+//
+// Same math, tile geometry, weight packing and epilogue as conv3x3.hip (which stays as the
+// statistics / 64-bit-epilogue / generic-shape kernel); what changes is how bytes move:
+//   * workgroups are persistent (grid = a few per CU) and walk tiles with stride gridDim.x;
+//   * the input patch is cut into 64-channel chunks; a 2-slot LDS ring of chunks is filled by
+//     LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip and no
+//     staging VALU) one chunk ahead of the MFMAs -- across tile boundaries too;
+//   * weights come through a 3-slot LDS ring of k-steps (one tap of one chunk, BN/16 1-KiB
+//     B fragments), also by LDS-DMA, two k-steps ahead; for the two thin layers (K = 144 / 288)
+//     the whole layer's fragments stay resident in LDS instead;
+//   * one raw s_barrier per k-step behind a COUNTED s_waitcnt vmcnt(N) (never 0 inside a tile
+//     except its first two steps, which also drain the previous tile's stores).
+// Pixel rows in LDS keep the 16-byte pad of the register-staged variant (conflict-free
+// ds_read_b128); the DMA lanes that fall on pad bytes read a dummy address.
+#include "y355_common.h"
+
+template <int CIN>
+struct KGeom2 {
+    static constexpr int CC = CIN < 64 ? CIN : 64;                // channels per chunk
+    static constexpr int NCH = CIN / CC;
+    static constexpr int STRIDE = (CC == 16) ? 16 : CC + 16;      // LDS bytes per pixel
+    static constexpr int SPC = (CC == 16) ? 3 : (CC == 32) ? 5 : 9;   // k-steps per chunk
+    static constexpr int KS = NCH * SPC;
+};
+
+__device__ __forceinline__ void glds16(const void *g, void *lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NT>
+__device__ __forceinline__ void store_bytes2(int8_t *dst, const int (&q)[NT]) {
+    if constexpr (NT == 1) {
+        *dst = (int8_t)q[0];
+    } else if constexpr (NT == 2) {
+        *(unsigned short *)dst = (unsigned short)((q[0] & 0xff) | ((q[1] & 0xff) << 8));
+    } else if constexpr (NT == 4) {
+        *(unsigned int *)dst = (unsigned int)((q[0] & 0xff) | ((q[1] & 0xff) << 8) |
+                                              ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24));
+    } else {
+        static_assert(NT == 8, "NT");
+        uint2 v;
+        v.x = (unsigned int)((q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24));
+        v.y = (unsigned int)((q[4] & 0xff) | ((q[5] & 0xff) << 8) | ((q[6] & 0xff) << 16) | ((unsigned)(q[7] & 0xff) << 24));
+        *(uint2 *)dst = v;
+    }
+}
+
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES>
+__global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, const int total_tiles) {
+    using G = KGeom2<CIN>;
+    constexpr int CC = G::CC, NCH = G::NCH, STRIDE = G::STRIDE, SPC = G::SPC, KS = G::KS;
+    constexpr int PW = TW + 2, PH = TH + 2, NPIX = PH * PW;
+    constexpr int BM = TH * TW;
+    constexpr int MT_TOT = (BM + 15) / 16;
+    constexpr int MT = (MT_TOT + WM - 1) / WM;
+    constexpr int NT = BN / 16 / WN;
+    constexpr int SLABB = (NPIX * STRIDE + 1023) / 1024 * 1024;   // bytes of one chunk slot
+    constexpr int NPIECE = SLABB / 1024;
+    constexpr int PPW = (NPIECE + 3) / 4;                          // slab pieces per wave
+    constexpr int WB = (BN / 16) * 1024;                           // weight bytes per k-step
+    constexpr int NFR = BN / 16;                                   // fragments per k-step
+    constexpr int WPW = (NFR + 3) / 4;                             // weight pieces per wave per k-step
+    constexpr int WSLOTS = WRES ? KS : 3;
+    constexpr int OFF_W = 2 * SLABB;
+    constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;                 // 1 KiB sink for padding pieces
+    constexpr int OFF_STG = OFF_DUMMY + 1024;                      // int8 output tile, row-major
+    constexpr int SROWS = POOL ? MT * WM * 4 : MT * WM * 16;       // staged rows (pixels / windows)
+    constexpr int SSTR = BN + 16;                                  // bytes per staged row (+pad)
+    constexpr int OROWS = POOL ? BM / 4 : BM;                      // real rows of a tile
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WRES || (SPC % 3 == 0), "weight ring slot must be static per tap");
+    static_assert(WRES ? NCH == 1 : true, "resident weights only for single-chunk layers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, g = lane >> 4;
+    const int H = p.H, W = p.W;
+
+    // ---- tile-independent per-lane geometry
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int row = (wm * MT + m) * 16 + li;
+        row = min(row, BM - 1);
+        int oy, ox;
+        if constexpr (POOL) {
+            const int w = row >> 2, r = row & 3;
+            oy = 2 * (w / (TW / 2)) + (r >> 1);
+            ox = 2 * (w % (TW / 2)) + (r & 1);
+        } else {
+            oy = row / TW;
+            ox = row % TW;
+        }
+        abase[m] = (oy * PW + ox) * STRIDE + (CC == 64 ? g * 16 : 0);
+    }
+    int kofs[(CC < 64) ? SPC : 1];
+    if constexpr (CC == 16) {
+#pragma unroll
+        for (int t = 0; t < SPC; ++t) {
+            const int tap = min(4 * t + g, 8);
+            kofs[t] = ((tap / 3) * PW + tap % 3) * STRIDE;
+        }
+    } else if constexpr (CC == 32) {
+#pragma unroll
+        for (int t = 0; t < SPC; ++t) {
+            const int tap = min(2 * t + (g >> 1), 8);
+            kofs[t] = ((tap / 3) * PW + tap % 3) * STRIDE + (g & 1) * 16;
+        }
+    } else {
+        kofs[0] = 0;
+    }
+    // slab DMA pieces of this wave: piece q = wave + 4*j covers LDS bytes [q*1024, +1024);
+    // lane l owns 16 of them: pixel = o / STRIDE, byte `within` of that pixel's chunk
+    int ppix[PPW];      // (py << 16) | px, or -1 for pad / out-of-patch lanes
+    int pwithin[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = wave + 4 * j;
+        const int o = q * 1024 + lane * 16;
+        const int pix = o / STRIDE, within = o - pix * STRIDE;
+        const bool ok = (q < NPIECE) && (pix < NPIX) && (within < CC);
+        ppix[j] = ok ? (((pix / PW) << 16) | (pix % PW)) : -1;
+        pwithin[j] = within;
+    }
+
+    auto decode = [&](int tile, int &b, int &y0, int &x0, int &nb) {
+        nb = tile % p.nblk;
+        tile /= p.nblk;
+        x0 = (tile % p.tiles_x) * TW;
+        tile /= p.tiles_x;
+        y0 = (tile % p.tiles_y) * TH;
+        b = tile / p.tiles_y;
+    };
+    const int dbg = p.mode >> 8;
+    auto issue_slab = [&](int b, int y0, int x0, int c, int slot) {
+        if (dbg & 2) return;
+        const int8_t *inb = p.in + (size_t)b * (H + 2) * (W + 2) * CIN + c * CC;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int q = wave + 4 * j;
+            const int8_t *src = p.in;                         // dummy for pad lanes
+            if (ppix[j] >= 0) {
+                const int gy = min(y0 + (ppix[j] >> 16), H + 1), gx = min(x0 + (ppix[j] & 0xffff), W + 1);
+                src = inb + ((size_t)gy * (W + 2) + gx) * CIN + pwithin[j];
+            }
+            char *dst = (q < NPIECE) ? smem + slot * SLABB + q * 1024 : smem + OFF_DUMMY;
+            glds16(src, dst);
+        }
+    };
+    auto issue_w = [&](int nb, int ks, int slot) {
+        if (dbg & 1) return;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) {
+            const int f = wave + 4 * j;                        // fragment of this k-step
+            const bool ok = f < NFR;
+            const int8_t *src = p.w + ((size_t)(nb * KS + ks) * NFR + (ok ? f : 0)) * 1024 + lane * 16;
+            char *dst = ok ? smem + OFF_W + slot * WB + f * 1024 : smem + OFF_DUMMY;
+            glds16(src, dst);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    int b, y0, x0, nb;
+    decode(tile, b, y0, x0, nb);
+    int sl = 0;                                                // slab slot of the current chunk
+    // ---- prologue
+    issue_slab(b, y0, x0, 0, 0);
+    if constexpr (WRES) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) issue_w(nb, ks, ks);
+    } else {
+        issue_w(nb, 0, 0);
+        issue_w(nb, 1, 1);
+    }
+
+    if (dbg & 8) { wait_vmcnt<0>(); return; }
+    const Requant rq = p.rq;
+    unsigned int nsat = 0;
+
+    for (;;) {
+        int ntile = tile + gridDim.x;
+        const bool more = ntile < total_tiles;
+        if (!more) ntile = tile;                               // keep the DMA counts static
+        int b2, y2, x2, nb2;
+        decode(ntile, b2, y2, x2, nb2);
+
+        v4i acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){0, 0, 0, 0};
+
+        for (int c = 0; c < NCH; ++c) {
+            const bool lastc = (c == NCH - 1);
+            int aaddr[MT];                                      // slot base + row base; taps are immediates
+#pragma unroll
+            for (int m = 0; m < MT; ++m) aaddr[m] = sl * SLABB + abase[m];
+#pragma unroll
+            for (int t = 0; t < SPC; ++t) {
+                // -- data of this k-step has landed (own DMAs) -> barrier -> everybody's has
+                if (c == 0 && t == 0) {
+                    wait_vmcnt<0>();                            // also drains the previous tile's stores
+                } else if constexpr (!WRES) {
+                    if (t == 1) wait_vmcnt<WPW + PPW>();        // W(t+1) and the slab issued at t=0 may fly
+                    else wait_vmcnt<WPW>();
+                }
+                if (!WRES || t == 0) __builtin_amdgcn_s_barrier();
+                // -- refill the rings (after the barrier: the slots' last readers are done)
+                if (t == 0) {
+                    if (!lastc) issue_slab(b, y0, x0, c + 1, sl ^ 1);
+                    else issue_slab(b2, y2, x2, 0, sl ^ 1);
+                }
+                if constexpr (!WRES) {
+                    const int ks2 = c * SPC + t + 2;
+                    if (ks2 < KS) issue_w(nb, ks2, (t + 2) % 3);
+                    else issue_w(nb2, ks2 - KS, (t + 2) % 3);
+                }
+                // -- MFMAs of this k-step
+                const char *wb = smem + OFF_W + (WRES ? t : (t % 3)) * WB + (wn * NT) * 1024 + lane * 16;
+                int ko;
+                if constexpr (CC < 64) ko = kofs[t];
+                else ko = ((t / 3) * PW + t % 3) * STRIDE;
+                v4i bf[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) bf[tt] = *(const v4i *)(wb + tt * 1024);
+                if (!(dbg & 4)) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const v4i a = *(const v4i *)(smem + aaddr[m] + ko);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+                        acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bf[tt], acc[m][tt], 0, 0, 0);
+                }
+                }
+            }
+            sl ^= 1;
+        }
+
+        // ---- epilogue of this tile: integer pipeline of conv3x3.hip (32-bit path) -> int8 tile in
+        //      LDS (each lane packs its NT adjacent channels) -> barrier -> 16-byte coalesced stores
+        if (!(dbg & 16)) {
+            const int ncol = wn * (NT * 16) + li * NT;           // first channel of this lane in the tile
+            int bias[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bias[t] = p.bias_t[nb * BN + ncol + t];
+            char *stg = smem + OFF_STG;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (POOL) {
+                    const int srow = (wm * MT + m) * 4 + g;      // pooling window of the tile
+                    int q[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const v4i a = acc[m][t];
+                        const int vmax = max(max(a[0], a[1]), max(a[2], a[3]));
+                        const int qq = y355_rne_shift<int>(y355_pre<int>(vmax, bias[t], rq), rq.sh);
+                        q[t] = y355_clamp8<int>(qq);
+                        nsat += (srow < OROWS && q[t] != qq) ? 1u : 0u;
+                    }
+                    store_bytes2<NT>((int8_t *)stg + srow * SSTR + ncol, q);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int srow = (wm * MT + m) * 16 + 4 * g + r;
+                        int q[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int qq = y355_rne_shift<int>(y355_pre<int>(acc[m][t][r], bias[t], rq), rq.sh);
+                            q[t] = y355_clamp8<int>(qq);
+                            nsat += (srow < OROWS && q[t] != qq) ? 1u : 0u;
+                        }
+                        store_bytes2<NT>((int8_t *)stg + srow * SSTR + ncol, q);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // copy-out: item = (row, 16-byte channel group); rows outside the image are dropped
+            const int halo = p.out_halo;
+            constexpr int CG = BN / 16;
+            constexpr int OTW = POOL ? TW / 2 : TW;
+            const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+            const int oy0 = POOL ? (y0 >> 1) : y0, ox0 = POOL ? (x0 >> 1) : x0;
+            int8_t *outb = p.out + (size_t)b * (Ho + 2 * halo) * (Wo + 2 * halo) * p.cstride + nb * BN;
+            for (int it = tid; it < OROWS * CG; it += 256) {
+                const int row = it / CG, cg = it % CG;
+                const int oy = oy0 + row / OTW, ox = ox0 + row % OTW;
+                if (oy < Ho && ox < Wo) {
+                    const v4i v = *(const v4i *)(stg + row * SSTR + cg * 16);
+                    *(v4i *)(outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.cstride + cg * 16) = v;
+                }
+            }
+        }
+        if (!more) break;
+        tile = ntile;
+        b = b2; y0 = y2; x0 = x2; nb = nb2;
+    }
+    wait_vmcnt<0>();       // retire the padding DMAs before the wave ends
+    if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
+}
+
+// ------------------------------------------------------------------------------------------
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES>
+struct ConvInst2 {
+    using G = KGeom2<CIN>;
+    static constexpr int SLABB = ((TH + 2) * (TW + 2) * G::STRIDE + 1023) / 1024 * 1024;
+    static constexpr int WB = (BN / 16) * 1024;
+    static constexpr int MTT = (TH * TW + 15) / 16;
+    static constexpr int SROWS = POOL ? ((MTT + WM - 1) / WM) * WM * 4 : ((MTT + WM - 1) / WM) * WM * 16;
+    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(WRES ? G::KS : 3) * WB + 1024 + (size_t)SROWS * (BN + 16);
+    static int prepare() {
+        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    }
+    static bool launch(const ConvParams &p, hipStream_t s) {
+        if (WRES && p.nblk != 1) return false;     // resident weights = one n-block
+        const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
+        int per_cu = (int)((160 * 1024) / LDS);
+        per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+        int grid = 256 * per_cu;
+        if (grid > total) grid = total;
+        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>), dim3(grid), dim3(256), LDS, s, p, total);
+        return true;
+    }
+};
+
+// must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
+using V2_CONV2 = ConvInst2<16, 32, 16, 52, true, 4, 1, true>;
+using V2_CONV3_1 = ConvInst2<32, 64, 13, 26, false, 2, 2, true>;
+using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 2, 2, false>;
+using V2_CONV4_1 = ConvInst2<64, 128, 13, 26, false, 2, 2, false>;
+using V2_CONV4_2 = ConvInst2<128, 64, 26, 26, true, 4, 1, false>;
+using V2_CONV5 = ConvInst2<128, 256, 13, 13, false, 1, 4, false>;
+using V2_CONV67 = ConvInst2<256, 256, 13, 13, false, 1, 4, false>;
+using V2_PRED = ConvInst2<256, 64, 13, 13, false, 4, 1, false>;
+
+int y355_prepare_conv_v2(void) {
+    int e = V2_CONV2::prepare();
+    if (!e) e = V2_CONV3_1::prepare();
+    if (!e) e = V2_CONV3_2::prepare();
+    if (!e) e = V2_CONV4_1::prepare();
+    if (!e) e = V2_CONV4_2::prepare();
+    if (!e) e = V2_CONV5::prepare();
+    if (!e) e = V2_CONV67::prepare();
+    if (!e) e = V2_PRED::prepare();
+    return e;
+}
+
+bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s) {
+    if ((p.mode & 0xff) != 0 || p.rq.wide || p.guard) return false;   // those go to conv3x3.hip
+    switch (kid) {
+    case Y355_K_CONV2: return V2_CONV2::launch(p, s);
+    case Y355_K_CONV3_1: return V2_CONV3_1::launch(p, s);
+    case Y355_K_CONV3_2: return V2_CONV3_2::launch(p, s);
+    case Y355_K_CONV4_1: return V2_CONV4_1::launch(p, s);
+    case Y355_K_CONV4_2: return V2_CONV4_2::launch(p, s);
+    case Y355_K_CONV5: return V2_CONV5::launch(p, s);
+    case Y355_K_CONV67: return V2_CONV67::launch(p, s);
+    case Y355_K_PRED: return V2_PRED::launch(p, s);
+    default: return false;
+    }
+}

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +67,8 @@ int prepare_kernels() {
         int e = y355_conv_kernel(i)->prepare();
         if (e) return fail(Y355_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString((hipError_t)e));
     }
+    if (int e = y355_prepare_conv_v2())
+        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(v2): ") + hipGetErrorString((hipError_t)e));
     kernels_prepared = 1;
     return 0;
 }
@@ -383,7 +386,11 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.rq = L.rq;
         p.mode = mode;
         p.guard = guard;
-        ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
+        static const bool no_v2 = getenv("Y355_NO_V2") != nullptr;
+        static const int v2dbg = getenv("Y355_V2_DBG") ? atoi(getenv("Y355_V2_DBG")) : 0;
+        if (mode == 0) p.mode |= v2dbg << 8;
+        if (no_v2 || !y355_launch_conv_v2(L.kid, p, h->stream))
+            ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -127,6 +127,10 @@ enum {
     Y355_K_COUNT
 };
 
+// production conv kernels (conv3x3_v2.hip): false = not available for this launch, use ki.launch
+bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s);
+int y355_prepare_conv_v2(void);
+
 void y355_launch_conv1(const Conv1Params &p, hipStream_t s);
 void y355_conv1_tiles(int H, int W, int *tx, int *ty);
 void y355_pack_conv1(const int8_t *q_w /*[16][3][3][3]*/, int8_t *dst /*1024*/);
