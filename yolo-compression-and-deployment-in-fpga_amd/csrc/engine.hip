@@ -67,6 +67,8 @@ int prepare_kernels() {
         int e = y355_conv_kernel(i)->prepare();
         if (e) return fail(Y355_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString((hipError_t)e));
     }
+    if (int e = y355_prepare_head())
+        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(head): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_v2())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(v2): ") + hipGetErrorString((hipError_t)e));
     kernels_prepared = 1;
@@ -228,9 +230,14 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.corig, sizeof(int) * cap * B, false);
     if (!rc) rc = dmalloc(h, &h->ws.count, sizeof(int) * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.mask, sizeof(unsigned long long) * 64 * cap * B, false);
-    if (!rc) rc = dmalloc(h, &h->ws.bstat, 32 * 64 * (size_t)B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.tilemap, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.rowvalid, 8 * cap * (size_t)B, true);
     if (!rc) rc = dmalloc(h, &h->ws.confl, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.binstart, sizeof(int) * (cap + 8) * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.tiny, sizeof(int) * cap * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.ntiny, sizeof(int) * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.keepw, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.rmask, sizeof(unsigned long long) * 64 * cap * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_cls, sizeof(int) * N * B, false);

@@ -13,66 +13,83 @@
 //
 // Greedy NMS is a walk over the "i suppresses j" relation in score order.  The relation is
 // sparse (a box only interacts with boxes of similar size whose centre is close), so:
-//   head_kernel  one workgroup per image: decode, threshold, compact the candidates in
-//                (anchor, cell) order -- 64 consecutive candidates then share their anchor and
-//                2-3 grid rows -- and reduce per-64-block extents (centre range, max w/h,
-//                min/max area);
-//   mask_kernel  persistent waves over (image, row-block, col-block >= row-block): a block
-//                pair whose extents prove IoU <= thr for every pair is skipped; otherwise a
-//                64x64 bit tile (+ its transpose, from the wave ballots) is written, with a
-//                per-pair early-out on the same bounds.  Sets a "computed" bit per tile and a
-//                "has conflicts" bit per candidate;
+//   head_kernel  one workgroup per image: decode, threshold, and counting-sort the candidates
+//                into (anchor, centre-bin) order -- bins are the Hs x Ws grid over the CLAMPED
+//                box centres -- plus per-anchor extents (max w/h, min/max area);
+//   pairs_kernel one thread per candidate walks only the bins a suppressor can sit in
+//                (|dcx| < (1-thr)(wi+wj)/2, same in y, area ratio > thr) and writes its own row
+//                of the bit matrix, word by word, remembering which words it initialised;
 //   scan_kernel  one workgroup per image: candidates without conflicts are kept outright;
 //                the others are sorted by (score desc, index asc) and resolved serially by one
 //                wave holding the "removed" bit-set one word per lane; survivors are emitted in
 //                anchor-index order into the padded outputs.
-// The early-outs are exact: a pair is skipped only when real IoU < 0.999*thr and the areas are
-// not degenerate, where the fp32 formula of the reference cannot exceed thr.
+// The pruning is exact: a pair is skipped only when real IoU < 0.999*thr and the union is not
+// degenerate, where the fp32 formula of the reference cannot exceed thr.
 #include "y355_common.h"
 #include <cstdlib>
 
 #define NMS_CAP Y355_NMS_CAP   // max anchors per image handled by this head (416x416: 3380)
 #define NBLK (NMS_CAP / 64)
-
-struct BlockStat { float cx0, cx1, cy0, cy1, wmax, hmax, amin, amax; };
+#define MAXA Y355_HEAD_MAXA
 
 struct HeadWork {
-    float *cbox;          // [B][CAP][4]  compacted candidates, (anchor, cell) order
+    float *cbox;          // [B][CAP][4]  compacted candidates, (anchor, bin) order
     float *cscore;        // [B][CAP]
     int *ccls;            // [B][CAP]
     int *corig;           // [B][CAP]     anchor index n = cell*A + a of compact position p
     int *count;           // [B]          candidates per image
-    unsigned long long *mask;    // [B][CAP][64]
-    BlockStat *bstat;            // [B][64]
-    unsigned long long *tilemap; // [B][64]  bit cb of word rb: tile (rb,cb) was computed
-    unsigned long long *confl;   // [B][64]  bit per compact position: has a nonzero row
+    unsigned long long *mask;     // [B][CAP][64]  row p: bit q set = p and q suppress each other
+    unsigned long long *rowvalid; // [B][CAP]      which words of row p were written
+    unsigned long long *confl;    // [B][64]       bit per compact position: has a nonzero row
+    int *binstart;        // [B][CAP+8]   first compact position of bin (a*HW + by*Ws + bx)
+    float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
+    int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
+    int *ntiny;           // [B]
+    unsigned long long *keepw;    // [B][64]       resolved survivors among the conflicted
+    unsigned long long *rmask;    // [B][CAP][64]  rank-space rows when a class has > 1024 conflicted
 };
+
+#define PRUNE_MARGIN 1.001f
+#define PRUNE_EPS 1e-6f
+#define AREA_MIN 1e-10f
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const HeadWork wk) {
+    __shared__ int hist[NMS_CAP];          // bin counts -> bin starts
     __shared__ int wsum[16];
-    __shared__ int total;
+    __shared__ unsigned int sstat[MAXA][4];
+    __shared__ int ntiny_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int A = p.A, C = p.C;
     const int HW = p.Hs * p.Ws;
     const int N = HW * A;
-    if (tid < 64) {
-        wk.tilemap[(size_t)b * 64 + tid] = 0ull;
-        wk.confl[(size_t)b * 64 + tid] = 0ull;
+    for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
+    if (tid < MAXA) {
+        sstat[tid][0] = 0u;                 // wmax
+        sstat[tid][1] = 0u;                 // hmax
+        sstat[tid][2] = 0x7f7fffffu;        // amin
+        sstat[tid][3] = 0u;                 // amax
     }
+    if (tid == 0) ntiny_s = 0;
+    if (tid < 64) {
+        wk.confl[(size_t)b * 64 + tid] = 0ull;
+        wk.keepw[(size_t)b * 64 + tid] = 0ull;
+    }
+    __syncthreads();
 
     float box[4][4], score[4];
-    int cls[4], orig[4];
+    int cls[4], orig[4], key[4], rk[4];
     bool valid[4];
-    int nvalid = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int np = tid * 4 + u;          // position in (anchor, cell) order
+        const int np = tid * 4 + u;          // (anchor, cell) enumeration
         valid[u] = false;
         score[u] = 0.f;
         cls[u] = 0;
         orig[u] = 0;
+        key[u] = 0;
+        rk[u] = 0;
         if (np < N) {
             const int a = np / HW, cell = np % HW;
             const int n = cell * A + a;      // the reference's anchor index (:337-341)
@@ -106,18 +123,37 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             cls[u] = bc;
             orig[u] = n;
             valid[u] = best >= p.conf_thresh;
-            nvalid += valid[u] ? 1 : 0;
             if (p.cand_score) {      // full per-anchor tap (parity tests)
                 p.cand_score[(size_t)b * N + n] = best;
                 p.cand_cls[(size_t)b * N + n] = bc;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) p.cand_box[((size_t)b * N + n) * 4 + k] = box[u][k];
             }
+            if (valid[u]) {
+                // bin of the clamped centre; per-anchor extents of the clamped boxes
+                const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
+                const float ccx = 0.5f * (box[u][0] + box[u][2]), ccy = 0.5f * (box[u][1] + box[u][3]);
+                const int bx = min(p.Ws - 1, max(0, (int)(ccx * (float)p.Ws)));
+                const int by = min(p.Hs - 1, max(0, (int)(ccy * (float)p.Hs)));
+                key[u] = a * HW + by * p.Ws + bx;
+                rk[u] = atomicAdd(&hist[key[u]], 1);
+                atomicMax(&sstat[a][0], __float_as_uint(w));
+                atomicMax(&sstat[a][1], __float_as_uint(h));
+                atomicMin(&sstat[a][2], __float_as_uint(ar));
+                atomicMax(&sstat[a][3], __float_as_uint(ar));
+            }
         }
     }
-    // ---- block exclusive scan of nvalid (wave scan + 16 wave totals)
+    __syncthreads();
+    // ---- exclusive scan of the bin counts: 4 consecutive bins per thread
     const int lane = tid & 63, wave = tid >> 6;
-    int incl = nvalid;
+    int c4[4], mine = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        c4[u] = hist[tid * 4 + u];
+        mine += c4[u];
+    }
+    int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(incl, o, 64);
@@ -128,55 +164,43 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     if (tid == 0) {
         int s = 0;
         for (int w = 0; w < 16; ++w) { const int t = wsum[w]; wsum[w] = s; s += t; }
-        total = s;
+        wk.count[b] = s;
     }
     __syncthreads();
-    int pos = wsum[wave] + incl - nvalid;
-    const int M = total;
+    int run = wsum[wave] + incl - mine;
+    int *bs = wk.binstart + (size_t)b * (NMS_CAP + 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        hist[tid * 4 + u] = run;
+        bs[tid * 4 + u] = run;
+        run += c4[u];
+    }
+    if (tid == 1023) bs[NMS_CAP] = run;
+    __syncthreads();
+    // ---- scatter into (anchor, bin) order
     float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
     float *cs = wk.cscore + (size_t)b * NMS_CAP;
     int *cc = wk.ccls + (size_t)b * NMS_CAP;
     int *co = wk.corig + (size_t)b * NMS_CAP;
+    int *tl = wk.tiny + (size_t)b * NMS_CAP;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (valid[u]) {
+            const int pos = hist[key[u]] + rk[u];
             *(float4 *)(cb + (size_t)pos * 4) = make_float4(box[u][0], box[u][1], box[u][2], box[u][3]);
             cs[pos] = score[u];
             cc[pos] = cls[u];
             co[pos] = orig[u];
-            ++pos;
+            if ((box[u][2] - box[u][0]) * (box[u][3] - box[u][1]) < AREA_MIN) tl[atomicAdd(&ntiny_s, 1)] = pos;
         }
     }
-    if (tid == 0) wk.count[b] = M;
-    __syncthreads();     // the block's global stores are visible to the block after the barrier
-    // ---- per-64-block extents of the compacted list
-    const int nblk = (M + 63) >> 6;
-    for (int k = wave; k < nblk; k += 16) {
-        const int i = k * 64 + lane;
-        const bool v = i < M;
-        const float4 q = v ? *(const float4 *)(cb + (size_t)i * 4) : make_float4(0, 0, 0, 0);
-        const float w = q.z - q.x, h = q.w - q.y;
-        const float cx = 0.5f * (q.x + q.z), cy = 0.5f * (q.y + q.w), ar = w * h;
-        float cx0 = v ? cx : 3e38f, cx1 = v ? cx : -3e38f, cy0 = v ? cy : 3e38f, cy1 = v ? cy : -3e38f;
-        float wm = v ? w : 0.f, hm = v ? h : 0.f, a0 = v ? ar : 3e38f, a1 = v ? ar : 0.f;
+    if (tid < MAXA) {
+        float *as = wk.astat + ((size_t)b * MAXA + tid) * 4;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            cx0 = fminf(cx0, __shfl_xor(cx0, o, 64));
-            cx1 = fmaxf(cx1, __shfl_xor(cx1, o, 64));
-            cy0 = fminf(cy0, __shfl_xor(cy0, o, 64));
-            cy1 = fmaxf(cy1, __shfl_xor(cy1, o, 64));
-            wm = fmaxf(wm, __shfl_xor(wm, o, 64));
-            hm = fmaxf(hm, __shfl_xor(hm, o, 64));
-            a0 = fminf(a0, __shfl_xor(a0, o, 64));
-            a1 = fmaxf(a1, __shfl_xor(a1, o, 64));
-        }
-        if (lane == 0) {
-            BlockStat s;
-            s.cx0 = cx0; s.cx1 = cx1; s.cy0 = cy0; s.cy1 = cy1;
-            s.wmax = wm; s.hmax = hm; s.amin = a0; s.amax = a1;
-            wk.bstat[(size_t)b * 64 + k] = s;
-        }
+        for (int k = 0; k < 4; ++k) as[k] = __uint_as_float(sstat[tid][k]);
     }
+    __syncthreads();
+    if (tid == 0) wk.ntiny[b] = ntiny_s;
 }
 
 // ---- the reference's suppression test (slim_yolo_v2.py:159-171), same class assumed
@@ -212,209 +236,258 @@ __device__ __forceinline__ bool suppresses(const float4 a, float area_a, const f
 // |dcx| < (wi+wj)/2 - thr*max(wi,wj) <= (1-thr)*(wi+wj)/2 (same in y), and min(area)/max(area) > thr.
 // With a 0.1% margin the fp32 evaluation of the reference formula cannot land above thr either,
 // provided the union is not degenerate (area sum >= 1e-10) and thr >= 1e-4.
-#define PRUNE_MARGIN 1.001f
-#define PRUNE_EPS 1e-6f
-#define AREA_MIN 1e-10f
-
-// grid (NBLK, batch): one workgroup per (image, row-block); its 4 waves walk the column
-// blocks cb >= rb, skipping tiles by the block extents.
-__global__ __launch_bounds__(256) void mask_kernel(const HeadWork wk, float thr, int dbg) {
-    __shared__ BlockStat sstat[64];
-    __shared__ float4 sbox[4][64];
-    __shared__ int scls[4][64];
-    const int b = blockIdx.y, rb = blockIdx.x;
+// grid (CAP/1024, batch), 1024 threads: one thread per candidate, it owns row `i` of the bit
+// matrix.  The image's candidate boxes, classes and bin starts are staged in LDS first (81 KB),
+// so the walk itself never waits on global memory.
+__global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const HeadWork wk, float thr) {
+    extern __shared__ __attribute__((aligned(16))) char plds[];
+    float4 *sbox = (float4 *)plds;                                   // [CAP]
+    int *scls = (int *)(plds + NMS_CAP * 16);                        // [CAP]
+    int *sbin = (int *)(plds + NMS_CAP * 20);                        // [CAP + 8]
+    const int b = blockIdx.y;
     const int M = wk.count[b];
-    const int nblk = (M + 63) >> 6;
-    if (rb >= nblk) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < nblk) sstat[threadIdx.x] = wk.bstat[(size_t)b * 64 + threadIdx.x];
+    if ((int)blockIdx.x * 1024 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int A = p.A, Ws = p.Ws, Hs = p.Hs, HW = Hs * Ws;
+    {
+        const float4 *cbx4 = (const float4 *)(wk.cbox + (size_t)b * NMS_CAP * 4);
+        const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
+        const int *bs = wk.binstart + (size_t)b * (NMS_CAP + 8);
+        for (int q = tid; q < M; q += 1024) { sbox[q] = cbx4[q]; scls[q] = ccl[q]; }
+        for (int q = tid; q <= A * HW; q += 1024) sbin[q] = bs[q];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + tid;
+    const bool vi = i < M;
     const bool fast = thr >= 1e-4f && thr < 1e4f;
     const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
     const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
-    const float *cbx = wk.cbox + (size_t)b * NMS_CAP * 4;
-    const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
-    const int i = rb * 64 + lane;
-    const bool vi = i < M;
-    const float4 bi = vi ? *(const float4 *)(cbx + (size_t)i * 4) : make_float4(0, 0, 0, 0);
-    const int ci = vi ? ccl[i] : -1;
+    const float *as = wk.astat + (size_t)b * MAXA * 4;
+    unsigned long long *row = wk.mask + ((size_t)b * NMS_CAP + (vi ? i : 0)) * 64;
+    const float4 bi = vi ? sbox[i] : make_float4(0, 0, 0, 0);
+    const int ci = vi ? scls[i] : -1;
     const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
     const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
-    unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
-    unsigned long long *tm = wk.tilemap + (size_t)b * 64, *cf = wk.confl + (size_t)b * 64;
-    __syncthreads();
-    const BlockStat sa = sstat[rb];
-    unsigned long long tiles_done = 0, row_any = 0;
-    if (dbg == 1) return;
-    for (int cb = rb + wave; cb < nblk; cb += 4) {
-        const BlockStat sb = sstat[cb];
-        if (fast && sa.amin + sb.amin >= AREA_MIN) {
-            const float dx = fmaxf(0.f, fmaxf(sb.cx0 - sa.cx1, sa.cx0 - sb.cx1));
-            const float dy = fmaxf(0.f, fmaxf(sb.cy0 - sa.cy1, sa.cy0 - sb.cy1));
-            if (dx >= kr * (sa.wmax + sb.wmax) + PRUNE_EPS || dy >= kr * (sa.hmax + sb.hmax) + PRUNE_EPS ||
-                sa.amax <= thr_lo * sb.amin || sb.amax <= thr_lo * sa.amin)
-                continue;                      // no pair of this tile can exceed thr
+    int curw = -1;
+    unsigned long long curbits = 0ull, touched = 0ull, anybits = 0ull;
+    auto flush = [&]() {
+        if (curw >= 0) {
+            if ((touched >> curw) & 1ull) row[curw] |= curbits;
+            else row[curw] = curbits;
+            touched |= 1ull << curw;
+            anybits |= curbits;
         }
-        if (dbg == 2) continue;
-        const int jg = cb * 64 + lane;
-        __builtin_amdgcn_wave_barrier();
-        sbox[wave][lane] = (jg < M) ? *(const float4 *)(cbx + (size_t)jg * 4) : make_float4(0, 0, 0, 0);
-        scls[wave][lane] = (jg < M) ? ccl[jg] : -2;
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long rowbits = 0, mycol = 0;
-        const int jn = min(64, M - cb * 64);
-        for (int j = 0; j < jn; ++j) {
-            const float4 bj = sbox[wave][j];
-            const int cj = scls[wave][j];
-            const float wj = bj.z - bj.x, hj = bj.w - bj.y, aj = wj * hj;
-            bool cand = (ci == cj) && (i != cb * 64 + j);
-            if (fast) {
-                const float dx = fabsf(cxi - 0.5f * (bj.x + bj.z)), dy = fabsf(cyi - 0.5f * (bj.y + bj.w));
-                const bool far = dx >= kr * (wi + wj) + PRUNE_EPS || dy >= kr * (hi + hj) + PRUNE_EPS ||
-                                 fminf(ai, aj) <= thr_lo * fmaxf(ai, aj);
-                cand = cand && !(far && (ai + aj >= AREA_MIN));
-            }
-            bool s = false;
-            if (__any(cand)) {
-                s = fast ? suppresses(bi, ai, bj, aj, thr, q_hi, q_lo) : suppresses_exact(bi, ai, bj, aj, thr);
-                s = s && cand;
-            }
-            rowbits |= s ? (1ull << j) : 0ull;
-            const unsigned long long colbits = __ballot(s);   // bits over i for column j
-            if (lane == j) mycol = colbits;
+    };
+    auto visit = [&](int q) {
+        const float4 bj = sbox[q];
+        const int cj = scls[q];
+        if (q == i || cj != ci) return;
+        const float wj = bj.z - bj.x, hj = bj.w - bj.y, aj = wj * hj;
+        if (fast && (ai + aj >= AREA_MIN)) {
+            const float dx = fabsf(cxi - 0.5f * (bj.x + bj.z)), dy = fabsf(cyi - 0.5f * (bj.y + bj.w));
+            if (dx >= kr * (wi + wj) + PRUNE_EPS || dy >= kr * (hi + hj) + PRUNE_EPS ||
+                fminf(ai, aj) <= thr_lo * fmaxf(ai, aj))
+                return;
         }
-        if (vi) mk[(size_t)i * 64 + cb] = rowbits;
-        if (cb != rb && jg < M) mk[(size_t)jg * 64 + rb] = mycol;
-        tiles_done |= 1ull << cb;
-        row_any |= rowbits;
-        const unsigned long long cnz = __ballot(mycol != 0ull);
-        if (lane == 0 && cb != rb) {
-            atomicOr(&tm[cb], 1ull << rb);
-            if (cnz) atomicOr(&cf[cb], cnz);
+        // the reference's predicate (slim_yolo_v2.py:159-171); IEEE division only near the threshold
+        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+        const float iw = fmaxf(1e-28f, xx2 - xx1), ih = fmaxf(1e-28f, yy2 - yy1);
+        const float inter = iw * ih, den = ai + aj - inter;
+        const float qv = inter * __builtin_amdgcn_rcpf(den);
+        bool s;
+        if (fast && den > 1e-30f && den < 1e30f && (qv > q_hi || qv < q_lo)) s = qv > q_hi;
+        else s = !(inter / den <= thr);
+        if (s) {
+            const int w = q >> 6;
+            if (w != curw) { flush(); curw = w; curbits = 0ull; }
+            curbits |= 1ull << (q & 63);
+        }
+    };
+    if (vi) {
+        for (int a2 = 0; a2 < A; ++a2) {
+            const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1], amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
+            if (amax < amin) continue;                         // no candidate of this anchor
+            int bx0 = 0, bx1 = Ws - 1, by0 = 0, by1 = Hs - 1;
+            if (fast && (ai + amin >= AREA_MIN)) {
+                if (ai <= thr_lo * amin || amax <= thr_lo * ai) continue;    // area ratio rules the anchor out
+                const float rx = kr * (wi + wmax) + PRUNE_EPS, ry = kr * (hi + hmax) + PRUNE_EPS;
+                bx0 = max(0, (int)floorf((cxi - rx) * (float)Ws));
+                bx1 = min(Ws - 1, (int)floorf((cxi + rx) * (float)Ws));
+                by0 = max(0, (int)floorf((cyi - ry) * (float)Hs));
+                by1 = min(Hs - 1, (int)floorf((cyi + ry) * (float)Hs));
+            }
+            for (int by = by0; by <= by1; ++by) {
+                const int k0 = a2 * HW + by * Ws;
+                const int q0 = sbin[k0 + bx0], q1 = sbin[k0 + bx1 + 1];
+                for (int q = q0; q < q1; ++q) visit(q);
+            }
+        }
+        if (fast && ai < AREA_MIN) {                               // degenerate boxes see each other
+            const int nt = wk.ntiny[b];
+            const int *tl = wk.tiny + (size_t)b * NMS_CAP;
+            for (int t = 0; t < nt; ++t) visit(tl[t]);
+        }
+        flush();
+        wk.rowvalid[(size_t)b * NMS_CAP + i] = touched;
+    }
+    const unsigned long long cm = __ballot(vi && anybits != 0ull);
+    if (lane == 0 && cm) atomicOr(&wk.confl[(size_t)b * 64 + (i >> 6)], cm);
+}
+#define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4)
+
+// ---- resolve_kernel: grid (classes, batch), one workgroup per (image, class).
+// Conflicts only exist inside a class, so every class is an independent greedy walk.  The
+// class's conflicted candidates are sorted by (score desc, anchor index asc); their rows are
+// re-indexed from compact positions to sorted RANKS (bit r' of row r = ranks r and r' suppress
+// each other), 64 ranks per block.  For block k each lane owns one rank: the AND of its row
+// with the kept ranks of blocks < k is a parallel loop; inside the block one scalar loop walks
+// only the surviving candidates (find-first-set), clearing what each kept one suppresses.
+#define RES_LDS_ROWS 832           // rank-space rows kept in LDS: 13 blocks of 64 ranks
+#define RES_LDS_STRIDE 15          // words per LDS row (13 used); odd-ish stride = no bank conflicts
+
+// rows re-indexed to ranks + the ordered walk; R is the LDS array or the global scratch
+template <bool IN_LDS>
+__device__ __forceinline__ void resolve_body(unsigned long long *R, const unsigned long long *keys,
+                                             const unsigned short *rank_of, unsigned long long *kept,
+                                             const HeadWork &wk, int b, int nconf, int tid, int dbg) {
+    constexpr int RS = IN_LDS ? RES_LDS_STRIDE : 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nwr = (nconf + 63) >> 6;
+    const unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
+    const unsigned long long *rv = wk.rowvalid + (size_t)b * NMS_CAP;
+    for (int r = tid; r < nconf; r += 1024) {
+        const int pos = (int)(keys[r] & 0xfffu);
+        unsigned long long *row = R + (size_t)(IN_LDS ? r : pos) * RS;
+        for (int w = 0; w < nwr; ++w) row[w] = 0ull;
+        unsigned long long valid = rv[pos];
+        while (valid) {
+            // up to 8 words of the position-space row in flight at once
+            int wi[8];
+            unsigned long long wd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                wi[u] = valid ? __ffsll((long long)valid) - 1 : -1;
+                valid &= valid - (valid ? 1ull : 0ull);
+                wd[u] = wi[u] >= 0 ? mk[(size_t)pos * 64 + wi[u]] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                unsigned long long bits = wd[u];
+                while (bits) {
+                    const int q = wi[u] * 64 + __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const int rr = rank_of[q];
+                    row[rr >> 6] |= 1ull << (rr & 63);
+                }
+            }
         }
     }
-    const unsigned long long rnz = __ballot(row_any != 0ull);
-    if (lane == 0) {
-        if (tiles_done) atomicOr(&tm[rb], tiles_done);
-        if (rnz) atomicOr(&cf[rb], rnz);
+    __syncthreads();
+    if (wave != 0 || dbg == 4) return;
+    for (int k = 0; k < nwr; ++k) {
+        const int r = k * 64 + lane;
+        const bool v = r < nconf;
+        const int pos = v ? (int)(keys[r] & 0xfffu) : 0;
+        const unsigned long long *row = R + (size_t)(IN_LDS ? (v ? r : 0) : pos) * RS;
+        unsigned long long sup = 0ull;
+        for (int w = 0; w < k; ++w) sup |= row[w] & kept[w];
+        const unsigned long long own = v ? row[k] : 0ull;
+        unsigned long long alive = __ballot(v && sup == 0ull);
+        unsigned long long keptk = 0ull;
+        while (alive) {
+            const int u = __ffsll((long long)alive) - 1;
+            keptk |= 1ull << u;
+            const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)own, u);
+            const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(own >> 32), u);
+            alive &= ~((((unsigned long long)hi << 32) | lo) | (1ull << u));
+        }
+        if (lane == 0) kept[k] = keptk;
+        __builtin_amdgcn_wave_barrier();
+        if (v && ((keptk >> lane) & 1ull)) atomicOr(&wk.keepw[(size_t)b * 64 + (pos >> 6)], 1ull << (pos & 63));
     }
 }
 
-__global__ __launch_bounds__(1024) void scan_kernel(const HeadParams p, const HeadWork wk, int dbg) {
-    __shared__ unsigned long long keys[NMS_CAP];    // conflicted candidates, sorted
-    __shared__ unsigned long long stg[2][64][64];   // staged mask rows of 64 consecutive ranks
-    __shared__ unsigned long long stile[64];
-    __shared__ unsigned long long keepw[64];        // by compact position
-    __shared__ unsigned long long keepn[64];        // by anchor index
-    __shared__ int wbase[64];
+__global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long rlds[];
+    __shared__ unsigned long long keys[NMS_CAP];      // gathered, then sorted
+    __shared__ unsigned short rank_of[NMS_CAP];
+    __shared__ unsigned long long kept[64];
     __shared__ int nconf_s;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, cls = blockIdx.x, tid = threadIdx.x;
     const int M = wk.count[b];
-    const int nw = (M + 63) >> 6;
-    const float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
     const float *cs = wk.cscore + (size_t)b * NMS_CAP;
     const int *cc = wk.ccls + (size_t)b * NMS_CAP;
     const int *co = wk.corig + (size_t)b * NMS_CAP;
-    const unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
     const unsigned long long *cf = wk.confl + (size_t)b * 64;
     if (tid == 0) nconf_s = 0;
-    if (tid < 64) {
-        const unsigned long long vm = tid < nw ? ((tid == nw - 1 && (M & 63)) ? ((1ull << (M & 63)) - 1ull) : ~0ull) : 0ull;
-        keepw[tid] = vm & ~(tid < nw ? cf[tid] : 0ull);      // conflict-free candidates survive
-        keepn[tid] = 0ull;
-        stile[tid] = wk.tilemap[(size_t)b * 64 + tid];
-    }
+    if (tid < 64) kept[tid] = 0ull;
     __syncthreads();
-    // ---- conflicted candidates -> keys (score desc, anchor index asc)
     for (int pos = tid; pos < M; pos += 1024) {
-        if ((cf[pos >> 6] >> (pos & 63)) & 1ull) {
+        if (((cf[pos >> 6] >> (pos & 63)) & 1ull) && cc[pos] == cls) {
             const int k = atomicAdd(&nconf_s, 1);
-            // anchor index in bits 12..31 orders ties; compact position in bits 0..11
             keys[k] = ((unsigned long long)(~__float_as_uint(cs[pos])) << 32) |
                       ((unsigned long long)(unsigned int)co[pos] << 12) | (unsigned int)pos;
         }
     }
     __syncthreads();
     const int nconf = nconf_s;
-    if (dbg == 11) return;
-    int P2 = 1;
-    while (P2 < nconf) P2 <<= 1;
-    for (int i = nconf + tid; i < P2; i += 1024) keys[i] = ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= P2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P2; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long x = keys[i], y = keys[ixj];
-                    const bool asc = (i & k) == 0;
-                    if ((x > y) == asc) { keys[i] = y; keys[ixj] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // ---- serial resolution: waves 1..15 stage the rows of the next 64 ranks into LDS while
-    //      wave 0 (lane w = word w of the "removed" set) walks the current 64
-    if (dbg == 12) return;
-    const int nchunks = (nconf + 63) >> 6;
-    auto stage = [&](int c, int buf) {
-        // 15 staging waves x up to 5 rows each: issue all global loads, then the LDS stores
-        unsigned long long word[5];
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int k = wave - 1 + 15 * u;
-            const int r = c * 64 + k;
-            word[u] = 0ull;
-            if (k < 64 && r < nconf) {
-                const int ix = (int)(keys[r] & 0xfffu);
-                if (lane < nw && ((stile[ix >> 6] >> lane) & 1ull)) word[u] = mk[(size_t)ix * 64 + lane];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int k = wave - 1 + 15 * u;
-            if (k < 64) stg[buf][k][lane] = word[u];
-        }
-    };
-    if (wave != 0 && nchunks > 0) stage(0, 0);
-    __syncthreads();
-    unsigned long long removed = 0, keep = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        if (wave != 0) {
-            if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
-        } else {
-            const int kn = min(64, nconf - c * 64);
-            for (int k0 = 0; k0 < kn; k0 += 8) {
-                // the 8 ranks' indices and rows do not depend on the decisions: fetch them first
-                int ii[8];
-                unsigned long long rr[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    ii[u] = (int)(keys[c * 64 + k0 + u] & 0xfffu);
-                    rr[u] = stg[c & 1][k0 + u][lane];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (k0 + u < kn) {
-                        const int i = __builtin_amdgcn_readfirstlane(ii[u]);
-                        const int w = i >> 6, bit = i & 63;
-                        const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)removed, w);
-                        const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(removed >> 32), w);
-                        const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
-                        const bool kept = !((rw >> bit) & 1ull);
-                        if (kept && lane == w) keep |= 1ull << bit;
-                        removed |= kept ? rr[u] : 0ull;
+    if (nconf == 0 || dbg == 1) return;
+    if (nconf <= 1024) {
+        // rank by counting: keys are unique, rank = number of smaller keys (no barriers)
+        const unsigned long long mine = tid < nconf ? keys[tid] : ~0ull;
+        int rk = 0;
+        for (int j = 0; j < nconf; ++j) rk += keys[j] < mine ? 1 : 0;
+        __syncthreads();
+        if (tid < nconf) keys[rk] = mine;
+        __syncthreads();
+    } else {
+        int P2 = 1;
+        while (P2 < nconf) P2 <<= 1;
+        for (int i = nconf + tid; i < P2; i += 1024) keys[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= P2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P2; i += 1024) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long x = keys[i], y = keys[ixj];
+                        const bool asc = (i & k) == 0;
+                        if ((x > y) == asc) { keys[i] = y; keys[ixj] = x; }
                     }
                 }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
-    if (wave == 0) keepw[lane] |= keep;
+    if (dbg == 2) return;
+    for (int r = tid; r < nconf; r += 1024) rank_of[(int)(keys[r] & 0xfffu)] = (unsigned short)r;
     __syncthreads();
-    if (dbg == 13) return;
-    // ---- survivors -> bit-set over anchor indices, then emit in that order
+    if (dbg == 3) return;
+    if (nconf <= RES_LDS_ROWS) resolve_body<true>(rlds, keys, rank_of, kept, wk, b, nconf, tid, dbg);
+    else resolve_body<false>(wk.rmask + (size_t)b * NMS_CAP * 64, keys, rank_of, kept, wk, b, nconf, tid, dbg);
+}
+
+// ---- emit_kernel: one workgroup per image: survivors = conflict-free candidates + resolved
+// ones, written in anchor-index order into the padded outputs.
+__global__ __launch_bounds__(1024) void emit_kernel(const HeadParams p, const HeadWork wk) {
+    __shared__ unsigned long long keepw[64];        // by compact position
+    __shared__ unsigned long long keepn[64];        // by anchor index
+    __shared__ int wbase[64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int M = wk.count[b];
+    const int nw = (M + 63) >> 6;
+    const float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
+    const float *cs = wk.cscore + (size_t)b * NMS_CAP;
+    const int *cc = wk.ccls + (size_t)b * NMS_CAP;
+    const int *co = wk.corig + (size_t)b * NMS_CAP;
+    if (tid < 64) {
+        const unsigned long long vm = tid < nw ? ((tid == nw - 1 && (M & 63)) ? ((1ull << (M & 63)) - 1ull) : ~0ull) : 0ull;
+        const unsigned long long cf = tid < nw ? wk.confl[(size_t)b * 64 + tid] : 0ull;
+        keepw[tid] = (vm & ~cf) | (wk.keepw[(size_t)b * 64 + tid] & cf & vm);
+        keepn[tid] = 0ull;
+    }
+    __syncthreads();
     for (int pos = tid; pos < M; pos += 1024) {
         if ((keepw[pos >> 6] >> (pos & 63)) & 1ull) {
             const int n = co[pos];
@@ -451,6 +524,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(const HeadParams p, const He
     }
 }
 
+int y355_prepare_head(void) {
+    int e = (int)hipFuncSetAttribute((const void *)resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     RES_LDS_ROWS * RES_LDS_STRIDE * 8);
+    if (e) return e;
+    return (int)hipFuncSetAttribute((const void *)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
+}
+
 void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid) {
     HeadWork wk;
     wk.cbox = (float *)ws.cbox;
@@ -459,12 +539,18 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     wk.corig = (int *)ws.corig;
     wk.count = (int *)ws.count;
     wk.mask = (unsigned long long *)ws.mask;
-    wk.bstat = (BlockStat *)ws.bstat;
-    wk.tilemap = (unsigned long long *)ws.tilemap;
+    wk.rowvalid = (unsigned long long *)ws.rowvalid;
     wk.confl = (unsigned long long *)ws.confl;
+    wk.binstart = (int *)ws.binstart;
+    wk.astat = (float *)ws.astat;
+    wk.tiny = (int *)ws.tiny;
+    wk.ntiny = (int *)ws.ntiny;
+    wk.keepw = (unsigned long long *)ws.keepw;
+    wk.rmask = (unsigned long long *)ws.rmask;
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);
+    hipLaunchKernelGGL(pairs_kernel, dim3(NMS_CAP / 1024, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
     static int dbg = getenv("Y355_NMS_DBG") ? atoi(getenv("Y355_NMS_DBG")) : 0;
-    hipLaunchKernelGGL(mask_kernel, dim3(NBLK, batch), dim3(256), 0, s, wk, p.nms_thresh, dbg);
-    hipLaunchKernelGGL(scan_kernel, dim3(batch), dim3(1024), 0, s, p, wk, dbg);
+    hipLaunchKernelGGL(resolve_kernel, dim3(p.C, batch), dim3(1024), RES_LDS_ROWS * RES_LDS_STRIDE * 8, s, wk, dbg);
+    hipLaunchKernelGGL(emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
 }

@@ -153,9 +153,12 @@ struct HeadParams {
     int *out_count;
 };
 #define Y355_NMS_CAP 4096   // anchors per image the NMS workspace is sized for
-// head_nms.hip workspace, per image: cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP],
-// corig i32[CAP], count i32, mask u64[CAP][64], bstat 8 x f32[64], tilemap u64[64], confl u64[64].
-struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *mask, *bstat, *tilemap, *confl; };
+#define Y355_HEAD_MAXA 16
+// head_nms.hip workspace, per image: cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP], corig i32[CAP],
+// count i32, mask u64[CAP][64], rowvalid u64[CAP], confl u64[64], binstart i32[CAP+8],
+// astat f32[16][4], tiny i32[CAP], ntiny i32.
+struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *mask, *rowvalid, *confl, *binstart, *astat, *tiny, *ntiny, *keepw, *rmask; };
+int y355_prepare_head(void);
 // decode + compact, pruned suppression bit-matrix, ordered scan.  `mid` (optional) is recorded
 // between decode and NMS.
 void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid);
