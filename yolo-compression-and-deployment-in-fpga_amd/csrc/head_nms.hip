@@ -338,90 +338,34 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
 
 // ---- resolve_kernel: grid (classes, batch), one workgroup per (image, class).
 // Conflicts only exist inside a class, so every class is an independent greedy walk.  The
-// class's conflicted candidates are sorted by (score desc, anchor index asc); their rows are
-// re-indexed from compact positions to sorted RANKS (bit r' of row r = ranks r and r' suppress
-// each other), 64 ranks per block.  For block k each lane owns one rank: the AND of its row
-// with the kept ranks of blocks < k is a parallel loop; inside the block one scalar loop walks
-// only the surviving candidates (find-first-set), clearing what each kept one suppresses.
-#define RES_LDS_ROWS 832           // rank-space rows kept in LDS: 13 blocks of 64 ranks
-#define RES_LDS_STRIDE 15          // words per LDS row (13 used); odd-ish stride = no bank conflicts
+// class's conflicted candidates are sorted by (score desc, anchor index asc) and every one
+// gets the list of its conflicting candidates that come EARLIER in that order (u16 ranks in
+// LDS).  The walk takes 64 ranks per step, one per lane: a lane is suppressed if one of its
+// earlier neighbours from a previous step was kept (parallel check against the kept bit-set);
+// neighbours inside the same step are settled by a scalar find-first-set loop over the few
+// lanes that have any.
+#define RES_EDGE_CAP 36864          // earlier-neighbour edges kept in LDS (u16 ranks, 72 KiB)
 
-// rows re-indexed to ranks + the ordered walk; R is the LDS array or the global scratch
-template <bool IN_LDS>
-__device__ __forceinline__ void resolve_body(unsigned long long *R, const unsigned long long *keys,
-                                             const unsigned short *rank_of, unsigned long long *kept,
-                                             const HeadWork &wk, int b, int nconf, int tid, int dbg) {
-    constexpr int RS = IN_LDS ? RES_LDS_STRIDE : 64;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int nwr = (nconf + 63) >> 6;
-    const unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
-    const unsigned long long *rv = wk.rowvalid + (size_t)b * NMS_CAP;
-    for (int r = tid; r < nconf; r += 1024) {
-        const int pos = (int)(keys[r] & 0xfffu);
-        unsigned long long *row = R + (size_t)(IN_LDS ? r : pos) * RS;
-        for (int w = 0; w < nwr; ++w) row[w] = 0ull;
-        unsigned long long valid = rv[pos];
-        while (valid) {
-            // up to 8 words of the position-space row in flight at once
-            int wi[8];
-            unsigned long long wd[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                wi[u] = valid ? __ffsll((long long)valid) - 1 : -1;
-                valid &= valid - (valid ? 1ull : 0ull);
-                wd[u] = wi[u] >= 0 ? mk[(size_t)pos * 64 + wi[u]] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                unsigned long long bits = wd[u];
-                while (bits) {
-                    const int q = wi[u] * 64 + __ffsll((long long)bits) - 1;
-                    bits &= bits - 1;
-                    const int rr = rank_of[q];
-                    row[rr >> 6] |= 1ull << (rr & 63);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (wave != 0 || dbg == 4) return;
-    for (int k = 0; k < nwr; ++k) {
-        const int r = k * 64 + lane;
-        const bool v = r < nconf;
-        const int pos = v ? (int)(keys[r] & 0xfffu) : 0;
-        const unsigned long long *row = R + (size_t)(IN_LDS ? (v ? r : 0) : pos) * RS;
-        unsigned long long sup = 0ull;
-        for (int w = 0; w < k; ++w) sup |= row[w] & kept[w];
-        const unsigned long long own = v ? row[k] : 0ull;
-        unsigned long long alive = __ballot(v && sup == 0ull);
-        unsigned long long keptk = 0ull;
-        while (alive) {
-            const int u = __ffsll((long long)alive) - 1;
-            keptk |= 1ull << u;
-            const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)own, u);
-            const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(own >> 32), u);
-            alive &= ~((((unsigned long long)hi << 32) | lo) | (1ull << u));
-        }
-        if (lane == 0) kept[k] = keptk;
-        __builtin_amdgcn_wave_barrier();
-        if (v && ((keptk >> lane) & 1ull)) atomicOr(&wk.keepw[(size_t)b * 64 + (pos >> 6)], 1ull << (pos & 63));
-    }
-}
-
+// ---- resolve_kernel (continued): sort, edge lists, ordered walk
 __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long rlds[];
     __shared__ unsigned long long keys[NMS_CAP];      // gathered, then sorted
     __shared__ unsigned short rank_of[NMS_CAP];
-    __shared__ unsigned long long kept[64];
+    __shared__ int eoff[NMS_CAP + 1];                 // per rank: start of its earlier-neighbour list
+    __shared__ unsigned short edges[RES_EDGE_CAP];
+    __shared__ unsigned long long keptw[64];          // kept ranks, 64 per word
+    __shared__ int wsum[16];
     __shared__ int nconf_s;
-    const int b = blockIdx.y, cls = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, cls = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = wk.count[b];
     const float *cs = wk.cscore + (size_t)b * NMS_CAP;
     const int *cc = wk.ccls + (size_t)b * NMS_CAP;
     const int *co = wk.corig + (size_t)b * NMS_CAP;
     const unsigned long long *cf = wk.confl + (size_t)b * 64;
+    const unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
+    const unsigned long long *rv = wk.rowvalid + (size_t)b * NMS_CAP;
     if (tid == 0) nconf_s = 0;
-    if (tid < 64) kept[tid] = 0ull;
+    if (tid < 64) keptw[tid] = 0ull;
     __syncthreads();
     for (int pos = tid; pos < M; pos += 1024) {
         if (((cf[pos >> 6] >> (pos & 63)) & 1ull) && cc[pos] == cls) {
@@ -433,15 +377,8 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
     __syncthreads();
     const int nconf = nconf_s;
     if (nconf == 0 || dbg == 1) return;
-    if (nconf <= 1024) {
-        // rank by counting: keys are unique, rank = number of smaller keys (no barriers)
-        const unsigned long long mine = tid < nconf ? keys[tid] : ~0ull;
-        int rk = 0;
-        for (int j = 0; j < nconf; ++j) rk += keys[j] < mine ? 1 : 0;
-        __syncthreads();
-        if (tid < nconf) keys[rk] = mine;
-        __syncthreads();
-    } else {
+    // ---- sort by (score desc, anchor index asc)
+    {
         int P2 = 1;
         while (P2 < nconf) P2 <<= 1;
         for (int i = nconf + tid; i < P2; i += 1024) keys[i] = ~0ull;
@@ -463,9 +400,155 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
     if (dbg == 2) return;
     for (int r = tid; r < nconf; r += 1024) rank_of[(int)(keys[r] & 0xfffu)] = (unsigned short)r;
     __syncthreads();
-    if (dbg == 3) return;
-    if (nconf <= RES_LDS_ROWS) resolve_body<true>(rlds, keys, rank_of, kept, wk, b, nconf, tid, dbg);
-    else resolve_body<false>(wk.rmask + (size_t)b * NMS_CAP * 64, keys, rank_of, kept, wk, b, nconf, tid, dbg);
+    // ---- per rank: the conflicting candidates that come EARLIER in the order.  Words of the
+    //      position-space row are fetched once (up to 16 in flight) and walked twice.
+    constexpr int RPT = NMS_CAP / 1024;                 // ranks per thread
+    // fetch the (up to 16) conflict words of rank r's row; false if the row has more
+    auto fetch = [&](int r, unsigned long long (&wd)[16], int (&wix)[16]) -> bool {
+        const int pos = (int)(keys[r] & 0xfffu);
+        unsigned long long valid = rv[pos];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            wd[u] = 0ull;
+            wix[u] = 0;
+            if (valid) {
+                wix[u] = __ffsll((long long)valid) - 1;
+                valid &= valid - 1;
+                wd[u] = mk[(size_t)pos * 64 + wix[u]];
+            }
+        }
+        return valid == 0ull;
+    };
+#pragma unroll 1
+    for (int t = 0; t < RPT; ++t) {
+        const int r = tid + t * 1024;
+        if (r < nconf) {
+            unsigned long long wd[16];
+            int wix[16];
+            int c = 0;
+            if (!fetch(r, wd, wix)) {
+                c = RES_EDGE_CAP + 1;                   // > 16 conflict words: take the slow path
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    unsigned long long bits = wd[u];
+                    while (bits) {
+                        const int q = wix[u] * 64 + __ffsll((long long)bits) - 1;
+                        bits &= bits - 1;
+                        c += rank_of[q] < r ? 1 : 0;
+                    }
+                }
+            }
+            eoff[r] = c;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counts in rank order (rank = tid + t*1024: scan per t, chained)
+    int base = 0;
+#pragma unroll 1
+    for (int t = 0; t < RPT; ++t) {
+        const int r = tid + t * 1024;
+        const int c = r < nconf ? eoff[r] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wb = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; if (w < wave) wb += v; tot += v; }
+        if (r < nconf) eoff[r] = base + wb + incl - c;
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) eoff[nconf] = base;
+    const bool overflow = base > RES_EDGE_CAP;          // wave-uniform (same value in every thread)
+    if (!overflow) {
+#pragma unroll 1
+        for (int t = 0; t < RPT; ++t) {
+            const int r = tid + t * 1024;
+            if (r < nconf) {
+                unsigned long long wd[16];
+                int wix[16];
+                fetch(r, wd, wix);
+                int e = eoff[r];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    unsigned long long bits = wd[u];
+                    while (bits) {
+                        const int q = wix[u] * 64 + __ffsll((long long)bits) - 1;
+                        bits &= bits - 1;
+                        const int rq = rank_of[q];
+                        if (rq < r) edges[e++] = (unsigned short)rq;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0 || dbg == 4) return;
+    // ---- ordered walk, 64 ranks per step.  sup: an earlier neighbour of an earlier block is
+    //      kept; own: earlier neighbours inside this block, settled by the scalar loop
+    const int nblk = (nconf + 63) >> 6;
+    for (int k = 0; k < nblk; ++k) {
+        const int r = k * 64 + lane;
+        const bool v = r < nconf;
+        const int pos = v ? (int)(keys[r] & 0xfffu) : 0;
+        bool sup = false;
+        unsigned long long own = 0ull;
+        if (!overflow) {
+            const int e0 = v ? eoff[r] : 0, e1 = v ? eoff[r + 1] : 0;
+            for (int e = e0; e < e1; e += 4) {          // 4 edges per trip: the LDS reads overlap
+                int rq[4];
+                unsigned long long kw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rq[u] = edges[min(e + u, RES_EDGE_CAP - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kw[u] = keptw[(rq[u] >> 6) & 63];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (e + u < e1) {
+                        const unsigned long long bit = 1ull << (rq[u] & 63);
+                        if ((rq[u] >> 6) < k) sup = sup || (kw[u] & bit) != 0ull;
+                        else own |= bit;
+                    }
+                }
+            }
+        } else if (v) {
+            // slow path (very dense conflicts): walk the position-space row in global memory
+            unsigned long long valid = rv[pos];
+            while (valid) {
+                const int w = __ffsll((long long)valid) - 1;
+                valid &= valid - 1;
+                unsigned long long bits = mk[(size_t)pos * 64 + w];
+                while (bits) {
+                    const int q = w * 64 + __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const int rq = rank_of[q];
+                    if (rq < r) {
+                        const unsigned long long bit = 1ull << (rq & 63);
+                        if ((rq >> 6) < k) sup = sup || (keptw[rq >> 6] & bit) != 0ull;
+                        else own |= bit;
+                    }
+                }
+            }
+        }
+        const unsigned long long alive = __ballot(v && !sup);
+        unsigned long long keptk = __ballot(v && !sup && own == 0ull);
+        unsigned long long hard = alive & ~keptk;
+        while (hard) {
+            const int u = __ffsll((long long)hard) - 1;
+            hard &= hard - 1;
+            const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)own, u);
+            const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(own >> 32), u);
+            if (((((unsigned long long)hi << 32) | lo) & keptk) == 0ull) keptk |= 1ull << u;
+        }
+        if (lane == 0) keptw[k] = keptk;
+        __builtin_amdgcn_wave_barrier();
+        if (v && ((keptk >> lane) & 1ull)) atomicOr(&wk.keepw[(size_t)b * 64 + (pos >> 6)], 1ull << (pos & 63));
+    }
 }
 
 // ---- emit_kernel: one workgroup per image: survivors = conflict-free candidates + resolved
@@ -525,9 +608,6 @@ __global__ __launch_bounds__(1024) void emit_kernel(const HeadParams p, const He
 }
 
 int y355_prepare_head(void) {
-    int e = (int)hipFuncSetAttribute((const void *)resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     RES_LDS_ROWS * RES_LDS_STRIDE * 8);
-    if (e) return e;
     return (int)hipFuncSetAttribute((const void *)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
 }
 
@@ -551,6 +631,6 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     if (mid) (void)hipEventRecord(mid, s);
     hipLaunchKernelGGL(pairs_kernel, dim3(NMS_CAP / 1024, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
     static int dbg = getenv("Y355_NMS_DBG") ? atoi(getenv("Y355_NMS_DBG")) : 0;
-    hipLaunchKernelGGL(resolve_kernel, dim3(p.C, batch), dim3(1024), RES_LDS_ROWS * RES_LDS_STRIDE * 8, s, wk, dbg);
+    hipLaunchKernelGGL(resolve_kernel, dim3(p.C, batch), dim3(1024), 0, s, wk, dbg);
     hipLaunchKernelGGL(emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
 }
