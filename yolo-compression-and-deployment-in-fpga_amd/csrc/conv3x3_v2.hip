@@ -11,15 +11,25 @@
 //     the whole layer's fragments stay resident in LDS instead;
 //   * one raw s_barrier per k-step behind a COUNTED s_waitcnt vmcnt(N) (never 0 inside a tile
 //     except its first two steps, which also drain the previous tile's stores).
-// Pixel rows in LDS keep the 16-byte pad of the register-staged variant (conflict-free
-// ds_read_b128); the DMA lanes that fall on pad bytes read a dummy address.
+// LDS pixel rows are unpadded (16 / 32 / 64 bytes).  For 64-byte rows the four 16-byte chunks
+// of pixel p are stored at chunk ^ ((p >> 1) & 3): with that XOR the ds_read_b128 of an MFMA
+// A fragment (16 pixel rows x 4 k-groups) is bank-conflict free for contiguous pixels and for
+// 2x2 pooling-window order (4 LDS cycles instead of 8).  The DMA applies the XOR on its SOURCE
+// address, the MFMA side on its read address (LDS-DMA destinations are lane-linear).
 #include "y355_common.h"
+
+// -DY355_DIAG=1 builds the ablation switches (ConvParams.mode bits 8..) and the s_memtime
+// stamps into the kernel; the production build has neither (they fragment the k-step into
+// basic blocks and stop the scheduler from overlapping LDS reads with the MFMAs).
+#ifndef Y355_DIAG
+#define Y355_DIAG 0
+#endif
 
 template <int CIN>
 struct KGeom2 {
     static constexpr int CC = CIN < 64 ? CIN : 64;                // channels per chunk
     static constexpr int NCH = CIN / CC;
-    static constexpr int STRIDE = (CC == 16) ? 16 : CC + 16;      // LDS bytes per pixel
+    static constexpr int STRIDE = CC;                             // LDS bytes per pixel (no padding)
     static constexpr int SPC = (CC == 16) ? 3 : (CC == 32) ? 5 : 9;   // k-steps per chunk
     static constexpr int KS = NCH * SPC;
 };
@@ -54,20 +64,26 @@ __device__ __forceinline__ void store_bytes2(int8_t *dst, const int (&q)[NT]) {
 }
 
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES>
-__global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvParams p, const int total_tiles) {
+    constexpr int NW = WM * WN;                                    // waves per workgroup (4 or 8)
+    constexpr int NTHR = NW * 64;
     using G = KGeom2<CIN>;
     constexpr int CC = G::CC, NCH = G::NCH, STRIDE = G::STRIDE, SPC = G::SPC, KS = G::KS;
-    constexpr int PW = TW + 2, PH = TH + 2, NPIX = PH * PW;
+    constexpr int PW = TW + 2, PH = TH + 2;
+    // LDS row pitch in pixels: a multiple of 8 for 64-byte pixels, so that the chunk XOR depends
+    // on the patch column only and every tap stays an immediate offset
+    constexpr int PWL = (CC == 64) ? (PW + 7) / 8 * 8 : PW;
+    constexpr int NPIX = PH * PWL;
     constexpr int BM = TH * TW;
     constexpr int MT_TOT = (BM + 15) / 16;
     constexpr int MT = (MT_TOT + WM - 1) / WM;
     constexpr int NT = BN / 16 / WN;
     constexpr int SLABB = (NPIX * STRIDE + 1023) / 1024 * 1024;   // bytes of one chunk slot
     constexpr int NPIECE = SLABB / 1024;
-    constexpr int PPW = (NPIECE + 3) / 4;                          // slab pieces per wave
+    constexpr int PPW = (NPIECE + NW - 1) / NW;                    // slab pieces per wave
     constexpr int WB = (BN / 16) * 1024;                           // weight bytes per k-step
     constexpr int NFR = BN / 16;                                   // fragments per k-step
-    constexpr int WPW = (NFR + 3) / 4;                             // weight pieces per wave per k-step
+    constexpr int WPW = (NFR + NW - 1) / NW;                       // weight pieces per wave per k-step
     constexpr int WSLOTS = WRES ? KS : 3;
     constexpr int OFF_W = 2 * SLABB;
     constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;                 // 1 KiB sink for padding pieces
@@ -75,7 +91,9 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
     constexpr int SROWS = POOL ? MT * WM * 4 : MT * WM * 16;       // staged rows (pixels / windows)
     constexpr int SSTR = BN + 16;                                  // bytes per staged row (+pad)
     constexpr int OROWS = POOL ? BM / 4 : BM;                      // real rows of a tile
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int NIT = (OROWS * (BN / 16) + NTHR - 1) / NTHR;     // output stores per thread per tile (static)
+    constexpr int cap63 = 63;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(WRES || (SPC % 3 == 0), "weight ring slot must be static per tap");
     static_assert(WRES ? NCH == 1 : true, "resident weights only for single-chunk layers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -88,7 +106,7 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
     const int H = p.H, W = p.W;
 
     // ---- tile-independent per-lane geometry
-    int abase[MT];
+    int abase[MT][(CC == 64) ? 3 : 1];       // CC==64: one swizzled base per tap column dx
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         int row = (wm * MT + m) * 16 + li;
@@ -102,35 +120,43 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
             oy = row / TW;
             ox = row % TW;
         }
-        abase[m] = (oy * PW + ox) * STRIDE + (CC == 64 ? g * 16 : 0);
+        if constexpr (CC == 64) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ (((ox + dx) >> 1) & 3)) << 4);
+        } else {
+            abase[m][0] = (oy * PWL + ox) * STRIDE;
+        }
     }
     int kofs[(CC < 64) ? SPC : 1];
     if constexpr (CC == 16) {
 #pragma unroll
         for (int t = 0; t < SPC; ++t) {
             const int tap = min(4 * t + g, 8);
-            kofs[t] = ((tap / 3) * PW + tap % 3) * STRIDE;
+            kofs[t] = ((tap / 3) * PWL + tap % 3) * STRIDE;
         }
     } else if constexpr (CC == 32) {
 #pragma unroll
         for (int t = 0; t < SPC; ++t) {
             const int tap = min(2 * t + (g >> 1), 8);
-            kofs[t] = ((tap / 3) * PW + tap % 3) * STRIDE + (g & 1) * 16;
+            kofs[t] = ((tap / 3) * PWL + tap % 3) * STRIDE + (g & 1) * 16;
         }
     } else {
         kofs[0] = 0;
     }
-    // slab DMA pieces of this wave: piece q = wave + 4*j covers LDS bytes [q*1024, +1024);
+    // slab DMA pieces of this wave: piece q = wave + NW*j covers LDS bytes [q*1024, +1024);
     // lane l owns 16 of them: pixel = o / STRIDE, byte `within` of that pixel's chunk
     int ppix[PPW];      // (py << 16) | px, or -1 for pad / out-of-patch lanes
     int pwithin[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int q = wave + 4 * j;
+        const int q = wave + NW * j;
         const int o = q * 1024 + lane * 16;
-        const int pix = o / STRIDE, within = o - pix * STRIDE;
-        const bool ok = (q < NPIECE) && (pix < NPIX) && (within < CC);
-        ppix[j] = ok ? (((pix / PW) << 16) | (pix % PW)) : -1;
+        const int pix = o / STRIDE;
+        int within = o - pix * STRIDE;
+        if constexpr (CC == 64) within ^= ((pix >> 1) & 3) << 4;     // LDS slot s holds chunk s ^ swz(pix)
+        const bool ok = (q < NPIECE) && (pix < NPIX);
+        ppix[j] = ok ? (((pix / PWL) << 16) | min(pix % PWL, PW - 1)) : -1;    // pitch padding re-reads column PW-1
         pwithin[j] = within;
     }
 
@@ -142,13 +168,13 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
         y0 = (tile % p.tiles_y) * TH;
         b = tile / p.tiles_y;
     };
-    const int dbg = p.mode >> 8;
+    const int dbg = Y355_DIAG ? (p.mode >> 8) : 0;
     auto issue_slab = [&](int b, int y0, int x0, int c, int slot) {
         if (dbg & 2) return;
         const int8_t *inb = p.in + (size_t)b * (H + 2) * (W + 2) * CIN + c * CC;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int q = wave + 4 * j;
+            const int q = wave + NW * j;
             const int8_t *src = p.in;                         // dummy for pad lanes
             if (ppix[j] >= 0) {
                 const int gy = min(y0 + (ppix[j] >> 16), H + 1), gx = min(x0 + (ppix[j] & 0xffff), W + 1);
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
         if (dbg & 1) return;
 #pragma unroll
         for (int j = 0; j < WPW; ++j) {
-            const int f = wave + 4 * j;                        // fragment of this k-step
+            const int f = wave + NW * j;                       // fragment of this k-step
             const bool ok = f < NFR;
             const int8_t *src = p.w + ((size_t)(nb * KS + ks) * NFR + (ok ? f : 0)) * 1024 + lane * 16;
             char *dst = ok ? smem + OFF_W + slot * WB + f * 1024 : smem + OFF_DUMMY;
@@ -172,6 +198,13 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
 
     int tile = blockIdx.x;
     if (tile >= total_tiles) return;
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if constexpr (Y355_DIAG) {
+            if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp();
     int b, y0, x0, nb;
     decode(tile, b, y0, x0, nb);
     int sl = 0;                                                // slab slot of the current chunk
@@ -188,6 +221,8 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
     if (dbg & 8) { wait_vmcnt<0>(); return; }
     const Requant rq = p.rq;
     unsigned int nsat = 0;
+    bool first = true;
+    stamp();
 
     for (;;) {
         int ntile = tile + gridDim.x;
@@ -204,19 +239,31 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
 
         for (int c = 0; c < NCH; ++c) {
             const bool lastc = (c == NCH - 1);
-            int aaddr[MT];                                      // slot base + row base; taps are immediates
+            int aaddr[MT][(CC == 64) ? 3 : 1];                   // slot base + row base (bytes); taps are immediates
 #pragma unroll
-            for (int m = 0; m < MT; ++m) aaddr[m] = sl * SLABB + abase[m];
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int dx = 0; dx < ((CC == 64) ? 3 : 1); ++dx) aaddr[m][dx] = sl * SLABB + abase[m][dx];
 #pragma unroll
             for (int t = 0; t < SPC; ++t) {
                 // -- data of this k-step has landed (own DMAs) -> barrier -> everybody's has
+                const bool fine = Y355_DIAG && p.stamps && (p.mode >> 16) && c == 1;
+                if (fine) stamp();
+                // vmcnt is in-order: "at most N younger operations may still fly".  Younger than the
+                // data of this step are: the weight pieces of the following step(s), a slab issued
+                // at t = 0, and -- at a tile's first steps -- the NIT output stores of the previous
+                // tile (always issued, see the copy-out), so finished tiles do not stall the ring.
                 if (c == 0 && t == 0) {
-                    wait_vmcnt<0>();                            // also drains the previous tile's stores
+                    if (first) { if constexpr (WRES) wait_vmcnt<0>(); else wait_vmcnt<WPW>(); }
+                    else wait_vmcnt<(NIT + (WRES ? 0 : WPW) < cap63 ? NIT + (WRES ? 0 : WPW) : cap63)>();
                 } else if constexpr (!WRES) {
-                    if (t == 1) wait_vmcnt<WPW + PPW>();        // W(t+1) and the slab issued at t=0 may fly
+                    if (c == 0 && t == 1 && !first) wait_vmcnt<(NIT + PPW + WPW < cap63 ? NIT + PPW + WPW : cap63)>();
+                    else if (t == 1) wait_vmcnt<WPW + PPW>();   // W(t+1) and the slab issued at t=0 may fly
                     else wait_vmcnt<WPW>();
                 }
+                if (fine) stamp();
                 if (!WRES || t == 0) __builtin_amdgcn_s_barrier();
+                if (Y355_DIAG && (fine || (c == 0 && t == 0 && !(p.mode >> 16)))) stamp();
                 // -- refill the rings (after the barrier: the slots' last readers are done)
                 if (t == 0) {
                     if (!lastc) issue_slab(b, y0, x0, c + 1, sl ^ 1);
@@ -231,23 +278,33 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
                 const char *wb = smem + OFF_W + (WRES ? t : (t % 3)) * WB + (wn * NT) * 1024 + lane * 16;
                 int ko;
                 if constexpr (CC < 64) ko = kofs[t];
-                else ko = ((t / 3) * PW + t % 3) * STRIDE;
+                else ko = (t / 3) * PWL * 64;                   // row offset of the tap; its column picks the base
+                // software pipeline inside the step: B fragments and A[0], A[1] first, then the read of
+                // A[m+2] is issued between the MFMA groups of A[m] and A[m+1] (counted lgkmcnt), so
+                // the LDS latency hides under the matrix pipe instead of in front of it
+                const int acol = (CC == 64) ? (t % 3) : 0;
                 v4i bf[NT];
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) bf[tt] = *(const v4i *)(wb + tt * 1024);
+                v4i af[MT];
+                af[0] = *(const v4i *)(smem + aaddr[0][acol] + ko);
+                if constexpr (MT > 1) af[1] = *(const v4i *)(smem + aaddr[1][acol] + ko);
                 if (!(dbg & 4)) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const v4i a = *(const v4i *)(smem + aaddr[m] + ko);
+                    if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + aaddr[m + 2][acol] + ko);
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt)
-                        acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bf[tt], acc[m][tt], 0, 0, 0);
+                        acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // ... then this row's MFMAs
                 }
                 }
             }
             sl ^= 1;
         }
 
+        stamp();
         // ---- epilogue of this tile: integer pipeline of conv3x3.hip (32-bit path) -> int8 tile in
         //      LDS (each lane packs its NT adjacent channels) -> barrier -> 16-byte coalesced stores
         if (!(dbg & 16)) {
@@ -265,7 +322,7 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
                     for (int t = 0; t < NT; ++t) {
                         const v4i a = acc[m][t];
                         const int vmax = max(max(a[0], a[1]), max(a[2], a[3]));
-                        const int qq = y355_rne_shift<int>(y355_pre<int>(vmax, bias[t], rq), rq.sh);
+                        const int qq = y355_requant_fast(vmax, bias[t], rq);
                         q[t] = y355_clamp8<int>(qq);
                         nsat += (srow < OROWS && q[t] != qq) ? 1u : 0u;
                     }
@@ -277,7 +334,7 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
                         int q[NT];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
-                            const int qq = y355_rne_shift<int>(y355_pre<int>(acc[m][t][r], bias[t], rq), rq.sh);
+                            const int qq = y355_requant_fast(acc[m][t][r], bias[t], rq);
                             q[t] = y355_clamp8<int>(qq);
                             nsat += (srow < OROWS && q[t] != qq) ? 1u : 0u;
                         }
@@ -286,6 +343,7 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp();
             __builtin_amdgcn_s_barrier();
             // copy-out: item = (row, 16-byte channel group); rows outside the image are dropped
             const int halo = p.out_halo;
@@ -294,15 +352,19 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
             const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
             const int oy0 = POOL ? (y0 >> 1) : y0, ox0 = POOL ? (x0 >> 1) : x0;
             int8_t *outb = p.out + (size_t)b * (Ho + 2 * halo) * (Wo + 2 * halo) * p.cstride + nb * BN;
-            for (int it = tid; it < OROWS * CG; it += 256) {
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int it = min(tid + j * NTHR, OROWS * CG - 1);   // tail clamps: duplicates rewrite the same bytes
                 const int row = it / CG, cg = it % CG;
                 const int oy = oy0 + row / OTW, ox = ox0 + row % OTW;
-                if (oy < Ho && ox < Wo) {
-                    const v4i v = *(const v4i *)(stg + row * SSTR + cg * 16);
-                    *(v4i *)(outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.cstride + cg * 16) = v;
-                }
+                const v4i v = *(const v4i *)(stg + row * SSTR + cg * 16);
+                int8_t *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.cstride + cg * 16;
+                if (!(oy < Ho && ox < Wo)) dst = p.sink + tid * 16;  // outside the image: a scratch line
+                *(v4i *)dst = v;
             }
         }
+        first = false;
+        stamp();
         if (!more) break;
         tile = ntile;
         b = b2; y0 = y2; x0 = x2; nb = nb2;
@@ -315,7 +377,8 @@ __global__ __launch_bounds__(256) void conv3x3_i8_v2_kernel(const ConvParams p, 
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES>
 struct ConvInst2 {
     using G = KGeom2<CIN>;
-    static constexpr int SLABB = ((TH + 2) * (TW + 2) * G::STRIDE + 1023) / 1024 * 1024;
+    static constexpr int PWL = (G::CC == 64) ? (TW + 2 + 7) / 8 * 8 : TW + 2;
+    static constexpr int SLABB = ((TH + 2) * PWL * G::STRIDE + 1023) / 1024 * 1024;
     static constexpr int WB = (BN / 16) * 1024;
     static constexpr int MTT = (TH * TW + 15) / 16;
     static constexpr int SROWS = POOL ? ((MTT + WM - 1) / WM) * WM * 4 : ((MTT + WM - 1) / WM) * WM * 16;
@@ -331,7 +394,7 @@ struct ConvInst2 {
         per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
         int grid = 256 * per_cu;
         if (grid > total) grid = total;
-        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>), dim3(grid), dim3(256), LDS, s, p, total);
+        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
         return true;
     }
 };
@@ -339,11 +402,11 @@ struct ConvInst2 {
 // must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
 using V2_CONV2 = ConvInst2<16, 32, 16, 52, true, 4, 1, true>;
 using V2_CONV3_1 = ConvInst2<32, 64, 13, 26, false, 2, 2, true>;
-using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 2, 2, false>;
-using V2_CONV4_1 = ConvInst2<64, 128, 13, 26, false, 2, 2, false>;
-using V2_CONV4_2 = ConvInst2<128, 64, 26, 26, true, 4, 1, false>;
-using V2_CONV5 = ConvInst2<128, 256, 13, 13, false, 1, 4, false>;
-using V2_CONV67 = ConvInst2<256, 256, 13, 13, false, 1, 4, false>;
+using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 8, 1, false>;
+using V2_CONV4_1 = ConvInst2<64, 128, 13, 26, false, 4, 2, false>;
+using V2_CONV4_2 = ConvInst2<128, 64, 26, 26, true, 8, 1, false>;
+using V2_CONV5 = ConvInst2<128, 256, 13, 13, false, 2, 4, false>;
+using V2_CONV67 = ConvInst2<256, 256, 13, 13, false, 2, 4, false>;
 using V2_PRED = ConvInst2<256, 64, 13, 13, false, 4, 1, false>;
 
 int y355_prepare_conv_v2(void) {

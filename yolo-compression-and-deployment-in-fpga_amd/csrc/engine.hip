@@ -108,6 +108,11 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     rq->shl = shl;
     rq->sh = sh;
     rq->leaky = leaky;
+    rq->lk = leaky ? 3 : 0;
+    rq->sh_l = sh < 0 ? -sh : 0;
+    rq->sh_r = sh > 0 ? sh : 0;
+    rq->hm1 = sh > 0 ? (int)((1ll << (sh - 1)) - 1) : 0;
+    rq->bw = sh > 0 ? 1 : 0;
     int g = 15 + Fp - retune;
     rq->guard_log2 = g < 0 ? 0 : (g > 63 ? 63 : g);
     *frac_bits = Fp;
@@ -126,6 +131,8 @@ struct y355_engine {
     int8_t *w0_dev = nullptr;       // conv1 fragment
     Counters *ctr_dev = nullptr;    // [10]
     unsigned int *absmax_dev = nullptr;
+    int8_t *sink_dev = nullptr;
+    unsigned long long *stamps_dev = nullptr;
     int Hs = 0, Ws = 0, N = 0;
     // head workspace
     y355_head_ws ws{};
@@ -136,6 +143,7 @@ struct y355_engine {
     float *o_box = nullptr, *o_score = nullptr;
     int *o_cls = nullptr, *o_count = nullptr;
     int max_det = 0;
+    int stamp_layer = -1;
     int profile = 0;
     hipEvent_t ev[Y355_NUM_TIMERS + 1];
     bool ev_ok = false;
@@ -224,6 +232,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, (void **)&h->w0_dev, 1024, true);
     if (!rc) rc = dmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * 10, true);
     if (!rc) rc = dmalloc(h, (void **)&h->absmax_dev, 16, true);
+    if (!rc) rc = dmalloc(h, (void **)&h->sink_dev, 16384, true);
     if (!rc) rc = dmalloc(h, &h->ws.cbox, sizeof(float) * 4 * cap * B, false);
     if (!rc) rc = dmalloc(h, &h->ws.cscore, sizeof(float) * cap * B, false);
     if (!rc) rc = dmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
@@ -382,6 +391,8 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.bias_t = L.bias_dev;
         p.bias_w = L.bias_w_dev;
         p.ctr = h->ctr_dev + k;
+        p.sink = h->sink_dev;
+        p.stamps = (h->stamp_layer == k) ? h->stamps_dev : nullptr;
         p.B = B;
         p.H = L.Hin;
         p.W = L.Win;
@@ -396,6 +407,8 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         static const bool no_v2 = getenv("Y355_NO_V2") != nullptr;
         static const int v2dbg = getenv("Y355_V2_DBG") ? atoi(getenv("Y355_V2_DBG")) : 0;
         if (mode == 0) p.mode |= v2dbg << 8;
+        static const int fine = getenv("Y355_STAMP_FINE") ? 1 : 0;
+        if (mode == 0 && fine) p.mode |= 1 << 16;
         if (no_v2 || !y355_launch_conv_v2(L.kid, p, h->stream))
             ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
     }
@@ -585,6 +598,22 @@ extern "C" int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, in
 
 extern "C" int y355_max_det(y355_engine *h) { return h ? h->max_det : Y355_EINVAL; }
 extern "C" int y355_num_anchors_total(y355_engine *h) { return h ? h->N : Y355_EINVAL; }
+
+// diagnostic: record s_memtime stamps of the production conv kernel of `layer` (-1 = off)
+extern "C" int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *out_host, int nwg) {
+    if (!h) return fail(Y355_EINVAL, "null engine");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    if (!h->stamps_dev) {
+        if (int rc = dmalloc(h, (void **)&h->stamps_dev, 8 * 32 * 1024, true)) return rc;
+    }
+    if (out_host) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(out_host, h->stamps_dev, 8 * 32 * (size_t)(nwg > 1024 ? 1024 : nwg), hipMemcpyDeviceToHost));
+    }
+    h->stamp_layer = layer;
+    HIPCHK(hipMemset(h->stamps_dev, 0, 8 * 32 * 1024));
+    return 0;
+}
 
 extern "C" int y355_sync(y355_engine *h) {
     if (!h) return fail(Y355_EINVAL, "null engine");

@@ -17,7 +17,20 @@ struct Requant {
     int leaky;
     int guard_log2;   // guard trips when |t'| >= 2^guard_log2 ( >= 63: never )
     int wide;         // 1: worst-case |t'| does not fit 30 bits -> 64-bit epilogue kernels
+    // branch-free form of the same pipeline (32-bit path), filled by the host:
+    //   t' = max(t, t << lk)                       lk = leaky ? 3 : 0
+    //   q  = ((t' << sh_l) + hm1 + bfe(t', sh_r, bw)) >> sh_r
+    // with sh_r = max(sh,0), sh_l = max(-sh,0), hm1 = sh>0 ? 2^(sh-1)-1 : 0, bw = sh>0 ? 1 : 0
+    int lk, sh_l, sh_r, hm1, bw;
 };
+
+// q before clamping, 32-bit, no branches (production kernels)
+__device__ __forceinline__ int y355_requant_fast(int acc, int bias, const Requant &rq) {
+    int t = (acc << rq.shl) + bias;
+    t = max(t, t << rq.lk);
+    const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)t, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
+    return ((t << rq.sh_l) + rq.hm1 + rb) >> rq.sh_r;
+}
 
 struct Counters {
     unsigned long long absmax;   // max |t'| (stats mode)
@@ -33,6 +46,8 @@ struct ConvParams {
     const int *bias_t;    // [cout_pad]
     const long long *bias_w;  // [cout_pad] 64-bit copy for the wide epilogue
     Counters *ctr;
+    int8_t *sink;         // >= 4 KiB scratch for masked-out stores (keeps store counts static)
+    unsigned long long *stamps;   // diagnostic builds only: per-workgroup s_memtime stamps (or null)
     int B, H, W;          // input feature-map size (unpadded)
     int cstride;          // channels of the output buffer
     int out_halo;         // 1: output buffer carries a zero halo
