@@ -133,6 +133,114 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
     if (nsat_in) atomicAdd(&p.ctr->in_sat, (unsigned long long)nsat_in);
 }
 
+// ---- production variant: same arithmetic (32-bit epilogue, no statistics / guard), organised so
+// that nothing in the hot loops needs an integer division: waves quantise whole patch rows (lanes
+// along x) and own whole rows of pooling windows, so LDS addresses advance by constants.
+template <int TW>
+__global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
+    constexpr int TH = 16;
+    constexpr int PW = TW + 2, PH = TH + 2;
+    constexpr int WPR = TW / 2;                    // pooling windows per window-row
+    constexpr int NWR = TH / 2;                    // window rows per tile
+    constexpr int NW = NWR * WPR;
+    constexpr int MPR = WPR / 4;                   // m-tiles (4 windows) per window row
+    static_assert(WPR % 4 == 0, "window rows split into whole m-tiles");
+    __shared__ __attribute__((aligned(16))) unsigned int patch[PH * PW + 8];
+    __shared__ __attribute__((aligned(16))) unsigned char otile[NW * 16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = y355_xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int H = p.H, W = p.W;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float sc = p.in_scale;
+    unsigned int nsat_in = 0;
+
+    // ---- quantise the patch: wave w takes patch rows w, w+4, ...; lanes run along x
+    const float *xb = p.x + (size_t)b * 3 * H * W;
+    const size_t plane = (size_t)H * W;
+    constexpr int XP = (PW + 63) / 64;             // passes along a row
+#pragma unroll 1
+    for (int py = wave; py < PH; py += 4) {
+        const int gy = y0 + py - 1;
+        const bool rowin = gy >= 0 && gy < H;
+        const size_t ro = (size_t)min(max(gy, 0), H - 1) * W;
+        float v[XP][3];
+#pragma unroll
+        for (int xp = 0; xp < XP; ++xp) {
+            const int gx = x0 + xp * 64 + lane - 1;
+            const size_t o = ro + min(max(gx, 0), W - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[xp][c] = xb[c * plane + o];
+        }
+#pragma unroll
+        for (int xp = 0; xp < XP; ++xp) {
+            const int px = xp * 64 + lane;
+            const int gx = x0 + px - 1;
+            const bool inside = rowin && gx >= 0 && gx < W;
+            const bool own = inside && py >= 1 && py <= TH && px >= 1 && px <= TW;
+            unsigned int w = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float r = rintf(v[xp][c] * sc);
+                const float rc = fminf(fmaxf(r, -127.f), 127.f);
+                nsat_in += (own && rc != r) ? 1u : 0u;
+                const int q = inside ? (int)rc : 0;
+                w |= (unsigned int)(q & 0xff) << (8 * c);
+            }
+            if (px < PW) patch[py * PW + px] = w;
+        }
+    }
+    if (tid < 8) patch[PH * PW + tid] = 0;
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    const v4i bw = *(const v4i *)(p.w + lane * 16);
+    const int bias = p.bias_t[li];
+    const Requant rq = p.rq;
+    const int Ho = H >> 1, Wo = W >> 1;
+    unsigned int nsat = 0;
+    // lane geometry inside an m-tile: window li>>2, position li&3 -> pixel (r>>1, 2*(li>>2) + (r&1))
+    const int r4 = li & 3;
+    const int lbase = ((r4 >> 1) + min(g, 2)) * PW + 2 * (li >> 2) + (r4 & 1);
+#pragma unroll 1
+    for (int wy = wave; wy < NWR; wy += 4) {
+        const unsigned int *src = patch + lbase + wy * 2 * PW;
+        unsigned char *dst = otile + (wy * WPR + g) * 16 + li;
+#pragma unroll
+        for (int mt = 0; mt < MPR; ++mt) {
+            v4i a;
+            a[0] = (int)src[mt * 8 + 0];
+            a[1] = (int)src[mt * 8 + 1];
+            a[2] = (int)src[mt * 8 + 2];
+            a[3] = (int)src[mt * 8 + 3];
+            v4i acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw, acc, 0, 0, 0);
+            const int vmax = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
+            const int qq = y355_requant_fast(vmax, bias, rq);
+            const int q = y355_clamp8<int>(qq);
+            const int wx = mt * 4 + g;
+            nsat += (q != qq && (y0 >> 1) + wy < Ho && (x0 >> 1) + wx < Wo) ? 1u : 0u;
+            dst[mt * 64] = (unsigned char)(q & 0xff);
+        }
+    }
+    __syncthreads();
+    int8_t *outb = p.out + (size_t)b * (Ho + 2) * (Wo + 2) * 16;
+    for (int w = tid; w < NW; w += 256) {
+        const int wy = w / WPR, wx = w % WPR;
+        const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+        if (oy < Ho && ox < Wo)
+            *(v4i *)(outb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * 16) = *(const v4i *)(otile + w * 16);
+    }
+    if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
+    if (nsat_in) atomicAdd(&p.ctr->in_sat, (unsigned long long)nsat_in);
+}
+
 static int conv1_tw(int W) { return (W % 104 == 0) ? 104 : 32; }
 
 void y355_conv1_tiles(int H, int W, int *tx, int *ty) {
@@ -144,6 +252,11 @@ void y355_conv1_tiles(int H, int W, int *tx, int *ty) {
 void y355_launch_conv1(const Conv1Params &p, hipStream_t s) {
     const int n = p.tiles_x * p.tiles_y * p.B;
     const bool big = conv1_tw(p.W) == 104;
+    if (p.mode == 0 && !p.rq.wide && !p.guard) {
+        if (big) hipLaunchKernelGGL((conv1_fast_kernel<104>), dim3(n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv1_fast_kernel<32>), dim3(n), dim3(256), 0, s, p);
+        return;
+    }
     if (p.rq.wide) {
         if (big) hipLaunchKernelGGL((conv1_kernel<104, true>), dim3(n), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv1_kernel<32, true>), dim3(n), dim3(256), 0, s, p);

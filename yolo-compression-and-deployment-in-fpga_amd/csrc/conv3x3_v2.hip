@@ -401,13 +401,13 @@ struct ConvInst2 {
 
 // must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
 using V2_CONV2 = ConvInst2<16, 32, 16, 52, true, 4, 1, true>;
-using V2_CONV3_1 = ConvInst2<32, 64, 13, 26, false, 2, 2, true>;
+using V2_CONV3_1 = ConvInst2<32, 64, 13, 26, false, 4, 2, true>;
 using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 8, 1, false>;
 using V2_CONV4_1 = ConvInst2<64, 128, 13, 26, false, 4, 2, false>;
 using V2_CONV4_2 = ConvInst2<128, 64, 26, 26, true, 8, 1, false>;
 using V2_CONV5 = ConvInst2<128, 256, 13, 13, false, 2, 4, false>;
 using V2_CONV67 = ConvInst2<256, 256, 13, 13, false, 2, 4, false>;
-using V2_PRED = ConvInst2<256, 64, 13, 13, false, 4, 1, false>;
+using V2_PRED = ConvInst2<256, 64, 13, 13, false, 8, 1, false>;
 
 int y355_prepare_conv_v2(void) {
     int e = V2_CONV2::prepare();
