@@ -165,19 +165,27 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
     const float *xb = p.x + (size_t)b * 3 * H * W;
     const size_t plane = (size_t)H * W;
     constexpr int XP = (PW + 63) / 64;             // passes along a row
-#pragma unroll 1
-    for (int py = wave; py < PH; py += 4) {
+    constexpr int RPW = (PH + 3) / 4;              // patch rows per wave
+    // all of a wave's rows are loaded before any is quantised: RPW * XP * 3 loads in flight
+    float v[RPW][XP][3];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int py = wave + 4 * k;
         const int gy = y0 + py - 1;
-        const bool rowin = gy >= 0 && gy < H;
         const size_t ro = (size_t)min(max(gy, 0), H - 1) * W;
-        float v[XP][3];
 #pragma unroll
         for (int xp = 0; xp < XP; ++xp) {
             const int gx = x0 + xp * 64 + lane - 1;
             const size_t o = ro + min(max(gx, 0), W - 1);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[xp][c] = xb[c * plane + o];
+            for (int c = 0; c < 3; ++c) v[k][xp][c] = xb[c * plane + o];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int py = wave + 4 * k;
+        const int gy = y0 + py - 1;
+        const bool rowin = gy >= 0 && gy < H && py < PH;
 #pragma unroll
         for (int xp = 0; xp < XP; ++xp) {
             const int px = xp * 64 + lane;
@@ -187,13 +195,13 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
             unsigned int w = 0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float r = rintf(v[xp][c] * sc);
+                const float r = rintf(v[k][xp][c] * sc);
                 const float rc = fminf(fmaxf(r, -127.f), 127.f);
                 nsat_in += (own && rc != r) ? 1u : 0u;
                 const int q = inside ? (int)rc : 0;
                 w |= (unsigned int)(q & 0xff) << (8 * c);
             }
-            if (px < PW) patch[py * PW + px] = w;
+            if (px < PW && py < PH) patch[py * PW + px] = w;
         }
     }
     if (tid < 8) patch[PH * PW + tid] = 0;
