@@ -133,6 +133,11 @@ int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const int8_t *q_w, 
                           int batch, int cin, int cout, int height, int width,
                           int sa_in, int e_w, int e_b, int sa_out, int flags,
                           int8_t *out, y355_layer_stats *stats);
+/* same operands, NO requantisation: out[b][cout][H][W] = t' (int64) and *frac_bits = F' with
+ * Conv2d_fuse(x) == t' / 2^F' exactly (utils/modules.py:20-29 on fake-quantized operands). */
+int y355_conv3x3_i8_raw(int device_id, const int8_t *q_in, const int8_t *q_w, const int32_t *q_b,
+                        int batch, int cin, int cout, int height, int width,
+                        int sa_in, int e_w, int e_b, int flags, int64_t *out, int32_t *frac_bits);
 /* head only: pred int8 [B][A*(5+C)][Hs][Ws] NCHW host -> detections (host), synchronous.
  * Replaces slim_yolo_v2.py:330-358 (decode, score, threshold, per-class NMS). */
 int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred,
@@ -145,6 +150,8 @@ int y355_sync(y355_engine *h);
 #define Y355_NUM_TIMERS 12
 int y355_profile(y355_engine *h, int enable);
 int y355_profile_get(y355_engine *h, float *ms /*[Y355_NUM_TIMERS]*/);
+/* diagnostic builds (-DY355_DIAG=1): arm / read the s_memtime stamps of one conv layer */
+int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *out_host, int nwg);
 
 #ifdef __cplusplus
 }

@@ -209,6 +209,8 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvParams p) {
                 for (int t = 0; t < NT; ++t) {
                     const T tp = y355_pre<T>(acc[m][t][r], bias[t], rq);
                     amax = max(amax, valid ? y355_uabs<T>(tp) : (U)0);
+                    if (p.raw && valid)
+                        p.raw[(((size_t)b * H + y0 + oy) * W + x0 + ox) * p.cstride + nlane + t] = (long long)tp;
                 }
             }
         }

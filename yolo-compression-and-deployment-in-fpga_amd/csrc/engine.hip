@@ -637,6 +637,84 @@ extern "C" int y355_profile_get(y355_engine *h, float *ms) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Operator-level conv + bias + LeakyReLU WITHOUT requantisation: t' (int64) and F' such that the
+// reference's Conv2d_fuse output is exactly t' / 2^F' (utils/modules.py:20-29 on fake-quantized
+// operands).  Host pointers, synchronous.
+extern "C" int y355_conv3x3_i8_raw(int device_id, const int8_t *q_in, const int8_t *q_w, const int32_t *q_b,
+                                   int batch, int cin, int cout, int H, int W, int sa_in, int e_w, int e_b,
+                                   int flags, int64_t *out, int32_t *frac_bits) {
+    if (!q_in || !q_w || !q_b || !out || !frac_bits) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || cin < 1 || cin > 256 || cout < 1 || H < 1 || W < 1) return fail(Y355_EINVAL, "bad shape (cin <= 256)");
+    const int leaky = (flags & Y355_OP_LEAKY) ? 1 : 0;
+    HIPCHK(hipSetDevice(device_id));
+    if (int e = prepare_kernels()) return e;
+    const int cpad = cin <= 16 ? 16 : cin <= 32 ? 32 : cin <= 64 ? 64 : cin <= 128 ? 128 : 256;
+    const int sel = cpad == 16 ? 0 : cpad == 32 ? 1 : cpad == 64 ? 2 : cpad == 128 ? 3 : 4;
+    const ConvKernelInfo &ki = *y355_conv_kernel(Y355_K_GEN16 + sel);
+    const int cout_pad = (cout + ki.bn - 1) / ki.bn * ki.bn;
+    Requant rq{};
+    int fb = 0;
+    std::vector<int32_t> bt;
+    std::vector<long long> bw;
+    if (int rc = make_requant(cin, sa_in, e_w, e_b, 0, false, leaky, 10, q_b, cout, cout_pad, &rq, &fb, &bt, &bw)) return rc;
+    const size_t in_elems = ((size_t)batch * (H + 2) * (W + 2) + 64) * cpad;
+    std::vector<int8_t> xin(in_elems, 0);
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < cin; ++c)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x)
+                    xin[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * cpad + c] =
+                        q_in[(((size_t)b * cin + c) * H + y) * W + x];
+    std::vector<int8_t> packed(y355_packed_bytes(ki, cout_pad));
+    y355_pack_weights(ki, q_w, cout, cin, cout_pad, packed.data());
+    const size_t raw_elems = (size_t)batch * H * W * cout_pad;
+    int8_t *d_in = nullptr, *d_w = nullptr;
+    int *d_b = nullptr;
+    long long *d_bw = nullptr, *d_raw = nullptr;
+    Counters *d_c = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_bw); (void)hipFree(d_raw); (void)hipFree(d_c);
+    };
+#define RAWCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            cleanup();                                                                      \
+            return fail(Y355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        }                                                                                   \
+    } while (0)
+    RAWCHK(hipMalloc((void **)&d_in, in_elems));
+    RAWCHK(hipMalloc((void **)&d_w, packed.size()));
+    RAWCHK(hipMalloc((void **)&d_b, sizeof(int) * cout_pad));
+    RAWCHK(hipMalloc((void **)&d_bw, sizeof(long long) * cout_pad));
+    RAWCHK(hipMalloc((void **)&d_raw, sizeof(long long) * raw_elems));
+    RAWCHK(hipMalloc((void **)&d_c, sizeof(Counters)));
+    RAWCHK(hipMemcpy(d_in, xin.data(), in_elems, hipMemcpyHostToDevice));
+    RAWCHK(hipMemcpy(d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    RAWCHK(hipMemcpy(d_b, bt.data(), sizeof(int) * cout_pad, hipMemcpyHostToDevice));
+    RAWCHK(hipMemcpy(d_bw, bw.data(), sizeof(long long) * cout_pad, hipMemcpyHostToDevice));
+    RAWCHK(hipMemset(d_c, 0, sizeof(Counters)));
+    ConvParams p{};
+    p.in = d_in; p.out = nullptr; p.w = d_w; p.bias_t = d_b; p.bias_w = d_bw; p.ctr = d_c; p.raw = d_raw;
+    p.B = batch; p.H = H; p.W = W; p.cstride = cout_pad; p.out_halo = 0;
+    p.tiles_x = (W + ki.tw - 1) / ki.tw; p.tiles_y = (H + ki.th - 1) / ki.th; p.nblk = cout_pad / ki.bn;
+    p.rq = rq; p.mode = 1; p.guard = 0;
+    ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * batch, 0);
+    RAWCHK(hipGetLastError());
+    RAWCHK(hipDeviceSynchronize());
+    std::vector<long long> o(raw_elems);
+    RAWCHK(hipMemcpy(o.data(), d_raw, sizeof(long long) * raw_elems, hipMemcpyDeviceToHost));
+    cleanup();
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < cout; ++c)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x)
+                    out[(((size_t)b * cout + c) * H + y) * W + x] = o[(((size_t)b * H + y) * W + x) * cout_pad + c];
+    *frac_bits = fb;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Operator-level fused layer on caller data (utils/modules.py Conv2d_fuse drop-in, unit tests)
 extern "C" int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const int8_t *q_w, const int32_t *q_b,
                                      int batch, int cin, int cout, int H, int W, int sa_in, int e_w, int e_b,

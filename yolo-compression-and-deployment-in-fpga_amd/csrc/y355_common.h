@@ -47,6 +47,7 @@ struct ConvParams {
     const long long *bias_w;  // [cout_pad] 64-bit copy for the wide epilogue
     Counters *ctr;
     int8_t *sink;         // >= 4 KiB scratch for masked-out stores (keeps store counts static)
+    long long *raw;       // statistics mode: optional dump of t' as [B][H][W][cstride] (operator API)
     unsigned long long *stamps;   // diagnostic builds only: per-workgroup s_memtime stamps (or null)
     int B, H, W;          // input feature-map size (unpadded)
     int cstride;          // channels of the output buffer

@@ -241,3 +241,22 @@ def conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=True, pool=F
                                          H, W, int(sa_in), int(e_w), int(e_b), int(sa_out), flags,
                                          out.ctypes.data, C.byref(st)))
     return out, dict(absmax_t=st.absmax_t, frac_bits=st.frac_bits, saturated=st.saturated, guard=st.guard)
+
+
+def conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=True, device_id=0):
+    """conv + bias + LeakyReLU(0.125) without requantisation (y355_conv3x3_i8_raw):
+    returns (t' int64 [B,cout,H,W], F') with value = t' / 2^F'."""
+    lib = _ffi.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("yolo355 needs a GPU; there is no CPU fallback")
+    qi = np.ascontiguousarray(q_in, dtype=np.int8)
+    qw = np.ascontiguousarray(q_w, dtype=np.int8)
+    qb = np.ascontiguousarray(q_b, dtype=np.int32)
+    B, cin, H, W = qi.shape
+    cout = qw.shape[0]
+    out = np.empty((B, cout, H, W), np.int64)
+    fb = C.c_int32()
+    _ffi.check(lib.y355_conv3x3_i8_raw(int(device_id), qi.ctypes.data, qw.ctypes.data, qb.ctypes.data, B, cin, cout,
+                                       H, W, int(sa_in), int(e_w), int(e_b), _ffi.OP_LEAKY if leaky else 0,
+                                       out.ctypes.data, C.byref(fb)))
+    return out, fb.value

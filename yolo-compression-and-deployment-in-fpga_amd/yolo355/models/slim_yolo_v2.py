@@ -1,0 +1,156 @@
+"""Drop-in for the reference's models/slim_yolo_v2.py quantized model, backed by the MI355X
+engine (include/yolo355.h).
+
+Same constructor, attributes, state_dict layout and eval-mode return as
+`SlimYOLOv2_quantize_bnfuse` (models/slim_yolo_v2.py:40-382):
+
+    net = SlimYOLOv2_quantize_bnfuse(device, input_size=[416, 416], num_classes=2,
+                                     anchor_size=ANCHOR_SIZE_MASK)
+    net.load_state_dict(torch.load(".../slim_yolo_v2_q_bf_retune_quantize_1.pth"), strict=False)
+    net.eval()
+    bboxes, scores, cls_inds = net(x, quantization=True)      # numpy, image 0, anchor order
+    all_images = net.forward_batch(x)                          # new: every image of the batch
+
+What runs where: parameters live in torch modules (checkpoint compatibility only); every
+forward goes through the C ABI into the HIP kernels.  There is no PyTorch compute path:
+`quantization=False` (fp32 math) and `trainable=True` (losses) raise NotImplementedError.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import prep
+from ..engine import Engine
+from ..utils import Conv2d_fuse
+
+_CONVS = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7"]
+_TRACKERS = ["a_tracker_in", "a_tracker1", "a_tracker2", "a_tracker3_1", "a_tracker3_2", "a_tracker4_1",
+             "a_tracker4_2", "a_tracker5", "a_tracker6", "a_tracker7", "a_tracker_pred"]
+
+
+class AveragedRangeTracker(nn.Module):
+    """Checkpoint-compatible holder of the tracker buffers (models/slim_yolo_v2.py:9-14).
+    The max|activation| statistics come from the GPU; the state update is prep.RangeTracker."""
+
+    def __init__(self, momentum=0.1):
+        super().__init__()
+        self.momentum = momentum
+        self.register_buffer("scale", torch.zeros(1))
+        self.register_buffer("first_a", torch.zeros(1))
+
+
+class SlimYOLOv2_quantize_bnfuse(nn.Module):
+    def __init__(self, device, input_size=None, num_classes=20, trainable=False, conf_thresh=0.01,
+                 nms_thresh=0.5, anchor_size=None, hr=False):
+        super().__init__()
+        self.device = device
+        self.input_size = list(input_size)
+        self.num_classes = num_classes
+        self.trainable = trainable
+        self.conf_thresh = conf_thresh
+        self.nms_thresh = nms_thresh
+        self.anchor_size = torch.tensor(anchor_size)
+        self.anchor_number = len(anchor_size)
+        self.stride = 16
+        self.scale = np.array([[[input_size[1], input_size[0], input_size[1], input_size[0]]]])
+
+        self.a_tracker_in = AveragedRangeTracker()
+        self.conv1 = Conv2d_fuse(3, 16, 3, 1, leakyReLU=True)
+        self.a_tracker1 = AveragedRangeTracker()
+        self.pool1 = nn.MaxPool2d(2, 2)
+        self.conv2 = Conv2d_fuse(16, 32, 3, 1, leakyReLU=True)
+        self.a_tracker2 = AveragedRangeTracker()
+        self.pool2 = nn.MaxPool2d(2, 2)
+        self.conv3_1 = Conv2d_fuse(32, 64, 3, 1, leakyReLU=True)
+        self.a_tracker3_1 = AveragedRangeTracker()
+        self.conv3_2 = Conv2d_fuse(64, 64, 3, 1, leakyReLU=True)
+        self.a_tracker3_2 = AveragedRangeTracker()
+        self.pool3 = nn.MaxPool2d(2, 2)
+        self.conv4_1 = Conv2d_fuse(64, 128, 3, 1, leakyReLU=True)
+        self.a_tracker4_1 = AveragedRangeTracker()
+        self.conv4_2 = Conv2d_fuse(128, 128, 3, 1, leakyReLU=True)
+        self.a_tracker4_2 = AveragedRangeTracker()
+        self.pool4 = nn.MaxPool2d(2, 2)
+        self.conv5 = Conv2d_fuse(128, 256, 3, 1, leakyReLU=True)
+        self.a_tracker5 = AveragedRangeTracker()
+        self.conv6 = Conv2d_fuse(256, 256, 3, 1, leakyReLU=True)
+        self.a_tracker6 = AveragedRangeTracker()
+        self.conv7 = Conv2d_fuse(256, 256, 3, 1, leakyReLU=True)
+        self.a_tracker7 = AveragedRangeTracker()
+        self.pred = nn.Conv2d(256, self.anchor_number * (1 + 4 + self.num_classes), 3, 1, padding=1)
+        self.a_tracker_pred = AveragedRangeTracker()
+
+        self._engine = None
+        self._engine_key = None
+        self._loaded_version = None
+        self._loaded_find = None
+
+    # ------------------------------------------------------------------ reference API
+    def set_grid(self, input_size):
+        """models/slim_yolo_v2.py:105-109: change the network input size."""
+        self.input_size = list(input_size)
+        self.scale = np.array([[[input_size[1], input_size[0], input_size[1], input_size[0]]]])
+
+    def forward(self, x, target=None, quantization=False, find=False):
+        """Eval-mode return of the reference (:344-358): detections of image 0 as NumPy arrays
+        (bboxes float32 [n,4] in [0,1], scores float32 [n], cls_inds int64 [n]), anchor order."""
+        return self.forward_batch(x, quantization=quantization, find=find)[0]
+
+    def forward_batch(self, x, quantization=True, find=False):
+        """Every image of the batch: element i equals forward(x[i:i+1]) of a frozen model."""
+        if self.trainable:
+            raise NotImplementedError("yolo355 is an inference engine: the training branch "
+                                      "(models/slim_yolo_v2.py:360-382) is out of scope")
+        if not quantization:
+            raise NotImplementedError("yolo355: quantization=False (fp32 math on the loaded weights) is not "
+                                      "built; the engine runs the int8 power-of-two quantized path")
+        eng = self._get_engine(int(x.shape[0]), find)
+        trackers = self._tracker_states()
+        freeze = not self.trainable
+        if any(t.first_a == 0 for t in trackers) or not freeze:
+            # first call ever (:25-27) calibrates every tracker on this input, layer by layer
+            sa = eng.calibrate(x, trackers, freeze=freeze)
+            self._store_trackers(trackers)
+        else:
+            sa = [t.exponent() for t in trackers]
+        eng.set_act_exponents(sa)
+        eng.set_thresholds(self.conf_thresh, self.nms_thresh)
+        return eng.forward(x, find=find)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _weights_version(self):
+        return tuple(int(p._version) for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def _get_engine(self, batch, find):
+        key = (tuple(self.input_size), self.num_classes, tuple(map(tuple, self.anchor_size.tolist())))
+        if self._engine is None or self._engine_key != key or self._engine.max_batch < batch:
+            if self._engine is not None:
+                self._engine.close()
+            dev = self.device if isinstance(self.device, (str, torch.device)) else "cuda:0"
+            self._engine = Engine(self.input_size, self.num_classes, self.anchor_size.tolist(),
+                                  self.conf_thresh, self.nms_thresh, max_batch=max(batch, 1), device=dev)
+            self._engine_key = key
+            self._loaded_version = None
+        ver = self._weights_version()
+        if self._loaded_version != ver or self._loaded_find != find:
+            mods = [getattr(self, n).convs[0] for n in _CONVS] + [self.pred]
+            for i, m in enumerate(mods):
+                q_w, e_w = prep.as_dyadic_int8(m.weight)
+                q_b, e_b = prep.as_dyadic_int8(m.bias)
+                # find=True: the checkpoint holds W * 2^r and the reference divides the conv output
+                # by 2^r (:222-227): same values as exponents e + r
+                r = prep.RETUNE[i] if find else 0
+                self._engine.load_layer(i, q_w, q_b, e_w + r, e_b + r)
+            self._engine.set_retune(prep.RETUNE)
+            self._loaded_version, self._loaded_find = ver, find
+        return self._engine
+
+    def _tracker_states(self):
+        return [prep.RangeTracker(getattr(self, n).scale, int(getattr(self, n).first_a.item())) for n in _TRACKERS]
+
+    def _store_trackers(self, trackers):
+        with torch.no_grad():
+            for n, t in zip(_TRACKERS, trackers):
+                m = getattr(self, n)
+                m.scale.copy_(t.scale.to(m.scale.device))
+                m.first_a.fill_(float(t.first_a))

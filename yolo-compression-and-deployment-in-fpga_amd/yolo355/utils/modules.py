@@ -1,0 +1,110 @@
+"""Drop-in operator modules with the reference's signatures (utils/modules.py:6-40).
+
+The classes keep the reference's parameter layout (`.convs` = nn.Sequential(nn.Conv2d, [BN],
+activation)) so checkpoints load unchanged.  `forward` of the BN-folded modules runs on the
+MI355X through the C ABI when the operands are the fake-quantized tensors of the quantized
+path (values q / 2^e with |q| <= 127, the only regime the FPGA path and this engine define):
+the result is the exact fp32 tensor the reference's nn.Conv2d + LeakyReLU(0.125) produces.
+Anything else (raw fp32 operands, training) raises -- there is no CPU / PyTorch fallback.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import prep
+
+
+def _int8_operands(module, x):
+    conv = module.convs[0]
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or conv.dilation != (1, 1):
+        raise NotImplementedError("yolo355 fused conv: only 3x3 / stride 1 / pad 1 (the slim-YOLOv2 layers)")
+    try:
+        q_in, sa_in = prep.as_dyadic_int8(x)
+        q_w, e_w = prep.as_dyadic_int8(conv.weight)
+        if conv.bias is not None:
+            q_b, e_b = prep.as_dyadic_int8(conv.bias)
+        else:
+            q_b, e_b = np.zeros(conv.out_channels, np.int32), 0
+    except ValueError as err:
+        raise NotImplementedError(
+            "yolo355 operator modules run the int8 power-of-two quantized path only "
+            "(input / weights must be fake-quantized: %s)" % err)
+    return q_in, sa_in, q_w, e_w, q_b, e_b
+
+
+class _FusedBase(nn.Module):
+    leaky = True
+
+    def forward(self, x):
+        from ..engine import conv3x3_i8_raw
+        q_in, sa_in, q_w, e_w, q_b, e_b = _int8_operands(self, x)
+        t, frac = conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=self.leaky,
+                                 device_id=x.device.index if x.is_cuda else 0)
+        y = torch.from_numpy(t.astype(np.float32) * np.float32(2.0 ** (-frac)))
+        return y.to(x.device)
+
+
+class Conv2d(nn.Module):
+    """conv + BatchNorm + LeakyReLU(0.125)/ReLU (utils/modules.py:6-18).  Un-folded BN only
+    exists on the fp32 training path, which this engine does not implement; fold it with
+    fuse_conv_and_bn (conv+bn2conv.py:314-326) and use Conv2d_fuse."""
+
+    def __init__(self, in_channels, out_channels, ksize, padding=0, stride=1, dilation=1, leakyReLU=False):
+        super().__init__()
+        self.convs = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, ksize, stride=stride, padding=padding, dilation=dilation),
+            nn.BatchNorm2d(out_channels),
+            nn.LeakyReLU(0.125, inplace=True) if leakyReLU else nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        raise NotImplementedError("yolo355: BN is folded before inference; use fuse_conv_and_bn + Conv2d_fuse")
+
+
+class Conv2d_fuse(_FusedBase):
+    """conv(+bias) + LeakyReLU(0.125)/ReLU (utils/modules.py:20-29)."""
+
+    def __init__(self, in_channels, out_channels, ksize, padding=0, stride=1, dilation=1, leakyReLU=False):
+        super().__init__()
+        self.leaky = bool(leakyReLU)
+        self.convs = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, ksize, stride=stride, padding=padding, dilation=dilation),
+            nn.LeakyReLU(0.125, inplace=True) if leakyReLU else nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if not self.leaky:
+            raise NotImplementedError("yolo355: ReLU epilogue is not used by slim-YOLOv2 and not built")
+        return super().forward(x)
+
+
+class Conv2d_fuse_nobias(_FusedBase):
+    """conv (no bias) + LeakyReLU(0.125)/ReLU (utils/modules.py:31-40)."""
+
+    def __init__(self, in_channels, out_channels, ksize, padding=0, stride=1, dilation=1, leakyReLU=False):
+        super().__init__()
+        self.leaky = bool(leakyReLU)
+        self.convs = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, ksize, stride=stride, padding=padding, dilation=dilation, bias=False),
+            nn.LeakyReLU(0.125, inplace=True) if leakyReLU else nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if not self.leaky:
+            raise NotImplementedError("yolo355: ReLU epilogue is not used by slim-YOLOv2 and not built")
+        return super().forward(x)
+
+
+class reorg_layer(nn.Module):
+    """utils/modules.py:43-57 -- only used by yolo_v2 (out of this round's scope)."""
+
+    def __init__(self, stride):
+        super().__init__()
+        self.stride = stride
+
+    def forward(self, x):
+        raise NotImplementedError("yolo355: reorg_layer is not on the slim-YOLOv2 path (SURVEY.md 8f)")
+
+
+class SPP(nn.Module):
+    """utils/modules.py:59-72 -- only used by yolo_v3_spp (out of scope)."""
+
+    def forward(self, x):
+        raise NotImplementedError("yolo355: SPP is not on the slim-YOLOv2 path (SURVEY.md 8f)")
