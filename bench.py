@@ -48,7 +48,7 @@ def quantized_layers(seed=2):
     return out
 
 
-def cpu_baseline(n_images=32):
+def cpu_baseline(n_images=256):
     """The plain-C oracle (oracle/yolo_oracle.c: int8 direct conv + shifts + C head, OpenMP) timed on
     the host cores on a bounded sample of the same workload.  Checker code, used here only as the
     reported baseline; its exponents come from the numpy oracle's first-call calibration."""
@@ -63,7 +63,7 @@ def cpu_baseline(n_images=32):
     c_oracle.detect(x, ql, sa, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES, 0.01, 0.5)
     dt = time.perf_counter() - t0
     return dict(value=round(n_images / dt, 2), unit="images/sec", cores=os.cpu_count(), kind="port",
-                sample="%d of the step's 64 images, 416x416, whole path (conv1..pred, decode, NMS) through "
+                sample="%d images (4 steps' worth), 416x416, whole path (conv1..pred, decode, NMS) through "
                        "oracle/yolo_oracle.c with OpenMP, %.1f s" % (n_images, dt))
 
 

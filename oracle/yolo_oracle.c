@@ -116,17 +116,22 @@ int yo_backbone(const float *x, int B, int H, int W, const yo_layer *layers, con
             w = wo;
         }
     }
-    int8_t *bufA = (int8_t *)calloc(maxel, 1), *bufB = (int8_t *)calloc(maxel, 1);
-    if (!bufA || !bufB) return -2;
+    int64_t ns_all[11] = {0};
+    int fail = 0;
+    /* batches: one image per thread (the per-layer loops then run serially inside);
+       single images: the per-layer loops are the parallel ones */
+#pragma omp parallel for schedule(dynamic, 1) if (B >= 8)
     for (int b = 0; b < B; ++b) {
+        int8_t *bufA = (int8_t *)calloc(maxel, 1), *bufB = (int8_t *)calloc(maxel, 1);
+        if (!bufA || !bufB) { fail = 1; free(bufA); free(bufB); continue; }
+        int64_t ns_img[11] = {0};
         int h = H, w = W;
-        memset(bufA, 0, maxel);
         for (int c = 0; c < 3; ++c)
             for (int y = 0; y < H; ++y)
                 for (int xx = 0; xx < W; ++xx) {
                     float r = rintf(x[(((size_t)b * 3 + c) * H + y) * W + xx] * s0);   /* RNE (:35) */
                     if (r > 127.f || r < -127.f) {
-                        ++nsat[0];
+                        ++ns_img[0];
                         if (saturate) r = r > 0 ? 127.f : -127.f;
                     }
                     bufA[(size_t)c * (H + 2) * (W + 2) + (size_t)(y + 1) * (W + 2) + xx + 1] = (int8_t)r;
@@ -138,7 +143,7 @@ int yo_backbone(const float *x, int B, int H, int W, const yo_layer *layers, con
             memset(out, 0, (size_t)layers[k].cout * (ho + 2) * (wo + 2));
             int64_t ns = 0;
             conv_layer(in, cin, h, w, &layers[k], sa[k], sa[k + 1], kLeaky[k], kPool[k], saturate, out, ho, wo, &ns);
-            nsat[k + 1] += ns;
+            ns_img[k + 1] += ns;
             int8_t *t = in;
             in = out;
             out = t;
@@ -151,10 +156,13 @@ int yo_backbone(const float *x, int B, int H, int W, const yo_layer *layers, con
             for (int y = 0; y < h; ++y)
                 for (int xx = 0; xx < w; ++xx)
                     pred[(((size_t)b * PC + c) * h + y) * w + xx] = in[(size_t)c * (h + 2) * (w + 2) + (size_t)(y + 1) * (w + 2) + xx + 1];
+        free(bufA);
+        free(bufB);
+#pragma omp critical
+        for (int i = 0; i < 11; ++i) ns_all[i] += ns_img[i];
     }
-    free(bufA);
-    free(bufB);
-    return 0;
+    for (int i = 0; i < 11; ++i) nsat[i] = ns_all[i];
+    return fail ? -2 : 0;
 }
 
 typedef struct { float score; int idx; } yo_key;
