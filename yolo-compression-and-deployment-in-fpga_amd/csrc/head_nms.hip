@@ -17,12 +17,13 @@
 //                into (anchor, centre-bin) order -- bins are the Hs x Ws grid over the CLAMPED
 //                box centres -- plus per-anchor extents (max w/h, min/max area);
 //   pairs_kernel one thread per candidate walks only the bins a suppressor can sit in
-//                (|dcx| < (1-thr)(wi+wj)/2, same in y, area ratio > thr) and writes its own row
-//                of the bit matrix, word by word, remembering which words it initialised;
-//   scan_kernel  one workgroup per image: candidates without conflicts are kept outright;
-//                the others are sorted by (score desc, index asc) and resolved serially by one
-//                wave holding the "removed" bit-set one word per lane; survivors are emitted in
-//                anchor-index order into the padded outputs.
+//                (|dcx| < (1-thr)(wi+wj)/2, same in y, area ratio > thr), each unordered pair
+//                once, and appends the suppressing pairs to the image's edge list;
+//   resolve_kernel one workgroup per (image, class): candidates without conflicts are kept
+//                outright; the others are sorted by (score desc, index asc), get CSR lists of
+//                their EARLIER conflicting ranks from the edge list, and are settled 64 ranks
+//                per step;
+//   emit_kernel  survivors in anchor-index order into the padded outputs.
 // The pruning is exact: a pair is skipped only when real IoU < 0.999*thr and the union is not
 // degenerate, where the fp32 formula of the reference cannot exceed thr.
 #include "y355_common.h"
@@ -31,6 +32,8 @@
 #define NMS_CAP Y355_NMS_CAP   // max anchors per image handled by this head (416x416: 3380)
 #define NBLK (NMS_CAP / 64)
 #define MAXA Y355_HEAD_MAXA
+#define EDGE_CAP (NMS_CAP * 64)   // edges per image the global list holds (the old bit-matrix footprint / 2)
+#define WG_EDGE_CAP 8192         // edges one pairs workgroup buffers in LDS
 
 struct HeadWork {
     float *cbox;          // [B][CAP][4]  compacted candidates, (anchor, bin) order
@@ -38,15 +41,14 @@ struct HeadWork {
     int *ccls;            // [B][CAP]
     int *corig;           // [B][CAP]     anchor index n = cell*A + a of compact position p
     int *count;           // [B]          candidates per image
-    unsigned long long *mask;     // [B][CAP][64]  row p: bit q set = p and q suppress each other
-    unsigned long long *rowvalid; // [B][CAP]      which words of row p were written
+    unsigned int *edges;  // [B][EDGE_CAP] suppressing pairs (p << 12) | q with p < q (compact positions)
+    int *nedges;          // [B][2]        number of edges; overflow flag (a list did not fit)
     unsigned long long *confl;    // [B][64]       bit per compact position: has a nonzero row
     int *binstart;        // [B][CAP+8]   first compact position of bin (a*HW + by*Ws + bx)
     float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
     int *ntiny;           // [B]
     unsigned long long *keepw;    // [B][64]       resolved survivors among the conflicted
-    unsigned long long *rmask;    // [B][CAP][64]  rank-space rows when a class has > 1024 conflicted
 };
 
 #define PRUNE_MARGIN 1.001f
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         wk.confl[(size_t)b * 64 + tid] = 0ull;
         wk.keepw[(size_t)b * 64 + tid] = 0ull;
     }
+    if (tid < 2) wk.nedges[b * 2 + tid] = 0;
     __syncthreads();
 
     float box[4][4], score[4];
@@ -236,18 +239,23 @@ __device__ __forceinline__ bool suppresses(const float4 a, float area_a, const f
 // |dcx| < (wi+wj)/2 - thr*max(wi,wj) <= (1-thr)*(wi+wj)/2 (same in y), and min(area)/max(area) > thr.
 // With a 0.1% margin the fp32 evaluation of the reference formula cannot land above thr either,
 // provided the union is not degenerate (area sum >= 1e-10) and thr >= 1e-4.
-// grid (CAP/1024, batch), 1024 threads: one thread per candidate, it owns row `i` of the bit
-// matrix.  The image's candidate boxes, classes and bin starts are staged in LDS first (81 KB),
-// so the walk itself never waits on global memory.
+// grid (CAP/1024, batch), 1024 threads: one thread per candidate i.  Every unordered pair is
+// visited once, from its lower compact position: partners q > i inside the window.  The image's
+// candidates and bin starts are staged in LDS (97 KB) so the walk never waits on global memory;
+// suppressing pairs are buffered in LDS and appended to the image's edge list with one atomic
+// per workgroup.
 __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const HeadWork wk, float thr) {
     extern __shared__ __attribute__((aligned(16))) char plds[];
     float4 *sbox = (float4 *)plds;                                   // [CAP]
     int *scls = (int *)(plds + NMS_CAP * 16);                        // [CAP]
     int *sbin = (int *)(plds + NMS_CAP * 20);                        // [CAP + 8]
+    unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 20 + (NMS_CAP + 8) * 4);   // [WG_EDGE_CAP]
+    __shared__ unsigned long long sconf[64];
+    __shared__ int nedge_s, gbase_s;
     const int b = blockIdx.y;
     const int M = wk.count[b];
     if ((int)blockIdx.x * 1024 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int A = p.A, Ws = p.Ws, Hs = p.Hs, HW = Hs * Ws;
     {
         const float4 *cbx4 = (const float4 *)(wk.cbox + (size_t)b * NMS_CAP * 4);
@@ -255,6 +263,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         const int *bs = wk.binstart + (size_t)b * (NMS_CAP + 8);
         for (int q = tid; q < M; q += 1024) { sbox[q] = cbx4[q]; scls[q] = ccl[q]; }
         for (int q = tid; q <= A * HW; q += 1024) sbin[q] = bs[q];
+        if (tid < 64) sconf[tid] = 0ull;
+        if (tid == 0) nedge_s = 0;
     }
     __syncthreads();
     const int i = blockIdx.x * 1024 + tid;
@@ -263,49 +273,46 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
     const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
     const float *as = wk.astat + (size_t)b * MAXA * 4;
-    unsigned long long *row = wk.mask + ((size_t)b * NMS_CAP + (vi ? i : 0)) * 64;
     const float4 bi = vi ? sbox[i] : make_float4(0, 0, 0, 0);
     const int ci = vi ? scls[i] : -1;
     const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
     const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
-    int curw = -1;
-    unsigned long long curbits = 0ull, touched = 0ull, anybits = 0ull;
-    auto flush = [&]() {
-        if (curw >= 0) {
-            if ((touched >> curw) & 1ull) row[curw] |= curbits;
-            else row[curw] = curbits;
-            touched |= 1ull << curw;
-            anybits |= curbits;
-        }
-    };
+    bool lost = false;
     auto visit = [&](int q) {
         const float4 bj = sbox[q];
         const int cj = scls[q];
-        if (q == i || cj != ci) return;
         const float wj = bj.z - bj.x, hj = bj.w - bj.y, aj = wj * hj;
-        if (fast && (ai + aj >= AREA_MIN)) {
+        bool cand = (q > i) && (cj == ci);
+        if (fast) {
             const float dx = fabsf(cxi - 0.5f * (bj.x + bj.z)), dy = fabsf(cyi - 0.5f * (bj.y + bj.w));
-            if (dx >= kr * (wi + wj) + PRUNE_EPS || dy >= kr * (hi + hj) + PRUNE_EPS ||
-                fminf(ai, aj) <= thr_lo * fmaxf(ai, aj))
-                return;
+            const bool far = dx >= kr * (wi + wj) + PRUNE_EPS || dy >= kr * (hi + hj) + PRUNE_EPS ||
+                             fminf(ai, aj) <= thr_lo * fmaxf(ai, aj);
+            cand = cand && !(far && (ai + aj >= AREA_MIN));
         }
-        // the reference's predicate (slim_yolo_v2.py:159-171); IEEE division only near the threshold
-        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-        const float iw = fmaxf(1e-28f, xx2 - xx1), ih = fmaxf(1e-28f, yy2 - yy1);
-        const float inter = iw * ih, den = ai + aj - inter;
-        const float qv = inter * __builtin_amdgcn_rcpf(den);
-        bool s;
-        if (fast && den > 1e-30f && den < 1e30f && (qv > q_hi || qv < q_lo)) s = qv > q_hi;
-        else s = !(inter / den <= thr);
-        if (s) {
-            const int w = q >> 6;
-            if (w != curw) { flush(); curw = w; curbits = 0ull; }
-            curbits |= 1ull << (q & 63);
+        if (cand) {
+            // the reference's predicate (slim_yolo_v2.py:159-171); IEEE division only near the threshold
+            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+            const float iw = fmaxf(1e-28f, xx2 - xx1), ih = fmaxf(1e-28f, yy2 - yy1);
+            const float inter = iw * ih, den = ai + aj - inter;
+            const float qv = inter * __builtin_amdgcn_rcpf(den);
+            bool s;
+            if (fast && den > 1e-30f && den < 1e30f && (qv > q_hi || qv < q_lo)) s = qv > q_hi;
+            else s = !(inter / den <= thr);
+            if (s) {
+                const int e = atomicAdd(&nedge_s, 1);
+                if (e < WG_EDGE_CAP) sedge[e] = ((unsigned int)i << 12) | (unsigned int)q;
+                else lost = true;
+                atomicOr(&sconf[i >> 6], 1ull << (i & 63));
+                atomicOr(&sconf[q >> 6], 1ull << (q & 63));
+            }
         }
     };
     if (vi) {
-        for (int a2 = 0; a2 < A; ++a2) {
+        // own anchor and bin (same formula as head_kernel)
+        const int a_i = wk.corig[(size_t)b * NMS_CAP + i] % A;
+        const int by_i = min(Hs - 1, max(0, (int)(cyi * (float)Hs)));
+        for (int a2 = a_i; a2 < A; ++a2) {              // lower anchors only hold positions < i
             const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1], amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
             if (amax < amin) continue;                         // no candidate of this anchor
             int bx0 = 0, bx1 = Ws - 1, by0 = 0, by1 = Hs - 1;
@@ -317,9 +324,10 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
                 by0 = max(0, (int)floorf((cyi - ry) * (float)Hs));
                 by1 = min(Hs - 1, (int)floorf((cyi + ry) * (float)Hs));
             }
+            if (a2 == a_i) by0 = max(by0, by_i);               // earlier bin rows of my anchor are < i
             for (int by = by0; by <= by1; ++by) {
                 const int k0 = a2 * HW + by * Ws;
-                const int q0 = sbin[k0 + bx0], q1 = sbin[k0 + bx1 + 1];
+                const int q0 = max(sbin[k0 + bx0], i + 1), q1 = sbin[k0 + bx1 + 1];
                 for (int q = q0; q < q1; ++q) visit(q);
             }
         }
@@ -328,13 +336,24 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
             const int *tl = wk.tiny + (size_t)b * NMS_CAP;
             for (int t = 0; t < nt; ++t) visit(tl[t]);
         }
-        flush();
-        wk.rowvalid[(size_t)b * NMS_CAP + i] = touched;
     }
-    const unsigned long long cm = __ballot(vi && anybits != 0ull);
-    if (lane == 0 && cm) atomicOr(&wk.confl[(size_t)b * 64 + (i >> 6)], cm);
+    __syncthreads();
+    const int ne = min(nedge_s, WG_EDGE_CAP);
+    if (tid == 0) {
+        gbase_s = atomicAdd(&wk.nedges[b * 2], ne);
+        if (nedge_s > WG_EDGE_CAP) wk.nedges[b * 2 + 1] = 1;
+    }
+    if (lost) wk.nedges[b * 2 + 1] = 1;
+    __syncthreads();
+    const int gb = gbase_s;
+    unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
+    for (int e = tid; e < ne; e += 1024) {
+        if (gb + e < EDGE_CAP) ge[gb + e] = sedge[e];
+        else wk.nedges[b * 2 + 1] = 1;
+    }
+    if (tid < 64 && sconf[tid]) atomicOr(&wk.confl[(size_t)b * 64 + tid], sconf[tid]);
 }
-#define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4)
+#define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
 
 // ---- resolve_kernel: grid (classes, batch), one workgroup per (image, class).
 // Conflicts only exist inside a class, so every class is an independent greedy walk.  The
@@ -346,11 +365,11 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
 // lanes that have any.
 #define RES_EDGE_CAP 36864          // earlier-neighbour edges kept in LDS (u16 ranks, 72 KiB)
 
-// ---- resolve_kernel (continued): sort, edge lists, ordered walk
-__global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int dbg) {
+__global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, float thr) {
     __shared__ unsigned long long keys[NMS_CAP];      // gathered, then sorted
     __shared__ unsigned short rank_of[NMS_CAP];
     __shared__ int eoff[NMS_CAP + 1];                 // per rank: start of its earlier-neighbour list
+    __shared__ int efill[NMS_CAP];                    // per rank: count, then insertion cursor
     __shared__ unsigned short edges[RES_EDGE_CAP];
     __shared__ unsigned long long keptw[64];          // kept ranks, 64 per word
     __shared__ int wsum[16];
@@ -362,13 +381,16 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
     const int *cc = wk.ccls + (size_t)b * NMS_CAP;
     const int *co = wk.corig + (size_t)b * NMS_CAP;
     const unsigned long long *cf = wk.confl + (size_t)b * 64;
-    const unsigned long long *mk = wk.mask + (size_t)b * NMS_CAP * 64;
-    const unsigned long long *rv = wk.rowvalid + (size_t)b * NMS_CAP;
+    const int ne_img = min(wk.nedges[b * 2], EDGE_CAP);
+    const bool lossy = wk.nedges[b * 2 + 1] != 0;     // some edge list overflowed: brute-force path
+    const unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
     if (tid == 0) nconf_s = 0;
     if (tid < 64) keptw[tid] = 0ull;
+    for (int i = tid; i < NMS_CAP; i += 1024) efill[i] = 0;
     __syncthreads();
     for (int pos = tid; pos < M; pos += 1024) {
-        if (((cf[pos >> 6] >> (pos & 63)) & 1ull) && cc[pos] == cls) {
+        const bool conflicted = lossy || ((cf[pos >> 6] >> (pos & 63)) & 1ull);
+        if (conflicted && cc[pos] == cls) {
             const int k = atomicAdd(&nconf_s, 1);
             keys[k] = ((unsigned long long)(~__float_as_uint(cs[pos])) << 32) |
                       ((unsigned long long)(unsigned int)co[pos] << 12) | (unsigned int)pos;
@@ -376,7 +398,7 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
     }
     __syncthreads();
     const int nconf = nconf_s;
-    if (nconf == 0 || dbg == 1) return;
+    if (nconf == 0) return;
     // ---- sort by (score desc, anchor index asc)
     {
         int P2 = 1;
@@ -397,58 +419,49 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
             }
         }
     }
-    if (dbg == 2) return;
-    for (int r = tid; r < nconf; r += 1024) rank_of[(int)(keys[r] & 0xfffu)] = (unsigned short)r;
-    __syncthreads();
-    // ---- per rank: the conflicting candidates that come EARLIER in the order.  Words of the
-    //      position-space row are fetched once (up to 16 in flight) and walked twice.
-    constexpr int RPT = NMS_CAP / 1024;                 // ranks per thread
-    // fetch the (up to 16) conflict words of rank r's row; false if the row has more
-    auto fetch = [&](int r, unsigned long long (&wd)[16], int (&wix)[16]) -> bool {
-        const int pos = (int)(keys[r] & 0xfffu);
-        unsigned long long valid = rv[pos];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            wd[u] = 0ull;
-            wix[u] = 0;
-            if (valid) {
-                wix[u] = __ffsll((long long)valid) - 1;
-                valid &= valid - 1;
-                wd[u] = mk[(size_t)pos * 64 + wix[u]];
-            }
-        }
-        return valid == 0ull;
-    };
-#pragma unroll 1
-    for (int t = 0; t < RPT; ++t) {
-        const int r = tid + t * 1024;
-        if (r < nconf) {
-            unsigned long long wd[16];
-            int wix[16];
-            int c = 0;
-            if (!fetch(r, wd, wix)) {
-                c = RES_EDGE_CAP + 1;                   // > 16 conflict words: take the slow path
-            } else {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    unsigned long long bits = wd[u];
-                    while (bits) {
-                        const int q = wix[u] * 64 + __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        c += rank_of[q] < r ? 1 : 0;
-                    }
+    const float *cbx = wk.cbox + (size_t)b * NMS_CAP * 4;
+    if (lossy) {
+        // ---- fallback (an edge list overflowed): the textbook walk, one kept candidate at a time
+        __shared__ unsigned char dead[NMS_CAP];
+        for (int r = tid; r < nconf; r += 1024) dead[r] = 0;
+        __syncthreads();
+        for (int r = 0; r < nconf; ++r) {
+            if (dead[r]) continue;                                  // uniform: read after the barrier below
+            const int pi = (int)(keys[r] & 0xfffu);
+            if (tid == 0) atomicOr(&wk.keepw[(size_t)b * 64 + (pi >> 6)], 1ull << (pi & 63));
+            const float4 bi = *(const float4 *)(cbx + (size_t)pi * 4);
+            const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+            for (int r2 = r + 1 + tid; r2 < nconf; r2 += 1024) {
+                if (!dead[r2]) {
+                    const int pj = (int)(keys[r2] & 0xfffu);
+                    const float4 bj = *(const float4 *)(cbx + (size_t)pj * 4);
+                    const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+                    if (suppresses_exact(bi, ai, bj, aj, thr)) dead[r2] = 1;
                 }
             }
-            eoff[r] = c;
+            __syncthreads();
+        }
+        return;
+    }
+    for (int r = tid; r < nconf; r += 1024) rank_of[(int)(keys[r] & 0xfffu)] = (unsigned short)r;
+    __syncthreads();
+    // ---- per rank: the conflicting candidates that come EARLIER in the order (CSR in LDS)
+    for (int e = tid; e < ne_img; e += 1024) {
+        const unsigned int pq = ge[e];
+        const int pi = (int)(pq >> 12), pj = (int)(pq & 0xfffu);
+        if (cc[pi] == cls) {
+            const int ri = rank_of[pi], rj = rank_of[pj];
+            atomicAdd(&efill[max(ri, rj)], 1);
         }
     }
     __syncthreads();
     // exclusive scan of the counts in rank order (rank = tid + t*1024: scan per t, chained)
+    constexpr int RPT = NMS_CAP / 1024;
     int base = 0;
 #pragma unroll 1
     for (int t = 0; t < RPT; ++t) {
         const int r = tid + t * 1024;
-        const int c = r < nconf ? eoff[r] : 0;
+        const int c = r < nconf ? efill[r] : 0;
         int incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -459,38 +472,26 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
         __syncthreads();
         int wb = 0, tot = 0;
         for (int w = 0; w < 16; ++w) { const int v = wsum[w]; if (w < wave) wb += v; tot += v; }
-        if (r < nconf) eoff[r] = base + wb + incl - c;
+        if (r < nconf) { eoff[r] = base + wb + incl - c; efill[r] = base + wb + incl - c; }
         base += tot;
         __syncthreads();
     }
     if (tid == 0) eoff[nconf] = base;
-    const bool overflow = base > RES_EDGE_CAP;          // wave-uniform (same value in every thread)
-    if (!overflow) {
-#pragma unroll 1
-        for (int t = 0; t < RPT; ++t) {
-            const int r = tid + t * 1024;
-            if (r < nconf) {
-                unsigned long long wd[16];
-                int wix[16];
-                fetch(r, wd, wix);
-                int e = eoff[r];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    unsigned long long bits = wd[u];
-                    while (bits) {
-                        const int q = wix[u] * 64 + __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        const int rq = rank_of[q];
-                        if (rq < r) edges[e++] = (unsigned short)rq;
-                    }
-                }
+    const bool big = base > RES_EDGE_CAP;               // same value in every thread
+    if (!big) {
+        for (int e = tid; e < ne_img; e += 1024) {
+            const unsigned int pq = ge[e];
+            const int pi = (int)(pq >> 12), pj = (int)(pq & 0xfffu);
+            if (cc[pi] == cls) {
+                const int ri = rank_of[pi], rj = rank_of[pj];
+                edges[atomicAdd(&efill[max(ri, rj)], 1)] = (unsigned short)min(ri, rj);
             }
         }
     }
     __syncthreads();
-    if (wave != 0 || dbg == 4) return;
-    // ---- ordered walk, 64 ranks per step.  sup: an earlier neighbour of an earlier block is
-    //      kept; own: earlier neighbours inside this block, settled by the scalar loop
+    if (wave != 0) return;
+    // ---- ordered walk, 64 ranks per step.  sup: an earlier neighbour of an earlier step is kept;
+    //      own: earlier neighbours inside this step, settled by the scalar loop
     const int nblk = (nconf + 63) >> 6;
     for (int k = 0; k < nblk; ++k) {
         const int r = k * 64 + lane;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
         const int pos = v ? (int)(keys[r] & 0xfffu) : 0;
         bool sup = false;
         unsigned long long own = 0ull;
-        if (!overflow) {
+        if (!big) {
             const int e0 = v ? eoff[r] : 0, e1 = v ? eoff[r + 1] : 0;
             for (int e = e0; e < e1; e += 4) {          // 4 edges per trip: the LDS reads overlap
                 int rq[4];
@@ -516,17 +517,13 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, int db
                     }
                 }
             }
-        } else if (v) {
-            // slow path (very dense conflicts): walk the position-space row in global memory
-            unsigned long long valid = rv[pos];
-            while (valid) {
-                const int w = __ffsll((long long)valid) - 1;
-                valid &= valid - 1;
-                unsigned long long bits = mk[(size_t)pos * 64 + w];
-                while (bits) {
-                    const int q = w * 64 + __ffsll((long long)bits) - 1;
-                    bits &= bits - 1;
-                    const int rq = rank_of[q];
+        } else {
+            // more earlier-neighbour edges than LDS holds: scan the image's edge list (slow, exact)
+            for (int e = 0; e < ne_img; ++e) {
+                const unsigned int pq = ge[e];
+                const int pi = (int)(pq >> 12), pj = (int)(pq & 0xfffu);
+                if (v && (pi == pos || pj == pos)) {
+                    const int rq = rank_of[pi == pos ? pj : pi];
                     if (rq < r) {
                         const unsigned long long bit = 1ull << (rq & 63);
                         if ((rq >> 6) < k) sup = sup || (keptw[rq >> 6] & bit) != 0ull;
@@ -618,19 +615,17 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     wk.ccls = (int *)ws.ccls;
     wk.corig = (int *)ws.corig;
     wk.count = (int *)ws.count;
-    wk.mask = (unsigned long long *)ws.mask;
-    wk.rowvalid = (unsigned long long *)ws.rowvalid;
+    wk.edges = (unsigned int *)ws.mask;
+    wk.nedges = (int *)ws.rowvalid;
     wk.confl = (unsigned long long *)ws.confl;
     wk.binstart = (int *)ws.binstart;
     wk.astat = (float *)ws.astat;
     wk.tiny = (int *)ws.tiny;
     wk.ntiny = (int *)ws.ntiny;
     wk.keepw = (unsigned long long *)ws.keepw;
-    wk.rmask = (unsigned long long *)ws.rmask;
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);
     hipLaunchKernelGGL(pairs_kernel, dim3(NMS_CAP / 1024, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
-    static int dbg = getenv("Y355_NMS_DBG") ? atoi(getenv("Y355_NMS_DBG")) : 0;
-    hipLaunchKernelGGL(resolve_kernel, dim3(p.C, batch), dim3(1024), 0, s, wk, dbg);
+    hipLaunchKernelGGL(resolve_kernel, dim3(p.C, batch), dim3(1024), 0, s, wk, p.nms_thresh);
     hipLaunchKernelGGL(emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
 }
