@@ -38,6 +38,23 @@ PEAK_I8_DENSE = 5.0e15                          # MI355X dense int8 MFMA (2x bf1
 LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7", "pred"]
 
 
+DOMINANT_KERNEL = "conv3x3_i8_v2_kernel<256, 256, 13, 13, false, 2, 4, false>"
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/, collected with
+    rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE runs at this workload); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            for name, v in json.load(f)["kernels"].items():
+                if kernel in name:
+                    return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def quantized_layers(seed=2):
     """synthetic fp32 weights -> per-tensor pow2 int8 (product-side prep, not the oracle)."""
     out = []
@@ -151,6 +168,8 @@ def main():
         value = world * B * args.steps / dt
         conv_ms = float(layer_ms[:10].sum())
         achieved = B * OPS_PER_IMAGE / (conv_ms * 1e-3) / 1e12
+        dom_ms = float(layer_ms[7] + layer_ms[8]) / 2
+        dom_tops = B * 2e6 * LAYER_MMAC[7] / (dom_ms * 1e-3) / 1e12
         layers = {n: dict(ms=round(float(layer_ms[i]), 4),
                           tops=round(B * 2e6 * LAYER_MMAC[i] / (layer_ms[i] * 1e-3) / 1e12, 1))
                   for i, n in enumerate(LAYER_NAMES)}
@@ -162,9 +181,14 @@ def main():
             "config": {"workload": "slim_yolo_v2_q_bf int8, batch %d per GPU, 416x416, 2 classes, conf 0.01" % B,
                        "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
                        "detections_per_step_rank0": ndet},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_I8_DENSE / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_I8_DENSE, 4), "traffic": None,
-                         "kernel": "conv1_kernel + conv3x3_i8_kernel (10 launches/step, int8 ops, 5.0432e9/image)",
+            "roofline": {"bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
+                         "unit": "TFLOP/s", "frac": round(dom_tops * 1e12 / PEAK_I8_DENSE, 4),
+                         "traffic": pmc_traffic(DOMINANT_KERNEL),
+                         "kernel": DOMINANT_KERNEL + " (conv6 and conv7: 2 launches/step, the largest share of "
+                                   "the step of any kernel; int8 ops = 2 x 398.72e6 MAC x %d images per launch)" % B,
+                         "launch_ms": round(dom_ms, 4),
+                         "all_conv_achieved": round(achieved, 2),
+                         "all_conv_frac": round(achieved * 1e12 / PEAK_I8_DENSE, 4),
                          "whole_path_frac": round(value / world * OPS_PER_IMAGE / PEAK_I8_DENSE, 4),
                          "layers": layers,
                          "head_ms": round(float(layer_ms[10]), 4), "nms_ms": round(float(layer_ms[11]), 4)},
