@@ -153,6 +153,61 @@ int y355_profile_get(y355_engine *h, float *ms /*[Y355_NUM_TIMERS]*/);
 /* diagnostic builds (-DY355_DIAG=1): arm / read the s_memtime stamps of one conv layer */
 int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *out_host, int nwg);
 
+/* ------------------------------------------------------------------------------------------
+ * y355_net: the other model families of the path, table-driven (csrc/net.hip).
+ *   Y355_ARCH_SLIM_V2  SlimYOLOv2 (models/slim_yolo_v2.py:386-422, forward :549-622): the fp32
+ *                      conv+BN+LeakyReLU(0.125) model; 10 weight slots conv1..conv7, pred.
+ *   Y355_ARCH_TINY_V3  YOLOv3tiny (models/tiny_yolo_v3.py:9-273, backbone/darknet.py:211-255);
+ *                      13 weight slots in forward order: conv_1..conv_7, conv_set_2, conv_1x1_2,
+ *                      conv_set_1, extra_conv_2, pred_2, pred_1.  anchors[] = level stride 16
+ *                      first, then stride 32, in pixels (data/config.py:27-31).
+ * dtype Y355_DT_BF16: weights are the BN-folded fp32 tensors (utils/bn_fuse.py:21-45, exact
+ * fold), rounded to bf16 at load; activations bf16 NHWC with a zero halo; MFMA accumulates in
+ * fp32; prediction maps stay fp32.  Same handle rules as y355_engine. */
+#define Y355_ARCH_SLIM_V2 0
+#define Y355_ARCH_TINY_V3 1
+#define Y355_DT_INT8 0
+#define Y355_DT_BF16 1
+typedef struct y355_net y355_net;
+typedef struct y355_net_config {
+    int32_t device_id;
+    int32_t arch, dtype;
+    int32_t height, width;        /* multiples of 32 */
+    int32_t num_classes;
+    int32_t num_anchors;          /* per prediction level */
+    float anchors[2 * Y355_MAX_ANCHORS];
+    float conf_thresh, nms_thresh;
+    int32_t max_batch, max_det;
+    void *stream;
+    int32_t own_stream;
+} y355_net_config;
+
+int y355_net_create(const y355_net_config *cfg, y355_net **out);
+void y355_net_destroy(y355_net *h);
+int y355_net_set_thresholds(y355_net *h, float conf_thresh, float nms_thresh);
+int y355_net_num_layers(y355_net *h);
+int y355_net_num_tensors(y355_net *h);
+int y355_net_layer_shape(y355_net *h, int idx, int32_t *shape /*[4] cout,cin,kh,kw*/);
+int y355_net_tensor_shape(y355_net *h, int idx, int32_t *shape /*[3] C,H,W*/);
+/* replaces load_state_dict + fuse_conv_and_bn for one conv: w fp32 [cout][cin][k][k], b fp32 [cout]
+ * (NULL = zero), host pointers */
+int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, const float *b, int cout, int cin, int ksize);
+/* replaces SlimYOLOv2.forward (:549-601) / YOLOv3tiny.forward (tiny_yolo_v3.py:176-243) for a whole
+ * batch; arguments and outputs as y355_forward. */
+int y355_net_forward(y355_net *h, const float *x_dev, int batch, int flags,
+                     float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev);
+int y355_net_get_candidates(y355_net *h, int batch, float *boxes, float *scores, int32_t *cls);
+/* parity tap: activation tensor idx (graph order, see csrc/net.hip) as fp32 NCHW on the host */
+int y355_net_get_tensor(y355_net *h, int idx, int batch, float *dst_host);
+/* max |value| of an activation tensor of the last forward (calibration of the int8 recipe) */
+int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *out_max);
+int y355_net_max_det(y355_net *h);
+int y355_net_num_anchors_total(y355_net *h);
+int y355_net_sync(y355_net *h);
+int y355_net_profile(y355_net *h, int enable);
+int y355_net_num_timers(y355_net *h);          /* ops + head decode + NMS */
+int y355_net_profile_get(y355_net *h, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

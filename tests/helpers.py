@@ -63,3 +63,28 @@ def dets_match(ref, got, box_tol=2e-5, score_tol=2e-6, all_scores=None):
     if abs(len(rs) - len(gs)) > max(4, 0.02 * max(len(rs), len(gs))):
         return False, "count differs beyond tie slack: ref %d got %d" % (len(rs), len(gs))
     return True, "tie-tolerant: %d one-sided below tied score %.6g" % (len(only), top)
+
+
+def iou_matrix(a, b):
+    """pairwise IoU of x1y1x2y2 boxes a [n,4], b [m,4] (float64)."""
+    a = np.asarray(a, np.float64)[:, None, :]
+    b = np.asarray(b, np.float64)[None, :, :]
+    iw = np.clip(np.minimum(a[..., 2], b[..., 2]) - np.maximum(a[..., 0], b[..., 0]), 0, None)
+    ih = np.clip(np.minimum(a[..., 3], b[..., 3]) - np.maximum(a[..., 1], b[..., 1]), 0, None)
+    inter = iw * ih
+    ua = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter
+    return inter / np.maximum(ua, 1e-12)
+
+
+def dets_close(ref, got, iou_min=0.8, score_tol=0.05):
+    """Tolerance comparison of two detection lists (floating-point paths): fraction of `ref`
+    detections that have a `got` detection of the same class with IoU >= iou_min and a score within
+    score_tol, and vice versa.  Returns (frac_ref_matched, frac_got_matched)."""
+    rb, rs, rc = ref[:3]
+    gb, gs, gc = got[:3]
+    if len(rs) == 0 or len(gs) == 0:
+        return (1.0 if len(rs) == 0 else 0.0), (1.0 if len(gs) == 0 else 0.0)
+    iou = iou_matrix(rb, gb)
+    ok = (iou >= iou_min) & (np.asarray(rc)[:, None] == np.asarray(gc)[None, :]) & \
+         (np.abs(np.asarray(rs, np.float64)[:, None] - np.asarray(gs, np.float64)[None, :]) <= score_tol)
+    return float(ok.any(axis=1).mean()), float(ok.any(axis=0).mean())

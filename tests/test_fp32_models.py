@@ -1,0 +1,191 @@
+"""fp32 model families: SlimYOLOv2 and YOLOv3tiny.
+
+CPU: the torch fp32 oracle (oracle/fp32_oracle.py) against the goldens the reference's own classes
+produced (tests/golden/fp32.npz), and the drop-in classes' parameter layout.
+GPU: the bf16-MFMA engine (y355_net) against the oracle and the goldens.
+
+Tolerances of the bf16 path (inputs, weights and inter-layer activations rounded to bf16, 8
+significant bits, fp32 accumulation, fp32 prediction maps and head), measured over these cases:
+  prediction maps   relative L2 error <= 1.5e-2 (measured 5e-3..7e-3), max |err| <= 2.5e-2 * max |pred|
+  per-anchor scores |err| <= 0.04 everywhere (measured max 0.016)
+  per-anchor boxes  |err| <= 0.03 (normalised units) on 98 % of the anchors, <= 0.08 everywhere
+                    (exp(tw) amplifies the logit error; measured max 0.038)
+  NMS               exact: the engine's detections equal the reference post-processing run on the
+                    engine's own per-anchor decode
+  detections vs the fp32 run: greedy NMS amplifies 1 % score changes among heavily overlapping
+                    boxes, so final lists are compared loosely: >= 80 % of either side matched at
+                    (same class, IoU >= 0.8, |score err| <= 0.05), >= 90 % at (IoU >= 0.5, 0.2);
+                    counts within 3 %
+"""
+import numpy as np
+import pytest
+import torch
+
+from cases import FP32_CASES, fp32_setup
+from helpers import dets_close, dets_match
+from oracle import fp32_oracle as F
+from oracle import yolo_oracle as O
+from yolo355 import synth
+
+IDS = [c[0] for c in FP32_CASES]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "fp32.npz"))
+
+
+@pytest.mark.parametrize("case", FP32_CASES, ids=IDS)
+def test_oracle_matches_reference(case, gold):
+    """the fp32 restatement reproduces the reference's prediction maps and detections"""
+    tag, arch, size, classes = case[:4]
+    layers, anchors, A, x = fp32_setup(case)
+    names = ["pred"] if arch == "slim_yolo_v2" else ["pred_1", "pred_2"]
+    for conf in (0.01, 0.1):
+        r = F.detect(arch, layers, x, size, anchors, classes, conf, 0.5)
+        for n, p in zip(names, r["preds"]):
+            g = gold["%s/%s" % (tag, n)]
+            assert p.shape == g.shape
+            # batch > 1 takes another conv blocking inside torch: a few ulp
+            assert np.abs(p - g).max() <= 1e-4 * max(1.0, np.abs(g).max())
+        for bi in range(x.shape[0]):
+            ref = tuple(gold["%s/%d/det%g/%s" % (tag, bi, conf, k)] for k in ("boxes", "scores", "cls"))
+            sc = r["cls_scores"][bi].max(axis=1)
+            ok, msg = dets_match(ref, r["dets"][bi][:3], box_tol=1e-4, score_tol=1e-4, all_scores=sc)
+            assert ok, "%s image %d conf %g: %s" % (tag, bi, conf, msg)
+
+
+def _state_dict_of(case):
+    tag, arch, size, classes = case[:4]
+    layers, anchors, A, x = fp32_setup(case)
+    return {k: torch.from_numpy(v.copy()) for k, v in synth.state_dict_fp32(layers).items()}, layers, anchors, x
+
+
+@pytest.mark.parametrize("case", [FP32_CASES[2], FP32_CASES[4]], ids=[IDS[2], IDS[4]])
+def test_dropin_state_dict_layout(case):
+    """the drop-in classes take the reference's state_dict keys unchanged (strict load)"""
+    from yolo355.models import SlimYOLOv2, YOLOv3tiny
+    tag, arch, size, classes = case[:4]
+    sd, layers, anchors, x = _state_dict_of(case)
+    cls = SlimYOLOv2 if arch == "slim_yolo_v2" else YOLOv3tiny
+    m = cls("cpu", input_size=size, num_classes=classes, anchor_size=anchors)
+    full = m.state_dict()
+    assert set(sd) <= set(full)
+    assert all(k.endswith("num_batches_tracked") for k in set(full) - set(sd))
+    m.load_state_dict(sd, strict=False)
+    m.eval()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):        # no GPU, no fallback
+            m(torch.from_numpy(x))
+
+
+def test_bn_fold_is_exact():
+    """folded_f32 (W', b') equals conv -> BN(eval) of the un-fused block"""
+    from yolo355.utils.modules import Conv2d, folded_f32
+    torch.manual_seed(0)
+    m = Conv2d(8, 12, 3, 1, leakyReLU=True).eval()
+    with torch.no_grad():
+        m.convs[1].running_mean.uniform_(-0.5, 0.5)
+        m.convs[1].running_var.uniform_(0.5, 2.0)
+        m.convs[1].weight.uniform_(0.5, 1.5)
+        m.convs[1].bias.uniform_(-0.3, 0.3)
+    x = torch.randn(2, 8, 9, 11)
+    w, b = folded_f32(m.convs)
+    with torch.no_grad():
+        ref = m.convs[1](m.convs[0](x))
+        got = torch.nn.functional.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), padding=1)
+    assert torch.allclose(ref, got, atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _load_net(case, max_batch):
+    from yolo355.netengine import Net
+    from yolo355.utils.modules import folded_f32  # noqa: F401
+    tag, arch, size, classes = case[:4]
+    layers, anchors, A, x = fp32_setup(case)
+    net = Net(arch, size, classes, anchors, 0.01, 0.5, max_batch=max_batch, device="cuda:0", dtype="bf16")
+    for i, L in enumerate(layers):
+        w, b = L["w"].astype(np.float64), L["b"].astype(np.float64)
+        if L["bn"] is not None:
+            g, be, mu, var = (a.astype(np.float64) for a in L["bn"])
+            s = g / np.sqrt(var + F.EPS)
+            w, b = w * s[:, None, None, None], (b - mu) * s + be
+        net.load_layer(i, w.astype(np.float32), b.astype(np.float32))
+    return net, layers, anchors, x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FP32_CASES, ids=IDS)
+def test_engine_vs_oracle(case, gold):
+    tag, arch, size, classes = case[:4]
+    net, layers, anchors, x = _load_net(case, len(case[5]))
+    r = F.detect(arch, layers, x, size, anchors, classes, 0.01, 0.5)
+    out = net.forward(x, tap=True)
+    B = x.shape[0]
+    # prediction maps (the last tensors of the graph)
+    for k, p in enumerate(r["preds"]):
+        got = net.get_tensor(net.num_tensors - len(r["preds"]) + k, B)
+        assert got.shape == p.shape
+        err = got.astype(np.float64) - p
+        rel = np.sqrt((err ** 2).sum() / (p.astype(np.float64) ** 2).sum())
+        assert rel <= 1.5e-2, "%s pred %d: relative L2 error %.3g" % (tag, k, rel)
+        assert np.abs(err).max() <= 2.5e-2 * np.abs(p).max(), "%s pred %d: max err %.3g" % (tag, k, np.abs(err).max())
+        # ... and the reference's own map
+        gname = ["pred"] if arch == "slim_yolo_v2" else ["pred_1", "pred_2"]
+        g = gold["%s/%s" % (tag, gname[k])]
+        relg = np.sqrt(((got - g).astype(np.float64) ** 2).sum() / (g.astype(np.float64) ** 2).sum())
+        assert relg <= 1.5e-2
+    # inter-layer activations
+    for k, t in enumerate(r["taps"]):
+        got = net.get_tensor(k, B).astype(np.float64)
+        rel = np.sqrt(((got - t) ** 2).sum() / (t.astype(np.float64) ** 2).sum())
+        assert rel <= 1.5e-2, "%s tensor %d: relative L2 error %.3g" % (tag, k, rel)
+    # per-anchor decode
+    cb, cs, cc = net.candidates(B)
+    best = r["cls_scores"].max(axis=2)
+    assert np.abs(cs - best).max() <= 0.04
+    db = np.abs(cb - r["box"]).max(axis=2)
+    assert (db <= 0.03).mean() >= 0.98 and db.max() <= 0.08
+    for bi in range(B):
+        # NMS: exact on the engine's own decode
+        prob = np.zeros((cs.shape[1], classes), np.float32)
+        prob[np.arange(cs.shape[1]), cc[bi]] = cs[bi]
+        own = O.postprocess(cb[bi], prob, 0.01, 0.5, classes)
+        ok, msg = dets_match(own[:3], out[bi], box_tol=0, score_tol=0, all_scores=cs[bi])
+        assert ok, "%s image %d NMS: %s" % (tag, bi, msg)
+        # final lists against the fp32 oracle and the reference's golden
+        for ref in (r["dets"][bi], tuple(gold["%s/%d/det0.01/%s" % (tag, bi, k)] for k in ("boxes", "scores", "cls"))):
+            fr, fg = dets_close(ref, out[bi], 0.8, 0.05)
+            assert fr >= 0.8 and fg >= 0.8, "%s image %d: matched %.3f of ref, %.3f of got" % (tag, bi, fr, fg)
+            fr, fg = dets_close(ref, out[bi], 0.5, 0.2)
+            assert fr >= 0.9 and fg >= 0.9, "%s image %d: loosely matched %.3f / %.3f" % (tag, bi, fr, fg)
+            assert abs(len(out[bi][1]) - len(ref[1])) <= max(0.03 * len(ref[1]), 5)
+    net.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [FP32_CASES[2], FP32_CASES[4]], ids=[IDS[2], IDS[4]])
+def test_dropin_forward(case):
+    """SlimYOLOv2 / YOLOv3tiny drop-ins: load_state_dict -> eval -> forward == engine, image 0 first"""
+    from yolo355.models import SlimYOLOv2, YOLOv3tiny
+    tag, arch, size, classes = case[:4]
+    sd, layers, anchors, x = _state_dict_of(case)
+    cls = SlimYOLOv2 if arch == "slim_yolo_v2" else YOLOv3tiny
+    m = cls("cuda:0", input_size=size, num_classes=classes, anchor_size=anchors)
+    m.load_state_dict(sd, strict=False)
+    m.eval()
+    b, s, c = m(torch.from_numpy(x))
+    assert b.dtype == np.float32 and b.flags.writeable and c.dtype == np.int64
+    allimg = m.forward_batch(torch.from_numpy(x))
+    assert len(allimg) == x.shape[0] and np.array_equal(allimg[0][1], s)
+    r = F.detect(arch, layers, x, size, anchors, classes, 0.01, 0.5)
+    for bi in range(x.shape[0]):
+        fr, fg = dets_close(r["dets"][bi], allimg[bi], 0.8, 0.05)
+        assert fr >= 0.8 and fg >= 0.8
+    # element i of a batch equals the image run alone (bit-exact: same kernels, same tiles per image)
+    alone = m.forward_batch(torch.from_numpy(x[1:2]))[0]
+    assert np.array_equal(alone[0], allimg[1][0]) and np.array_equal(alone[1], allimg[1][1])
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(torch.from_numpy(x))

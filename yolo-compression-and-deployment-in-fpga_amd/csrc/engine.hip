@@ -15,10 +15,11 @@
 #include <vector>
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) {
+int y355_fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+static int fail(int code, const std::string &msg) { return y355_fail(code, msg); }
 #define HIPCHK(expr)                                                                      \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \
@@ -61,7 +62,8 @@ struct Layer {
 };
 
 int kernels_prepared = 0;
-int prepare_kernels() {
+}  // namespace
+int y355_prepare_kernels() {
     if (kernels_prepared) return 0;
     for (int i = 0; i < Y355_K_COUNT; ++i) {
         int e = y355_conv_kernel(i)->prepare();
@@ -71,9 +73,13 @@ int prepare_kernels() {
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(head): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_v2())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(v2): ") + hipGetErrorString((hipError_t)e));
+    if (int e = y355_prepare_convg())
+        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(convg): ") + hipGetErrorString((hipError_t)e));
     kernels_prepared = 1;
     return 0;
 }
+namespace {
+int prepare_kernels() { return y355_prepare_kernels(); }
 
 // Fill the integer epilogue of one layer.  Returns Y355_ERANGE when the int32 path could
 // overflow for worst-case operands.
@@ -476,16 +482,23 @@ extern "C" int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst)
 static HeadParams head_params(y355_engine *h, int sa_pred, float *ob, float *os, int *oc, int *on) {
     HeadParams p{};
     const Layer &L = h->L[9];
-    p.pred = L.out_dev;
-    p.cstride = L.cout_pad;
-    p.Hs = h->Hs;
-    p.Ws = h->Ws;
+    p.nlev = 1;
+    HeadLevel &lv = p.lev[0];
+    lv.pred = L.out_dev;
+    lv.pred_f = nullptr;
+    lv.cstride = L.cout_pad;
+    lv.Hs = h->Hs;
+    lv.Ws = h->Ws;
+    lv.stride = 16.0f;                       // models/slim_yolo_v2.py:52
+    lv.dq = std::ldexp(1.0f, -sa_pred);
+    for (int i = 0; i < 2 * h->cfg.num_anchors; ++i) lv.anchors[i] = h->cfg.anchors[i];
     p.A = h->cfg.num_anchors;
     p.C = h->cfg.num_classes;
-    p.dq = std::ldexp(1.0f, -sa_pred);
+    p.wh_mul = 16.0f;                        // anchors in grid units (:126)
+    p.Hb = h->Hs;
+    p.Wb = h->Ws;
     p.in_w = (float)h->cfg.width;
     p.in_h = (float)h->cfg.height;
-    for (int i = 0; i < 2 * h->cfg.num_anchors; ++i) p.anchors[i] = h->cfg.anchors[i];
     p.conf_thresh = h->cfg.conf_thresh;
     p.nms_thresh = h->cfg.nms_thresh;
     p.cand_box = h->cand_box;

@@ -64,8 +64,10 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     __shared__ int ntiny_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int A = p.A, C = p.C;
-    const int HW = p.Hs * p.Ws;
-    const int N = HW * A;
+    const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
+    const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0;
+    const int N = N0 + HW1 * A;
+    const int HWb = p.Hb * p.Wb;
     for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
     if (tid < MAXA) {
         sstat[tid][0] = 0u;                 // wmax
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     bool valid[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int np = tid * 4 + u;          // (anchor, cell) enumeration
+        const int np = tid * 4 + u;          // (level, anchor, cell) enumeration
         valid[u] = false;
         score[u] = 0.f;
         cls[u] = 0;
@@ -94,30 +96,37 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         key[u] = 0;
         rk[u] = 0;
         if (np < N) {
-            const int a = np / HW, cell = np % HW;
-            const int n = cell * A + a;      // the reference's anchor index (:337-341)
-            const int gy = cell / p.Ws, gx = cell % p.Ws;
-            const int8_t *pp = p.pred + ((size_t)(b * p.Hs + gy) * p.Ws + gx) * p.cstride;
-            const float conf = (float)pp[a] * p.dq;
+            const int lv = np >= N0 ? 1 : 0;
+            const HeadLevel &L = p.lev[lv];
+            const int npl = np - lv * N0, HWl = lv ? HW1 : HW0;
+            const int a = npl / HWl, cell = npl % HWl;
+            const int n = lv * N0 + cell * A + a;      // the reference's anchor index (:337-341)
+            const int kt = lv * A + a;                 // anchor type: own bins and extents
+            const int gy = cell / L.Ws, gx = cell % L.Ws;
+            const size_t po = ((size_t)(b * L.Hs + gy) * L.Ws + gx) * L.cstride;
+            const int8_t *pq = L.pred ? L.pred + po : nullptr;
+            const float *pf = L.pred_f + po;
+            const float dq = L.dq;
+            auto ld = [&](int c) -> float { return pq ? (float)pq[c] * dq : pf[c]; };
+            const float conf = ld(a);
             const float obj = sigmoidf_(conf);
-            const int8_t *pc = pp + A + a * C;
+            const int c0 = A + a * C;
             float m = -3.0e38f;
-            for (int c = 0; c < C; ++c) m = fmaxf(m, (float)pc[c] * p.dq);
+            for (int c = 0; c < C; ++c) m = fmaxf(m, ld(c0 + c));
             float sum = 0.f;
-            for (int c = 0; c < C; ++c) sum += expf((float)pc[c] * p.dq - m);
+            for (int c = 0; c < C; ++c) sum += expf(ld(c0 + c) - m);
             float best = -1.f;
             int bc = 0;
             for (int c = 0; c < C; ++c) {
-                const float s = (expf((float)pc[c] * p.dq - m) / sum) * obj;
+                const float s = (expf(ld(c0 + c) - m) / sum) * obj;
                 if (s > best) { best = s; bc = c; }
             }
-            const int8_t *pt = pp + A * (1 + C) + a * 4;
-            const float tx = (float)pt[0] * p.dq, tyy = (float)pt[1] * p.dq;
-            const float tw = (float)pt[2] * p.dq, th = (float)pt[3] * p.dq;
-            const float cx = (sigmoidf_(tx) + (float)gx) * 16.0f;
-            const float cy = (sigmoidf_(tyy) + (float)gy) * 16.0f;
-            const float bw = (expf(tw) * p.anchors[2 * a]) * 16.0f;
-            const float bh = (expf(th) * p.anchors[2 * a + 1]) * 16.0f;
+            const int t0 = A * (1 + C) + a * 4;
+            const float tx = ld(t0), tyy = ld(t0 + 1), tw = ld(t0 + 2), th = ld(t0 + 3);
+            const float cx = (sigmoidf_(tx) + (float)gx) * L.stride;
+            const float cy = (sigmoidf_(tyy) + (float)gy) * L.stride;
+            const float bw = (expf(tw) * L.anchors[2 * a]) * p.wh_mul;
+            const float bh = (expf(th) * L.anchors[2 * a + 1]) * p.wh_mul;
             box[u][0] = fminf(fmaxf((cx - bw / 2) / p.in_w, 0.f), 1.f);
             box[u][1] = fminf(fmaxf((cy - bh / 2) / p.in_h, 0.f), 1.f);
             box[u][2] = fminf(fmaxf((cx + bw / 2) / p.in_w, 0.f), 1.f);
@@ -136,14 +145,14 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 // bin of the clamped centre; per-anchor extents of the clamped boxes
                 const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
                 const float ccx = 0.5f * (box[u][0] + box[u][2]), ccy = 0.5f * (box[u][1] + box[u][3]);
-                const int bx = min(p.Ws - 1, max(0, (int)(ccx * (float)p.Ws)));
-                const int by = min(p.Hs - 1, max(0, (int)(ccy * (float)p.Hs)));
-                key[u] = a * HW + by * p.Ws + bx;
+                const int bx = min(p.Wb - 1, max(0, (int)(ccx * (float)p.Wb)));
+                const int by = min(p.Hb - 1, max(0, (int)(ccy * (float)p.Hb)));
+                key[u] = kt * HWb + by * p.Wb + bx;
                 rk[u] = atomicAdd(&hist[key[u]], 1);
-                atomicMax(&sstat[a][0], __float_as_uint(w));
-                atomicMax(&sstat[a][1], __float_as_uint(h));
-                atomicMin(&sstat[a][2], __float_as_uint(ar));
-                atomicMax(&sstat[a][3], __float_as_uint(ar));
+                atomicMax(&sstat[kt][0], __float_as_uint(w));
+                atomicMax(&sstat[kt][1], __float_as_uint(h));
+                atomicMin(&sstat[kt][2], __float_as_uint(ar));
+                atomicMax(&sstat[kt][3], __float_as_uint(ar));
             }
         }
     }
@@ -256,7 +265,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     const int M = wk.count[b];
     if ((int)blockIdx.x * 1024 >= M) return;
     const int tid = threadIdx.x;
-    const int A = p.A, Ws = p.Ws, Hs = p.Hs, HW = Hs * Ws;
+    const int A = p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // anchor types, bin grid
+    const int N0 = p.lev[0].Hs * p.lev[0].Ws * p.A;
     {
         const float4 *cbx4 = (const float4 *)(wk.cbox + (size_t)b * NMS_CAP * 4);
         const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
@@ -310,7 +320,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     };
     if (vi) {
         // own anchor and bin (same formula as head_kernel)
-        const int a_i = wk.corig[(size_t)b * NMS_CAP + i] % A;
+        const int n_i = wk.corig[(size_t)b * NMS_CAP + i];
+        const int a_i = n_i < N0 ? n_i % p.A : p.A + (n_i - N0) % p.A;
         const int by_i = min(Hs - 1, max(0, (int)(cyi * (float)Hs)));
         for (int a2 = a_i; a2 < A; ++a2) {              // lower anchors only hold positions < i
             const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1], amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];

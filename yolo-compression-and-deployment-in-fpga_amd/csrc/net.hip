@@ -1,0 +1,578 @@
+// yolo355 -- table-driven network executor behind the y355_net_* C ABI (include/yolo355.h):
+//   Y355_ARCH_SLIM_V2  models/slim_yolo_v2.py:386-422, forward :549-622  (SlimYOLOv2, the fp32 model)
+//   Y355_ARCH_TINY_V3  models/tiny_yolo_v3.py:9-273 + backbone/darknet.py:211-255 (YOLOv3tiny)
+// in two arithmetic types: bf16 (BN-folded fp32 weights, bf16 MFMA, fp32 accumulate) and int8
+// (per-tensor power-of-two quantisation, the recipe of retune_bias_quantize.py:73-119 applied
+// to these graphs).  Every conv is convg.hip; the ops between the convs are the small kernels
+// in this file.
+#include "../../include/yolo355.h"
+#include "y355_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+int y355_fail(int code, const std::string &msg);
+int y355_prepare_kernels();
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return y355_fail(Y355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+enum { OP_CONV1 = 0, OP_CONV, OP_POOL, OP_UPSAMPLE };
+enum { ACT_NONE = 0, ACT_L125, ACT_L100 };     // LeakyReLU(0.125) utils/modules.py:15; (0.1) backbone/darknet.py:18
+
+struct TensorDef { int C, div, pred; };        // channels; H = height / div; pred: prediction map (no halo)
+struct OpDef {
+    int type, in, out;
+    int choff;        // first channel written in `out` (concat by construction)
+    int layer;        // weight slot
+    int cin, cout;    // cout 0 = A * (5 + C)
+    int ksize, pool, act;
+};
+struct ArchDef { int ntensors; const TensorDef *t; int nops; const OpDef *ops; int nlayers; int nlev; int pred_t[2]; float stride[2]; };
+
+// ---- SlimYOLOv2 (models/slim_yolo_v2.py:403-419, 551-567)
+const TensorDef kSlimT[] = {{16, 2, 0}, {32, 4, 0}, {64, 4, 0}, {64, 8, 0}, {128, 8, 0}, {128, 16, 0},
+                            {256, 16, 0}, {256, 16, 0}, {256, 16, 0}, {0, 16, 1}};
+const OpDef kSlimOps[] = {
+    {OP_CONV1, -1, 0, 0, 0, 3, 16, 3, 1, ACT_L125},
+    {OP_CONV, 0, 1, 0, 1, 16, 32, 3, 1, ACT_L125},
+    {OP_CONV, 1, 2, 0, 2, 32, 64, 3, 0, ACT_L125},
+    {OP_CONV, 2, 3, 0, 3, 64, 64, 3, 1, ACT_L125},
+    {OP_CONV, 3, 4, 0, 4, 64, 128, 3, 0, ACT_L125},
+    {OP_CONV, 4, 5, 0, 5, 128, 128, 3, 1, ACT_L125},
+    {OP_CONV, 5, 6, 0, 6, 128, 256, 3, 0, ACT_L125},
+    {OP_CONV, 6, 7, 0, 7, 256, 256, 3, 0, ACT_L125},
+    {OP_CONV, 7, 8, 0, 8, 256, 256, 3, 0, ACT_L125},
+    {OP_CONV, 8, 9, 0, 9, 256, 0, 3, 0, ACT_NONE},
+};
+// ---- YOLOv3tiny (backbone/darknet.py:215-253, models/tiny_yolo_v3.py:27-39, 176-200)
+// tensor 4 is the concat buffer [C_4 (256) | up(conv_1x1_2(C_5)) (128)] (:190)
+const TensorDef kTinyT[] = {{16, 2, 0}, {32, 4, 0}, {64, 8, 0}, {128, 16, 0}, {384, 16, 0}, {256, 32, 0}, {512, 32, 0},
+                            {512, 32, 0}, {1024, 32, 0}, {256, 32, 0}, {128, 32, 0}, {256, 16, 0}, {512, 32, 0},
+                            {0, 16, 1}, {0, 32, 1}};
+const OpDef kTinyOps[] = {
+    {OP_CONV1, -1, 0, 0, 0, 3, 16, 3, 1, ACT_L100},        // conv_1 + maxpool_1
+    {OP_CONV, 0, 1, 0, 1, 16, 32, 3, 1, ACT_L100},         // conv_2 + maxpool_2
+    {OP_CONV, 1, 2, 0, 2, 32, 64, 3, 1, ACT_L100},         // conv_3 + maxpool_3
+    {OP_CONV, 2, 3, 0, 3, 64, 128, 3, 1, ACT_L100},        // conv_4 + maxpool_4
+    {OP_CONV, 3, 4, 0, 4, 128, 256, 3, 0, ACT_L100},       // conv_5 = C_4
+    {OP_POOL, 4, 5, 0, -1, 256, 256, 2, 0, 0},             // maxpool_5 (2x2, stride 2)
+    {OP_CONV, 5, 6, 0, 5, 256, 512, 3, 0, ACT_L100},       // conv_6
+    {OP_POOL, 6, 7, 0, -1, 512, 512, 2, 1, 0},             // maxpool_6: ZeroPad2d((0,1,0,1)) + MaxPool(2, 1)
+    {OP_CONV, 7, 8, 0, 6, 512, 1024, 3, 0, ACT_L100},      // conv_7 = C_5
+    {OP_CONV, 8, 9, 0, 7, 1024, 256, 3, 0, ACT_L125},      // conv_set_2
+    {OP_CONV, 9, 10, 0, 8, 256, 128, 1, 0, ACT_L125},      // conv_1x1_2
+    {OP_UPSAMPLE, 10, 4, 256, -1, 128, 128, 0, 0, 0},      // bilinear x2, align_corners (:188)
+    {OP_CONV, 4, 11, 0, 9, 384, 256, 3, 0, ACT_L125},      // conv_set_1
+    {OP_CONV, 9, 12, 0, 10, 256, 512, 3, 0, ACT_L125},     // extra_conv_2
+    {OP_CONV, 12, 14, 0, 11, 512, 0, 1, 0, ACT_NONE},      // pred_2 (stride 32)
+    {OP_CONV, 11, 13, 0, 12, 256, 0, 1, 0, ACT_NONE},      // pred_1 (stride 16)
+};
+const ArchDef kArch[2] = {
+    {10, kSlimT, 10, kSlimOps, 10, 1, {9, -1}, {16.f, 0.f}},
+    {15, kTinyT, 16, kTinyOps, 13, 2, {13, 14}, {16.f, 32.f}},
+};
+
+struct Tensor {
+    int C = 0, Cpad = 0, H = 0, W = 0, halo = 1, pred = 0;
+    size_t pb = 0;          // bytes per pixel
+    char *dev = nullptr;
+    size_t bytes = 0;
+};
+struct NLayer {
+    int cin = 0, cout = 0, cout_pad = 0, ksize = 3, kid = -1, op = -1;
+    bool loaded = false;
+    char *w_dev = nullptr;
+    float *bias_dev = nullptr;
+    size_t w_bytes = 0;
+};
+
+__global__ void pool_bf16_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int cbytes, int Ho, int Wo,
+                                 int out_pb, int stride) {
+    // 16 bytes (8 bf16 channels) of one output pixel per thread; the zero halo IS the padding
+    const int cg = cbytes / 16;
+    const size_t total = (size_t)B * Ho * Wo * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg);
+        size_t r = i / cg;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const char *src = in + (((size_t)b * (Hin + 2) + y * stride + 1) * (Win + 2) + x * stride + 1) * in_pb + c * 16;
+        uint4 v[4];
+        v[0] = *(const uint4 *)src;
+        v[1] = *(const uint4 *)(src + in_pb);
+        v[2] = *(const uint4 *)(src + (size_t)(Win + 2) * in_pb);
+        v[3] = *(const uint4 *)(src + (size_t)(Win + 2) * in_pb + in_pb);
+        unsigned int o[4];
+        const unsigned int *w0 = (const unsigned int *)&v[0], *w1 = (const unsigned int *)&v[1];
+        const unsigned int *w2 = (const unsigned int *)&v[2], *w3 = (const unsigned int *)&v[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned int res = 0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int sh = 16 * hf;
+                const float a = __uint_as_float(((w0[k] >> sh) & 0xffffu) << 16), bb = __uint_as_float(((w1[k] >> sh) & 0xffffu) << 16);
+                const float cc = __uint_as_float(((w2[k] >> sh) & 0xffffu) << 16), d = __uint_as_float(((w3[k] >> sh) & 0xffffu) << 16);
+                const float m = fmaxf(fmaxf(a, bb), fmaxf(cc, d));
+                res |= (__float_as_uint(m) >> 16) << sh;
+            }
+            o[k] = res;
+        }
+        *(uint4 *)(out + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * out_pb + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (models/tiny_yolo_v3.py:188):
+// src = dst * (in - 1) / (out - 1), the two-tap blend of torch's upsample_bilinear2d in fp32.
+__global__ void upsample_bf16_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int C, int out_pb,
+                                     int out_off, float ry, float rx) {
+    const int Ho = 2 * Hin, Wo = 2 * Win;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float sy = ry * (float)y, sx = rx * (float)x;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        auto ld = [&](int yy, int xx) -> float {
+            const unsigned short h = *(const unsigned short *)(in + (((size_t)b * (Hin + 2) + yy + 1) * (Win + 2) + xx + 1) * in_pb + c * 2);
+            return __uint_as_float((unsigned int)h << 16);
+        };
+        const float v = hy * (hx * ld(y0, x0) + lx * ld(y0, x1)) + ly * (hx * ld(y1, x0) + lx * ld(y1, x1));
+        *(unsigned short *)(out + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * out_pb + out_off + c * 2) =
+            __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+}
+
+__global__ void absmax_bf16_kernel(const char *t, size_t n_elems, unsigned int *out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned short h = ((const unsigned short *)t)[i];
+        m = fmaxf(m, fabsf(__uint_as_float((unsigned int)h << 16)));
+    }
+    const unsigned int u = y355_wave_max_u32(__float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, u);
+}
+}  // namespace
+
+struct y355_net {
+    y355_net_config cfg{};
+    const ArchDef *arch = nullptr;
+    bool bf = true;
+    int es = 2;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<Tensor> T;
+    std::vector<NLayer> L;
+    char *w0_dev = nullptr;           // first-layer fragments
+    int predc = 0, N = 0, max_det = 0;
+    y355_head_ws ws{};
+    float *cand_box = nullptr, *cand_score = nullptr;
+    int *cand_cls = nullptr;
+    unsigned int *absmax_dev = nullptr;
+    int profile = 0;
+    std::vector<hipEvent_t> ev;
+    std::vector<void *> allocs;
+};
+
+static int nmalloc(y355_net *h, void **p, size_t bytes, bool zero) {
+    HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+    h->allocs.push_back(*p);
+    if (zero) HIPCHK(hipMemset(*p, 0, bytes ? bytes : 16));
+    return 0;
+}
+
+extern "C" void y355_net_destroy(y355_net *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
+    if (!cfg || !out) return y355_fail(Y355_EINVAL, "null argument");
+    if (cfg->arch != Y355_ARCH_SLIM_V2 && cfg->arch != Y355_ARCH_TINY_V3) return y355_fail(Y355_EINVAL, "unknown arch");
+    if (cfg->dtype != Y355_DT_BF16) return y355_fail(Y355_EINVAL, "y355_net: dtype not built (bf16 only)");
+    if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % 32 || cfg->width % 32)
+        return y355_fail(Y355_EINVAL, "input size must be a positive multiple of 32");
+    const ArchDef &A = kArch[cfg->arch];
+    if (cfg->num_anchors < 1 || cfg->num_anchors * A.nlev > Y355_HEAD_MAXA || cfg->num_classes < 1)
+        return y355_fail(Y355_EINVAL, "bad anchors / classes");
+    if (cfg->max_batch < 1) return y355_fail(Y355_EINVAL, "max_batch < 1");
+    const int predc = cfg->num_anchors * (5 + cfg->num_classes);
+    if (predc > 256) return y355_fail(Y355_EINVAL, "A*(5+C) > 256 not supported");
+    int N = 0;
+    for (int l = 0; l < A.nlev; ++l) N += (cfg->height / (int)A.stride[l]) * (cfg->width / (int)A.stride[l]) * cfg->num_anchors;
+    const int Hb = cfg->height / (int)A.stride[0], Wb = cfg->width / (int)A.stride[0];
+    if (N > Y355_NMS_CAP || Hb * Wb * cfg->num_anchors * A.nlev > Y355_NMS_CAP)
+        return y355_fail(Y355_EINVAL, "more than 4096 anchors / sort bins per image not supported");
+    HIPCHK(hipSetDevice(cfg->device_id));
+    if (int e = y355_prepare_kernels()) return e;
+    y355_net *h = new y355_net();
+    h->cfg = *cfg;
+    h->arch = &A;
+    h->bf = true;
+    h->es = 2;
+    h->predc = predc;
+    h->N = N;
+    h->max_det = (cfg->max_det <= 0 || cfg->max_det > N) ? N : cfg->max_det;
+    if (!cfg->own_stream) h->stream = (hipStream_t)cfg->stream;
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return y355_fail(Y355_EHIP, "hipStreamCreate failed");
+        }
+        h->own_stream = true;
+    }
+    const int B = cfg->max_batch;
+    int rc = 0;
+    h->T.resize(A.ntensors);
+    for (int i = 0; i < A.ntensors && !rc; ++i) {
+        Tensor &t = h->T[i];
+        t.C = A.t[i].C ? A.t[i].C : predc;
+        t.pred = A.t[i].pred;
+        t.halo = t.pred ? 0 : 1;
+        t.H = cfg->height / A.t[i].div;
+        t.W = cfg->width / A.t[i].div;
+        t.Cpad = t.pred ? (t.C <= 64 ? 64 : t.C <= 128 ? 128 : 256) : (t.C + 15) / 16 * 16;
+        t.pb = (size_t)t.Cpad * (t.pred ? 4 : h->es);
+        t.bytes = ((size_t)B * (t.H + 2 * t.halo) * (t.W + 2 * t.halo) + 64) * t.pb;
+        rc = nmalloc(h, (void **)&t.dev, t.bytes, true);
+    }
+    h->L.resize(A.nlayers);
+    for (int i = 0; i < A.nops && !rc; ++i) {
+        const OpDef &o = A.ops[i];
+        if (o.type != OP_CONV1 && o.type != OP_CONV) continue;
+        NLayer &L = h->L[o.layer];
+        L.op = i;
+        L.cin = o.cin;
+        L.cout = o.cout ? o.cout : predc;
+        L.ksize = o.ksize;
+        if (o.type == OP_CONV1) {
+            L.cout_pad = 16;
+            rc = nmalloc(h, (void **)&h->w0_dev, 2048, true);
+        } else {
+            const Tensor &ti = h->T[o.in];
+            L.kid = y355_convg_select((int)(o.cin * h->es), L.cout, o.pool, ti.H, ti.W);
+            const ConvGInfo &ki = *y355_convg_kernel(1, L.kid);
+            L.cout_pad = (L.cout + ki.bn - 1) / ki.bn * ki.bn;
+            if (h->T[o.out].pred && L.cout_pad > h->T[o.out].Cpad) {
+                rc = y355_fail(Y355_EINVAL, "prediction map wider than its buffer");
+                break;
+            }
+            L.w_bytes = y355_convg_packed_bytes(ki, o.cin * h->es, o.ksize * o.ksize, L.cout_pad);
+            rc = nmalloc(h, (void **)&L.w_dev, L.w_bytes, true);
+        }
+        if (!rc) rc = nmalloc(h, (void **)&L.bias_dev, sizeof(float) * L.cout_pad, true);
+    }
+    const size_t cap = Y355_NMS_CAP;
+    if (!rc) rc = nmalloc(h, (void **)&h->absmax_dev, 16, true);
+    if (!rc) rc = nmalloc(h, &h->ws.cbox, sizeof(float) * 4 * cap * B, false);
+    if (!rc) rc = nmalloc(h, &h->ws.cscore, sizeof(float) * cap * B, false);
+    if (!rc) rc = nmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
+    if (!rc) rc = nmalloc(h, &h->ws.corig, sizeof(int) * cap * B, false);
+    if (!rc) rc = nmalloc(h, &h->ws.count, sizeof(int) * B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.mask, sizeof(unsigned long long) * 64 * cap * B, false);
+    if (!rc) rc = nmalloc(h, &h->ws.rowvalid, 8 * cap * (size_t)B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.confl, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.binstart, sizeof(int) * (cap + 8) * B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.tiny, sizeof(int) * cap * B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.ntiny, sizeof(int) * B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.keepw, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = nmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
+    if (!rc) rc = nmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
+    if (!rc) rc = nmalloc(h, (void **)&h->cand_cls, sizeof(int) * N * B, false);
+    if (!rc) {
+        h->ev.resize(A.nops + 3);
+        for (auto &e : h->ev)
+            if (hipEventCreate(&e) != hipSuccess) { rc = y355_fail(Y355_EHIP, "hipEventCreate failed"); break; }
+    }
+    if (rc) {
+        std::string keep = y355_last_error();
+        y355_net_destroy(h);
+        y355_fail(rc, keep);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int y355_net_set_thresholds(y355_net *h, float conf, float nms) {
+    if (!h) return y355_fail(Y355_EINVAL, "null net");
+    h->cfg.conf_thresh = conf;
+    h->cfg.nms_thresh = nms;
+    return 0;
+}
+
+extern "C" int y355_net_num_layers(y355_net *h) { return h ? h->arch->nlayers : Y355_EINVAL; }
+extern "C" int y355_net_num_tensors(y355_net *h) { return h ? h->arch->ntensors : Y355_EINVAL; }
+extern "C" int y355_net_max_det(y355_net *h) { return h ? h->max_det : Y355_EINVAL; }
+extern "C" int y355_net_num_anchors_total(y355_net *h) { return h ? h->N : Y355_EINVAL; }
+
+extern "C" int y355_net_layer_shape(y355_net *h, int idx, int32_t *shape) {
+    if (!h || !shape || idx < 0 || idx >= h->arch->nlayers) return y355_fail(Y355_EINVAL, "bad argument");
+    const NLayer &L = h->L[idx];
+    shape[0] = L.cout; shape[1] = L.cin; shape[2] = L.ksize; shape[3] = L.ksize;
+    return 0;
+}
+
+extern "C" int y355_net_tensor_shape(y355_net *h, int idx, int32_t *shape) {
+    if (!h || !shape || idx < 0 || idx >= h->arch->ntensors) return y355_fail(Y355_EINVAL, "bad argument");
+    const Tensor &t = h->T[idx];
+    shape[0] = t.C; shape[1] = t.H; shape[2] = t.W;
+    return 0;
+}
+
+extern "C" int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, const float *b, int cout, int cin, int ksize) {
+    if (!h || !w) return y355_fail(Y355_EINVAL, "null argument");
+    if (idx < 0 || idx >= h->arch->nlayers) return y355_fail(Y355_EINVAL, "layer index out of range");
+    if (!h->bf) return y355_fail(Y355_EINVAL, "fp32 weights go to a bf16 net");
+    NLayer &L = h->L[idx];
+    if (cout != L.cout || cin != L.cin || ksize != L.ksize) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "layer %d expects [%d,%d,%d,%d], got [%d,%d,%d,%d]", idx, L.cout, L.cin, L.ksize, L.ksize,
+                 cout, cin, ksize, ksize);
+        return y355_fail(Y355_EINVAL, buf);
+    }
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const OpDef &o = h->arch->ops[L.op];
+    if (o.type == OP_CONV1) {
+        char frag[2048];
+        y355_pack_conv1f(w, frag);
+        HIPCHK(hipMemcpy(h->w0_dev, frag, 2048, hipMemcpyHostToDevice));
+    } else {
+        const ConvGInfo &ki = *y355_convg_kernel(1, L.kid);
+        std::vector<char> packed(L.w_bytes);
+        y355_convg_pack(ki, w, nullptr, cout, cin, ksize, cin * h->es, L.cout_pad, packed.data());
+        HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
+    std::vector<float> bias(L.cout_pad, 0.f);
+    if (b) memcpy(bias.data(), b, sizeof(float) * cout);
+    HIPCHK(hipMemcpy(L.bias_dev, bias.data(), sizeof(float) * L.cout_pad, hipMemcpyHostToDevice));
+    L.loaded = true;
+    return 0;
+}
+
+static float act_slope(int act) { return act == ACT_L125 ? 0.125f : act == ACT_L100 ? 0.1f : 1.0f; }
+
+static int run_op(y355_net *h, int i, int B, const float *x_dev) {
+    const OpDef &o = h->arch->ops[i];
+    hipStream_t s = h->stream;
+    if (o.type == OP_CONV1) {
+        const NLayer &L = h->L[o.layer];
+        if (!L.loaded) return y355_fail(Y355_ENOTREADY, "layer weights not loaded");
+        Conv1FParams p{};
+        p.x = x_dev;
+        p.out = h->T[o.out].dev;
+        p.w = h->w0_dev;
+        p.bias = L.bias_dev;
+        p.B = B;
+        p.H = h->cfg.height;
+        p.W = h->cfg.width;
+        y355_conv1f_tiles(p.H, p.W, &p.tiles_x, &p.tiles_y);
+        p.slope = act_slope(o.act);
+        y355_launch_conv1f(p, s);
+    } else if (o.type == OP_CONV) {
+        const NLayer &L = h->L[o.layer];
+        if (!L.loaded) return y355_fail(Y355_ENOTREADY, "layer weights not loaded");
+        const Tensor &ti = h->T[o.in], &to = h->T[o.out];
+        const ConvGInfo &ki = *y355_convg_kernel(1, L.kid);
+        ConvGParams p{};
+        p.in = ti.dev;
+        p.out = to.dev;
+        p.w = L.w_dev;
+        p.bias_f = L.bias_dev;
+        p.B = B;
+        p.H = ti.H;
+        p.W = ti.W;
+        p.in_pb = (int)ti.pb;
+        p.nchunks = o.cin * h->es / ki.chb;
+        p.out_pb = (int)to.pb;
+        p.out_off = o.choff * (to.pred ? 4 : h->es);
+        p.out_halo = to.halo;
+        p.tiles_x = (ti.W + ki.tw - 1) / ki.tw;
+        p.tiles_y = (ti.H + ki.th - 1) / ki.th;
+        p.nblk = L.cout_pad / ki.bn;
+        p.taps = o.ksize * o.ksize;
+        p.slope = act_slope(o.act);
+        p.out_f32 = to.pred;
+        ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, s);
+    } else if (o.type == OP_POOL) {
+        const Tensor &ti = h->T[o.in], &to = h->T[o.out];
+        const int stride = o.pool ? 1 : 2;
+        const size_t total = (size_t)B * to.H * to.W * (o.cin * h->es / 16);
+        const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(pool_bf16_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb,
+                           o.cin * h->es, to.H, to.W, (int)to.pb, stride);
+    } else {
+        const Tensor &ti = h->T[o.in], &to = h->T[o.out];
+        const size_t total = (size_t)B * to.H * to.W * o.cin;
+        const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+        const float ry = (float)(ti.H - 1) / (float)(to.H - 1), rx = (float)(ti.W - 1) / (float)(to.W - 1);
+        hipLaunchKernelGGL(upsample_bf16_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb, o.cin,
+                           (int)to.pb, o.choff * h->es, ry, rx);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static HeadParams net_head_params(y355_net *h, float *ob, float *os, int *oc, int *on) {
+    HeadParams p{};
+    const ArchDef &A = *h->arch;
+    p.nlev = A.nlev;
+    for (int l = 0; l < A.nlev; ++l) {
+        const Tensor &t = h->T[A.pred_t[l]];
+        HeadLevel &lv = p.lev[l];
+        lv.pred = nullptr;
+        lv.pred_f = (const float *)t.dev;
+        lv.cstride = t.Cpad;
+        lv.Hs = t.H;
+        lv.Ws = t.W;
+        lv.stride = A.stride[l];
+        lv.dq = 1.0f;
+        for (int i = 0; i < 2 * h->cfg.num_anchors; ++i) lv.anchors[i] = h->cfg.anchors[l * 2 * h->cfg.num_anchors + i];
+    }
+    p.A = h->cfg.num_anchors;
+    p.C = h->cfg.num_classes;
+    // slim-YOLOv2 anchors are in grid units (models/slim_yolo_v2.py:126), tiny-v3's in pixels (tiny_yolo_v3.py:85)
+    p.wh_mul = h->cfg.arch == Y355_ARCH_SLIM_V2 ? 16.0f : 1.0f;
+    p.Hb = h->T[A.pred_t[0]].H;
+    p.Wb = h->T[A.pred_t[0]].W;
+    p.in_w = (float)h->cfg.width;
+    p.in_h = (float)h->cfg.height;
+    p.conf_thresh = h->cfg.conf_thresh;
+    p.nms_thresh = h->cfg.nms_thresh;
+    p.cand_box = h->cand_box;
+    p.cand_score = h->cand_score;
+    p.cand_cls = h->cand_cls;
+    p.max_det = h->max_det;
+    p.out_box = ob;
+    p.out_score = os;
+    p.out_cls = oc;
+    p.out_count = on;
+    return p;
+}
+
+extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
+                                int32_t *cls_dev, int32_t *count_dev) {
+    if (!h || !x_dev || !boxes_dev || !scores_dev || !cls_dev || !count_dev) return y355_fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return y355_fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const bool prof = h->profile != 0;
+    const int nops = h->arch->nops;
+    for (int i = 0; i < nops; ++i) {
+        if (prof) HIPCHK(hipEventRecord(h->ev[i], h->stream));
+        if (int rc = run_op(h, i, batch, x_dev)) return rc;
+    }
+    if (prof) HIPCHK(hipEventRecord(h->ev[nops], h->stream));
+    HeadParams hp = net_head_params(h, boxes_dev, scores_dev, cls_dev, count_dev);
+    if (!(flags & Y355_F_TAP)) { hp.cand_box = nullptr; hp.cand_score = nullptr; hp.cand_cls = nullptr; }
+    y355_launch_head_nms(hp, batch, h->ws, h->stream, prof ? h->ev[nops + 1] : nullptr);
+    HIPCHK(hipGetLastError());
+    if (prof) HIPCHK(hipEventRecord(h->ev[nops + 2], h->stream));
+    return 0;
+}
+
+extern "C" int y355_net_get_candidates(y355_net *h, int batch, float *boxes, float *scores, int32_t *cls) {
+    if (!h || !boxes || !scores || !cls) return y355_fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return y355_fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(boxes, h->cand_box, sizeof(float) * 4 * h->N * batch, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(scores, h->cand_score, sizeof(float) * h->N * batch, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cls, h->cand_cls, sizeof(int) * h->N * batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// parity tap: tensor idx as fp32 NCHW [B][C][H][W] on the host (halo and channel padding stripped)
+extern "C" int y355_net_get_tensor(y355_net *h, int idx, int batch, float *dst) {
+    if (!h || !dst || idx < 0 || idx >= h->arch->ntensors) return y355_fail(Y355_EINVAL, "bad argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return y355_fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const Tensor &t = h->T[idx];
+    const int Hp = t.H + 2 * t.halo, Wp = t.W + 2 * t.halo;
+    std::vector<char> tmp((size_t)batch * Hp * Wp * t.pb);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(tmp.data(), t.dev, tmp.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < t.C; ++c)
+            for (int y = 0; y < t.H; ++y)
+                for (int x = 0; x < t.W; ++x) {
+                    const char *src = tmp.data() + (((size_t)b * Hp + y + t.halo) * Wp + x + t.halo) * t.pb;
+                    float v;
+                    if (t.pred) {
+                        memcpy(&v, src + (size_t)c * 4, 4);
+                    } else {
+                        unsigned short hbits;
+                        memcpy(&hbits, src + (size_t)c * 2, 2);
+                        const unsigned int u = (unsigned int)hbits << 16;
+                        memcpy(&v, &u, 4);
+                    }
+                    dst[(((size_t)b * t.C + c) * t.H + y) * t.W + x] = v;
+                }
+    return 0;
+}
+
+// max |value| of tensor idx (calibration tap for the int8 recipe); synchronous
+extern "C" int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *out_max) {
+    if (!h || !out_max || idx < 0 || idx >= h->arch->ntensors) return y355_fail(Y355_EINVAL, "bad argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return y355_fail(Y355_EINVAL, "batch out of range");
+    const Tensor &t = h->T[idx];
+    if (t.pred) return y355_fail(Y355_EINVAL, "prediction maps are fp32: read them with y355_net_get_tensor");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemsetAsync(h->absmax_dev, 0, 16, h->stream));
+    const size_t n = (size_t)batch * (t.H + 2) * (t.W + 2) * t.Cpad;
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3(1024), dim3(256), 0, h->stream, t.dev, n, h->absmax_dev);
+    HIPCHK(hipGetLastError());
+    unsigned int bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, h->absmax_dev, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(out_max, &bits, 4);
+    return 0;
+}
+
+extern "C" int y355_net_sync(y355_net *h) {
+    if (!h) return y355_fail(Y355_EINVAL, "null net");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int y355_net_profile(y355_net *h, int enable) {
+    if (!h) return y355_fail(Y355_EINVAL, "null net");
+    h->profile = enable;
+    return 0;
+}
+
+extern "C" int y355_net_num_timers(y355_net *h) { return h ? h->arch->nops + 2 : Y355_EINVAL; }
+
+extern "C" int y355_net_profile_get(y355_net *h, float *ms) {
+    if (!h || !ms) return y355_fail(Y355_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const int n = h->arch->nops + 2;
+    HIPCHK(hipEventSynchronize(h->ev[n]));
+    for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return 0;
+}

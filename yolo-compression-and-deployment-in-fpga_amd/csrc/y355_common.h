@@ -151,13 +151,24 @@ void y355_launch_conv1(const Conv1Params &p, hipStream_t s);
 void y355_conv1_tiles(int H, int W, int *tx, int *ty);
 void y355_pack_conv1(const int8_t *q_w /*[16][3][3][3]*/, int8_t *dst /*1024*/);
 
-struct HeadParams {
-    const int8_t *pred;   // [B][Hs][Ws][cstride] int8
+// One prediction map of the detection head.  Channel layout [A obj | A*C cls | A*4 txtytwth],
+// anchor-major (models/slim_yolo_v2.py:330-341, models/tiny_yolo_v3.py:202-222).
+struct HeadLevel {
+    const int8_t *pred;   // [B][Hs][Ws][cstride] int8 (value = q * dq) ...
+    const float *pred_f;  // ... or fp32 (bf16 nets; pred == nullptr)
     int cstride;
-    int Hs, Ws, A, C;
+    int Hs, Ws;
+    float stride;         // cx = (sigmoid(tx) + gx) * stride
     float dq;             // 2^-sa_pred
+    float anchors[32];    // (w, h) of this level's A anchors
+};
+struct HeadParams {
+    HeadLevel lev[2];     // anchor index n: level 0 first, n = cell * A + a inside a level
+    int nlev;
+    int A, C;             // anchors per level, classes
+    float wh_mul;         // w = exp(tw) * aw * wh_mul   (16: anchors in grid units; 1: pixels)
+    int Hb, Wb;           // bin grid of the candidate sort (level 0's grid)
     float in_w, in_h;     // network input size in pixels
-    float anchors[32];
     float conf_thresh, nms_thresh;
     float *cand_box;      // [B][N][4]
     float *cand_score;    // [B][N]
@@ -179,3 +190,55 @@ int y355_prepare_head(void);
 // between decode and NMS.
 void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid);
 void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStream_t s);
+
+// ---- generic chunked conv (convg.hip): bf16 nets and the int8 layers conv3x3.hip cannot hold --
+struct RequantG {
+    int shl;       // t = acc * 2^shl + bias
+    int sh;        // q = clamp(RNE(t' * 2^-sh))
+    int lk;        // t' = t >= 0 ? t * 2^lk : t * neg_mul     (LeakyReLU slope neg_mul / 2^lk)
+    int neg_mul;
+};
+
+struct ConvGParams {
+    const char *in;           // NHWC with halo, in_pb bytes per pixel
+    char *out;                // NHWC, out_pb bytes per pixel
+    const char *w;            // fragment-packed weights (y355_convg_pack)
+    const float *bias_f;      // bf16: [cout_pad]
+    const long long *bias_w;  // int8: [cout_pad] pre-shifted
+    Counters *ctr;            // int8: saturation counter (or null)
+    int B, H, W;
+    int in_pb, nchunks;       // bytes per input pixel; chunks of CHB bytes consumed
+    int out_pb, out_off;      // bytes per output pixel of the buffer; byte offset of this conv's channel 0
+    int out_halo, tiles_x, tiles_y, nblk;
+    int taps;                 // 9 (3x3, pad 1) or 1 (1x1)
+    float slope;              // bf16: y = x >= 0 ? x : slope * x
+    int out_f32;              // bf16: store fp32 (prediction layers)
+    RequantG rq;
+};
+
+struct Conv1FParams {
+    const float *x;       // fp32 NCHW [B][3][H][W]
+    char *out;            // bf16 NHWC16 with halo [B][H/2+2][W/2+2][16]
+    const char *w;        // two 1 KiB fragments
+    const float *bias;    // [16]
+    int B, H, W, tiles_x, tiles_y;
+    float slope;
+};
+
+struct ConvGInfo {
+    int bf, chb, bn, th, tw, pool, wm, wn, nt;
+    size_t lds_bytes;
+    void (*launch)(const ConvGParams &p, int nblocks, hipStream_t s);
+    int (*prepare)(void);
+};
+#define Y355_G_COUNT 9
+const ConvGInfo *y355_convg_kernel(int bf, int id);
+int y355_prepare_convg(void);
+int y355_convg_select(int in_pb, int cout, int pool, int H, int W);
+int y355_convg_ksteps(const ConvGInfo &ki, int in_pb, int taps);
+size_t y355_convg_packed_bytes(const ConvGInfo &ki, int in_pb, int taps, int cout_pad);
+void y355_convg_pack(const ConvGInfo &ki, const float *w_f, const int8_t *w_q, int cout, int cin, int ksize,
+                     int in_pb, int cout_pad, char *dst);
+void y355_conv1f_tiles(int H, int W, int *tx, int *ty);
+void y355_launch_conv1f(const Conv1FParams &p, hipStream_t s);
+void y355_pack_conv1f(const float *w, char *dst);

@@ -26,6 +26,20 @@ class Config(C.Structure):
                 ("own_stream", C.c_int32)]
 
 
+class NetConfig(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("arch", C.c_int32), ("dtype", C.c_int32),
+                ("height", C.c_int32), ("width", C.c_int32),
+                ("num_classes", C.c_int32), ("num_anchors", C.c_int32),
+                ("anchors", C.c_float * (2 * MAX_ANCHORS)),
+                ("conf_thresh", C.c_float), ("nms_thresh", C.c_float),
+                ("max_batch", C.c_int32), ("max_det", C.c_int32), ("stream", C.c_void_p),
+                ("own_stream", C.c_int32)]
+
+
+ARCH_SLIM_V2, ARCH_TINY_V3 = 0, 1
+DT_INT8, DT_BF16 = 0, 1
+
+
 class LayerStats(C.Structure):
     _fields_ = [("absmax_t", C.c_int64), ("frac_bits", C.c_int32), ("reserved", C.c_int32),
                 ("saturated", C.c_int64), ("guard", C.c_int64)]
@@ -70,6 +84,24 @@ _SIGS = {
     "y355_sync": (C.c_int, [C.c_void_p]),
     "y355_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "y355_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
+    "y355_net_create": (C.c_int, [P(NetConfig), P(C.c_void_p)]),
+    "y355_net_destroy": (None, [C.c_void_p]),
+    "y355_net_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "y355_net_num_layers": (C.c_int, [C.c_void_p]),
+    "y355_net_num_tensors": (C.c_int, [C.c_void_p]),
+    "y355_net_layer_shape": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32)]),
+    "y355_net_tensor_shape": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32)]),
+    "y355_net_load_layer_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "y355_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_net_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_net_get_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "y355_net_tensor_absmax": (C.c_int, [C.c_void_p, C.c_int, C.c_int, P(C.c_float)]),
+    "y355_net_max_det": (C.c_int, [C.c_void_p]),
+    "y355_net_num_anchors_total": (C.c_int, [C.c_void_p]),
+    "y355_net_sync": (C.c_int, [C.c_void_p]),
+    "y355_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "y355_net_num_timers": (C.c_int, [C.c_void_p]),
+    "y355_net_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
 }
 
 

@@ -21,7 +21,9 @@ import torch.nn as nn
 
 from .. import prep
 from ..engine import Engine
-from ..utils import Conv2d_fuse
+from ..netengine import Net
+from ..utils import Conv2d, Conv2d_fuse
+from ..utils.modules import folded_f32
 
 _CONVS = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7"]
 _TRACKERS = ["a_tracker_in", "a_tracker1", "a_tracker2", "a_tracker3_1", "a_tracker3_2", "a_tracker4_1",
@@ -154,3 +156,96 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
                 m = getattr(self, n)
                 m.scale.copy_(t.scale.to(m.scale.device))
                 m.first_a.fill_(float(t.first_a))
+
+
+class _NetModel(nn.Module):
+    """Shared plumbing of the fp32 model drop-ins: fold BN, load the engine, batched forward."""
+    _arch = None
+
+    def _conv_modules(self):
+        raise NotImplementedError
+
+    def _flat_anchors(self):
+        return [list(map(float, a)) for a in self.anchor_size.view(-1, 2).tolist()]
+
+    def set_grid(self, input_size):
+        self.input_size = list(input_size)
+        self.scale = np.array([[[input_size[1], input_size[0], input_size[1], input_size[0]]]])
+
+    def forward_batch(self, x):
+        if self.trainable:
+            raise NotImplementedError("yolo355 is an inference engine: the training branch is out of scope")
+        if self.training and any(isinstance(m, nn.BatchNorm2d) for m in self.modules()):
+            raise NotImplementedError("yolo355 folds BatchNorm with its running statistics: call .eval() first")
+        net = self._get_net(int(x.shape[0]))
+        net.set_thresholds(self.conf_thresh, self.nms_thresh)
+        return net.forward(x)
+
+    def _weights_version(self):
+        t = list(self.parameters()) + list(self.buffers())
+        return tuple(int(p._version) for p in t) + tuple(p.data_ptr() for p in t)
+
+    def _get_net(self, batch):
+        key = (tuple(self.input_size), self.num_classes, tuple(map(tuple, self._flat_anchors())))
+        if self._net is None or self._net_key != key or self._net.max_batch < batch:
+            if self._net is not None:
+                self._net.close()
+            dev = self.device if isinstance(self.device, (str, torch.device)) else "cuda:0"
+            self._net = Net(self._arch, self.input_size, self.num_classes, self._flat_anchors(), self.conf_thresh,
+                            self.nms_thresh, max_batch=max(batch, 1), device=dev, dtype="bf16")
+            self._net_key = key
+            self._loaded_version = None
+        ver = self._weights_version()
+        if self._loaded_version != ver:
+            for i, m in enumerate(self._conv_modules()):
+                w, b = folded_f32(m)
+                self._net.load_layer(i, w, b)
+            self._loaded_version = ver
+        return self._net
+
+
+class SlimYOLOv2(_NetModel):
+    """Drop-in for the reference's fp32 model (models/slim_yolo_v2.py:385-622): same constructor,
+    modules (utils.modules.Conv2d = conv + BN + LeakyReLU(0.125)), state_dict keys and eval-mode
+    return.  Inference runs BN-folded on the MI355X with bf16 MFMA and fp32 accumulation
+    (include/yolo355.h, y355_net); `quantization` / `find` are accepted and ignored like the
+    reference does (:549)."""
+    _arch = "slim_yolo_v2"
+
+    def __init__(self, device, input_size=None, num_classes=20, trainable=False, conf_thresh=0.01,
+                 nms_thresh=0.5, anchor_size=None, hr=False):
+        super().__init__()
+        self.device = device
+        self.input_size = list(input_size)
+        self.num_classes = num_classes
+        self.trainable = trainable
+        self.conf_thresh = conf_thresh
+        self.nms_thresh = nms_thresh
+        self.anchor_size = torch.tensor(anchor_size)
+        self.anchor_number = len(anchor_size)
+        self.stride = 16
+        self.scale = np.array([[[input_size[1], input_size[0], input_size[1], input_size[0]]]])
+        self.conv1 = Conv2d(3, 16, 3, 1, leakyReLU=True)
+        self.pool1 = nn.MaxPool2d(2, 2)
+        self.conv2 = Conv2d(16, 32, 3, 1, leakyReLU=True)
+        self.pool2 = nn.MaxPool2d(2, 2)
+        self.conv3_1 = Conv2d(32, 64, 3, 1, leakyReLU=True)
+        self.conv3_2 = Conv2d(64, 64, 3, 1, leakyReLU=True)
+        self.pool3 = nn.MaxPool2d(2, 2)
+        self.conv4_1 = Conv2d(64, 128, 3, 1, leakyReLU=True)
+        self.conv4_2 = Conv2d(128, 128, 3, 1, leakyReLU=True)
+        self.pool4 = nn.MaxPool2d(2, 2)
+        self.conv5 = Conv2d(128, 256, 3, 1, leakyReLU=True)
+        self.conv6 = Conv2d(256, 256, 3, 1, leakyReLU=True)
+        self.conv7 = Conv2d(256, 256, 3, 1, leakyReLU=True)
+        self.pred = nn.Conv2d(256, self.anchor_number * (1 + 4 + self.num_classes), 3, 1, padding=1)
+        self._net = None
+        self._net_key = None
+        self._loaded_version = None
+
+    def _conv_modules(self):
+        return [getattr(self, n).convs for n in _CONVS] + [self.pred]
+
+    def forward(self, x, target=None, quantization=False, find=False):
+        """Eval-mode return of the reference (:585-601): detections of image 0."""
+        return self.forward_batch(x)[0]

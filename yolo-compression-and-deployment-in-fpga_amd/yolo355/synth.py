@@ -124,3 +124,56 @@ def make_bn(seed, cout):
     var = 1.0 + 0.5 * uniform_pm1(seed * 7 + 4, (cout,))
     return (g.astype(np.float32), be.astype(np.float32), mu.astype(np.float32),
             var.astype(np.float32))
+
+
+# ---- fp32 model families (SlimYOLOv2 with BatchNorm, YOLOv3tiny) ---------------------------
+TINY_MULTI_ANCHOR_SIZE = [[34.01, 61.79], [86.94, 109.68], [93.49, 227.46],
+                          [246.38, 163.33], [178.68, 306.55], [344.89, 337.14]]      # data/config.py:27-28
+# (state_dict prefix, cin, cout, ksize, has_bn) in the weight-slot order of csrc/net.hip
+TINY_LAYERS = [
+    ("backbone.conv_1", 3, 16, 3, True), ("backbone.conv_2", 16, 32, 3, True), ("backbone.conv_3", 32, 64, 3, True),
+    ("backbone.conv_4", 64, 128, 3, True), ("backbone.conv_5", 128, 256, 3, True), ("backbone.conv_6", 256, 512, 3, True),
+    ("backbone.conv_7", 512, 1024, 3, True), ("conv_set_2", 1024, 256, 3, True), ("conv_1x1_2", 256, 128, 1, True),
+    ("conv_set_1", 384, 256, 3, True), ("extra_conv_2", 256, 512, 3, True), ("pred_2", 512, None, 1, False),
+    ("pred_1", 256, None, 1, False),
+]
+
+
+def make_fp32_model(arch, seed, num_classes, num_anchors, weight_gain=2.2, pred_gain=1.0, obj_bias=None):
+    """Synthetic fp32 parameters of an un-fused model: list of dicts
+    {name, w [cout,cin,k,k], b [cout], bn (gamma, beta, mean, var) or None} in weight-slot order.
+    weight_gain ~ 2.2 keeps activations O(1) through the LeakyReLU stack."""
+    if arch == "slim_yolo_v2":
+        table = [(n, cin, cout, 3, n != "pred") for (n, cin, cout, _p, _a) in SLIM_LAYERS]
+    elif arch == "tiny_yolo_v3":
+        table = TINY_LAYERS
+    else:
+        raise ValueError(arch)
+    out = []
+    for li, (name, cin, cout, k, has_bn) in enumerate(table):
+        if cout is None:
+            cout = pred_channels(num_classes, num_anchors)
+        bound = 1.0 / np.sqrt(cin * k * k)
+        gain = weight_gain if has_bn else pred_gain
+        w = uniform_pm1(seed * 1000 + 2 * li, (cout, cin, k, k)) * np.float32(bound * gain)
+        b = uniform_pm1(seed * 1000 + 2 * li + 1, (cout,)) * np.float32(bound)
+        if not has_bn and obj_bias is not None:
+            b[:num_anchors] = np.float32(obj_bias)
+        out.append(dict(name=name, w=w.astype(np.float32), b=b.astype(np.float32),
+                        bn=make_bn(seed * 100 + li, cout) if has_bn else None))
+    return out
+
+
+def state_dict_fp32(layers):
+    """torch state_dict entries (numpy) for the reference's / the drop-ins' module names."""
+    sd = {}
+    for L in layers:
+        n = L["name"]
+        if L["bn"] is None:
+            sd[n + ".weight"], sd[n + ".bias"] = L["w"], L["b"]
+        else:
+            g, be, mu, var = L["bn"]
+            sd[n + ".convs.0.weight"], sd[n + ".convs.0.bias"] = L["w"], L["b"]
+            sd[n + ".convs.1.weight"], sd[n + ".convs.1.bias"] = g, be
+            sd[n + ".convs.1.running_mean"], sd[n + ".convs.1.running_var"] = mu, var
+    return sd

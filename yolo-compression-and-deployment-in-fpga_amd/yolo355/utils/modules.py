@@ -44,10 +44,26 @@ class _FusedBase(nn.Module):
         return y.to(x.device)
 
 
+def folded_f32(convs):
+    """Exact eval-mode fold of nn.Sequential(conv, BatchNorm2d, act) (or a bare conv) into fp32
+    (W', b') numpy arrays: W' = W * g, b' = (b - mean) * g + beta, g = gamma / sqrt(var + eps).
+    (The reference's fuse_conv_and_bn, utils/bn_fuse.py:42-43, leaves b unscaled; the fp32 model's
+    own forward is conv -> BN, which this fold reproduces.)"""
+    conv = convs[0] if isinstance(convs, nn.Sequential) else convs
+    w = conv.weight.detach().double().cpu()
+    b = conv.bias.detach().double().cpu() if conv.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64)
+    if isinstance(convs, nn.Sequential) and len(convs) > 1 and isinstance(convs[1], nn.BatchNorm2d):
+        bn = convs[1]
+        g = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+        w = w * g.view(-1, 1, 1, 1)
+        b = (b - bn.running_mean.detach().double().cpu()) * g + bn.bias.detach().double().cpu()
+    return w.float().numpy(), b.float().numpy()
+
+
 class Conv2d(nn.Module):
-    """conv + BatchNorm + LeakyReLU(0.125)/ReLU (utils/modules.py:6-18).  Un-folded BN only
-    exists on the fp32 training path, which this engine does not implement; fold it with
-    fuse_conv_and_bn (conv+bn2conv.py:314-326) and use Conv2d_fuse."""
+    """conv + BatchNorm + LeakyReLU(0.125)/ReLU (utils/modules.py:6-18): the building block of the
+    fp32 models (SlimYOLOv2, the YOLOv3tiny head).  The models fold BN at load time and run whole
+    graphs through the engine; a stand-alone call of this module is not built."""
 
     def __init__(self, in_channels, out_channels, ksize, padding=0, stride=1, dilation=1, leakyReLU=False):
         super().__init__()
@@ -57,7 +73,8 @@ class Conv2d(nn.Module):
             nn.LeakyReLU(0.125, inplace=True) if leakyReLU else nn.ReLU(inplace=True))
 
     def forward(self, x):
-        raise NotImplementedError("yolo355: BN is folded before inference; use fuse_conv_and_bn + Conv2d_fuse")
+        raise NotImplementedError("yolo355: stand-alone Conv2d.forward is not built; the fp32 models "
+                                  "(SlimYOLOv2, YOLOv3tiny) run whole graphs through y355_net")
 
 
 class Conv2d_fuse(_FusedBase):
