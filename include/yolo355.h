@@ -192,6 +192,19 @@ int y355_net_tensor_shape(y355_net *h, int idx, int32_t *shape /*[3] C,H,W*/);
 /* replaces load_state_dict + fuse_conv_and_bn for one conv: w fp32 [cout][cin][k][k], b fp32 [cout]
  * (NULL = zero), host pointers */
 int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, const float *b, int cout, int cin, int ksize);
+/* dtype Y355_DT_INT8: the power-of-two int8 recipe of the q_bf path (retune_bias_quantize.py:73-119,
+ * models/slim_yolo_v2.py:16-38) applied to these graphs -- the reference itself has no int8 form of
+ * them.  q_w int8 [cout][cin][k][k] (value q_w / 2^e_w), q_b int32 [cout] (value q_b / 2^e_b).
+ * LeakyReLU(0.1) runs as the fixed-point slope 205/2048; DESIGN.md lists the integer semantics. */
+int y355_net_load_layer_i8(y355_net *h, int idx, const int8_t *q_w, const int32_t *q_b, int cout, int cin,
+                           int ksize, int e_w, int e_b);
+/* activation exponents (value = q / 2^sa): sa_in for the network input, sa[t] per activation tensor in
+ * graph order; a max-pool output takes its input's exponent (its entry is overridden), a concat
+ * buffer has one exponent.  get returns the effective values. */
+int y355_net_set_act_exponents(y355_net *h, int sa_in, const int32_t *sa, int n);
+int y355_net_get_act_exponents(y355_net *h, int32_t *sa_in, int32_t *sa, int n);
+/* outputs clamped to +-127 by the last forward of an int8 net; synchronous */
+int y355_net_counters(y355_net *h, int64_t *saturated);
 /* replaces SlimYOLOv2.forward (:549-601) / YOLOv3tiny.forward (tiny_yolo_v3.py:176-243) for a whole
  * batch; arguments and outputs as y355_forward. */
 int y355_net_forward(y355_net *h, const float *x_dev, int batch, int flags,

@@ -121,12 +121,13 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
         return;
     }
     __syncthreads();
-    int8_t *outb = p.out + (size_t)b * (Ho + 2) * (Wo + 2) * 16;
+    const int opb = p.out_pb ? p.out_pb : 16;
+    int8_t *outb = p.out + (size_t)b * (Ho + 2) * (Wo + 2) * opb;
     for (int w = tid; w < NW; w += 256) {
         const int wy = w / (TW / 2), wx = w % (TW / 2);
         const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
         if (oy < Ho && ox < Wo)
-            *(v4i *)(outb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * 16) = *(const v4i *)(otile + w * 16);
+            *(v4i *)(outb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * opb) = *(const v4i *)(otile + w * 16);
     }
     if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
     if (nguard) atomicAdd(&p.ctr->guard, (unsigned long long)nguard);
@@ -260,7 +261,7 @@ void y355_conv1_tiles(int H, int W, int *tx, int *ty) {
 void y355_launch_conv1(const Conv1Params &p, hipStream_t s) {
     const int n = p.tiles_x * p.tiles_y * p.B;
     const bool big = conv1_tw(p.W) == 104;
-    if (p.mode == 0 && !p.rq.wide && !p.guard) {
+    if (p.mode == 0 && !p.rq.wide && !p.guard && !p.out_pb) {
         if (big) hipLaunchKernelGGL((conv1_fast_kernel<104>), dim3(n), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv1_fast_kernel<32>), dim3(n), dim3(256), 0, s, p);
         return;

@@ -115,6 +115,7 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     rq->sh = sh;
     rq->leaky = leaky;
     rq->lk = leaky ? 3 : 0;
+    rq->neg_mul = 1;
     rq->sh_l = sh < 0 ? -sh : 0;
     rq->sh_r = sh > 0 ? sh : 0;
     rq->hm1 = sh > 0 ? (int)((1ll << (sh - 1)) - 1) : 0;

@@ -93,6 +93,13 @@ struct NLayer {
     char *w_dev = nullptr;
     float *bias_dev = nullptr;
     size_t w_bytes = 0;
+    // int8 nets
+    std::vector<int32_t> q_b;
+    int e_w = 0, e_b = 0;
+    long long *bias_w_dev = nullptr;
+    RequantG rq{};
+    Requant rq1{};            // first layer (conv1.hip epilogue)
+    bool dirty = true;
 };
 
 __global__ void pool_bf16_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int cbytes, int Ho, int Wo,
@@ -161,6 +168,67 @@ __global__ void upsample_bf16_kernel(const char *in, char *out, int B, int Hin, 
     }
 }
 
+__global__ void pool_i8_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int cbytes, int Ho, int Wo,
+                               int out_pb, int stride) {
+    const int cg = cbytes / 16;
+    const size_t total = (size_t)B * Ho * Wo * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg);
+        size_t r = i / cg;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const char *src = in + (((size_t)b * (Hin + 2) + y * stride + 1) * (Win + 2) + x * stride + 1) * in_pb + c * 16;
+        uint4 v[4];
+        v[0] = *(const uint4 *)src;
+        v[1] = *(const uint4 *)(src + in_pb);
+        v[2] = *(const uint4 *)(src + (size_t)(Win + 2) * in_pb);
+        v[3] = *(const uint4 *)(src + (size_t)(Win + 2) * in_pb + in_pb);
+        unsigned int o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned int res = 0;
+#pragma unroll
+            for (int by = 0; by < 4; ++by) {
+                int m = -128;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m = max(m, (int)(signed char)((((const unsigned int *)&v[j])[k] >> (8 * by)) & 0xffu));
+                res |= (unsigned int)(m & 0xff) << (8 * by);
+            }
+            o[k] = res;
+        }
+        *(uint4 *)(out + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * out_pb + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// int8 form of the bilinear x2: the blend of the integer values in fp32 (same expression as the bf16
+// kernel), rescaled by the power of two between the two tensors' exponents, rounded half-to-even.
+__global__ void upsample_i8_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int C, int out_pb,
+                                   int out_off, float ry, float rx, float rescale) {
+    const int Ho = 2 * Hin, Wo = 2 * Win;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float sy = ry * (float)y, sx = rx * (float)x;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        auto ld = [&](int yy, int xx) -> float {
+            return (float)*(const signed char *)(in + (((size_t)b * (Hin + 2) + yy + 1) * (Win + 2) + xx + 1) * in_pb + c);
+        };
+        const float v = hy * (hx * ld(y0, x0) + lx * ld(y0, x1)) + ly * (hx * ld(y1, x0) + lx * ld(y1, x1));
+        const float q = fminf(fmaxf(rintf(v * rescale), -127.f), 127.f);
+        *(signed char *)(out + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * out_pb + out_off + c) = (signed char)(int)q;
+    }
+}
+
 __global__ void absmax_bf16_kernel(const char *t, size_t n_elems, unsigned int *out) {
     float m = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += (size_t)gridDim.x * blockDim.x) {
@@ -187,6 +255,11 @@ struct y355_net {
     float *cand_box = nullptr, *cand_score = nullptr;
     int *cand_cls = nullptr;
     unsigned int *absmax_dev = nullptr;
+    // int8 nets: activation exponents (value = q / 2^sa) of the input and of every tensor
+    int sa_in = 0;
+    bool sa_ok = false;
+    std::vector<int> sa;
+    Counters *ctr_dev = nullptr;      // [nops + 1]
     int profile = 0;
     std::vector<hipEvent_t> ev;
     std::vector<void *> allocs;
@@ -212,7 +285,7 @@ extern "C" void y355_net_destroy(y355_net *h) {
 extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (!cfg || !out) return y355_fail(Y355_EINVAL, "null argument");
     if (cfg->arch != Y355_ARCH_SLIM_V2 && cfg->arch != Y355_ARCH_TINY_V3) return y355_fail(Y355_EINVAL, "unknown arch");
-    if (cfg->dtype != Y355_DT_BF16) return y355_fail(Y355_EINVAL, "y355_net: dtype not built (bf16 only)");
+    if (cfg->dtype != Y355_DT_BF16 && cfg->dtype != Y355_DT_INT8) return y355_fail(Y355_EINVAL, "unknown dtype");
     if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % 32 || cfg->width % 32)
         return y355_fail(Y355_EINVAL, "input size must be a positive multiple of 32");
     const ArchDef &A = kArch[cfg->arch];
@@ -231,9 +304,10 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     y355_net *h = new y355_net();
     h->cfg = *cfg;
     h->arch = &A;
-    h->bf = true;
-    h->es = 2;
+    h->bf = cfg->dtype == Y355_DT_BF16;
+    h->es = h->bf ? 2 : 1;
     h->predc = predc;
+    h->sa.assign(A.ntensors, 0);
     h->N = N;
     h->max_det = (cfg->max_det <= 0 || cfg->max_det > N) ? N : cfg->max_det;
     if (!cfg->own_stream) h->stream = (hipStream_t)cfg->stream;
@@ -254,8 +328,10 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
         t.halo = t.pred ? 0 : 1;
         t.H = cfg->height / A.t[i].div;
         t.W = cfg->width / A.t[i].div;
-        t.Cpad = t.pred ? (t.C <= 64 ? 64 : t.C <= 128 ? 128 : 256) : (t.C + 15) / 16 * 16;
-        t.pb = (size_t)t.Cpad * (t.pred ? 4 : h->es);
+        // a pixel is at least 32 bytes (the thin path of convg.hip)
+        const int cq = h->bf ? 16 : 32;
+        t.Cpad = t.pred ? (t.C <= 64 ? 64 : t.C <= 128 ? 128 : 256) : (t.C + cq - 1) / cq * cq;
+        t.pb = (size_t)t.Cpad * ((t.pred && h->bf) ? 4 : h->es);
         t.bytes = ((size_t)B * (t.H + 2 * t.halo) * (t.W + 2 * t.halo) + 64) * t.pb;
         rc = nmalloc(h, (void **)&t.dev, t.bytes, true);
     }
@@ -273,20 +349,22 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
             rc = nmalloc(h, (void **)&h->w0_dev, 2048, true);
         } else {
             const Tensor &ti = h->T[o.in];
-            L.kid = y355_convg_select((int)(o.cin * h->es), L.cout, o.pool, ti.H, ti.W);
-            const ConvGInfo &ki = *y355_convg_kernel(1, L.kid);
+            L.kid = y355_convg_select((int)(ti.Cpad * h->es), L.cout, o.pool, ti.H, ti.W);
+            const ConvGInfo &ki = *y355_convg_kernel(h->bf, L.kid);
             L.cout_pad = (L.cout + ki.bn - 1) / ki.bn * ki.bn;
             if (h->T[o.out].pred && L.cout_pad > h->T[o.out].Cpad) {
                 rc = y355_fail(Y355_EINVAL, "prediction map wider than its buffer");
                 break;
             }
-            L.w_bytes = y355_convg_packed_bytes(ki, o.cin * h->es, o.ksize * o.ksize, L.cout_pad);
+            L.w_bytes = y355_convg_packed_bytes(ki, ti.Cpad * h->es, o.ksize * o.ksize, L.cout_pad);
             rc = nmalloc(h, (void **)&L.w_dev, L.w_bytes, true);
         }
         if (!rc) rc = nmalloc(h, (void **)&L.bias_dev, sizeof(float) * L.cout_pad, true);
+        if (!rc) rc = nmalloc(h, (void **)&L.bias_w_dev, sizeof(long long) * L.cout_pad, true);
     }
     const size_t cap = Y355_NMS_CAP;
     if (!rc) rc = nmalloc(h, (void **)&h->absmax_dev, 16, true);
+    if (!rc) rc = nmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * (A.nops + 1), true);
     if (!rc) rc = nmalloc(h, &h->ws.cbox, sizeof(float) * 4 * cap * B, false);
     if (!rc) rc = nmalloc(h, &h->ws.cscore, sizeof(float) * cap * B, false);
     if (!rc) rc = nmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
@@ -365,13 +443,128 @@ extern "C" int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, con
     } else {
         const ConvGInfo &ki = *y355_convg_kernel(1, L.kid);
         std::vector<char> packed(L.w_bytes);
-        y355_convg_pack(ki, w, nullptr, cout, cin, ksize, cin * h->es, L.cout_pad, packed.data());
+        y355_convg_pack(ki, w, nullptr, cout, cin, ksize, h->T[o.in].Cpad * h->es, L.cout_pad, packed.data());
         HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
     }
     std::vector<float> bias(L.cout_pad, 0.f);
     if (b) memcpy(bias.data(), b, sizeof(float) * cout);
     HIPCHK(hipMemcpy(L.bias_dev, bias.data(), sizeof(float) * L.cout_pad, hipMemcpyHostToDevice));
     L.loaded = true;
+    return 0;
+}
+
+// replaces load_state_dict of a checkpoint written by quantize_layers (retune_bias_quantize.py:111-119)
+// for one conv of an int8 net: q_w int8 [cout][cin][k][k] (value q_w / 2^e_w), q_b int32 [cout]
+extern "C" int y355_net_load_layer_i8(y355_net *h, int idx, const int8_t *q_w, const int32_t *q_b, int cout, int cin,
+                                      int ksize, int e_w, int e_b) {
+    if (!h || !q_w || !q_b) return y355_fail(Y355_EINVAL, "null argument");
+    if (idx < 0 || idx >= h->arch->nlayers) return y355_fail(Y355_EINVAL, "layer index out of range");
+    if (h->bf) return y355_fail(Y355_EINVAL, "int8 weights go to an int8 net");
+    NLayer &L = h->L[idx];
+    if (cout != L.cout || cin != L.cin || ksize != L.ksize) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "layer %d expects [%d,%d,%d,%d], got [%d,%d,%d,%d]", idx, L.cout, L.cin, L.ksize, L.ksize,
+                 cout, cin, ksize, ksize);
+        return y355_fail(Y355_EINVAL, buf);
+    }
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const OpDef &o = h->arch->ops[L.op];
+    if (o.type == OP_CONV1) {
+        int8_t frag[1024];
+        y355_pack_conv1(q_w, frag);
+        HIPCHK(hipMemcpy(h->w0_dev, frag, 1024, hipMemcpyHostToDevice));
+    } else {
+        const ConvGInfo &ki = *y355_convg_kernel(0, L.kid);
+        std::vector<char> packed(L.w_bytes);
+        y355_convg_pack(ki, nullptr, q_w, cout, cin, ksize, h->T[o.in].Cpad, L.cout_pad, packed.data());
+        HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
+    L.q_b.assign(q_b, q_b + cout);
+    L.e_w = e_w;
+    L.e_b = e_b;
+    L.loaded = true;
+    L.dirty = true;
+    return 0;
+}
+
+// activation exponents of an int8 net: sa_in for the fp32 network input, sa[t] for tensor t (graph
+// order of csrc/net.hip).  A max-pool output takes its input's exponent (the entry given for it is
+// overridden); a concat buffer has ONE exponent that both producers requantise to.
+extern "C" int y355_net_set_act_exponents(y355_net *h, int sa_in, const int32_t *sa, int n) {
+    if (!h || !sa) return y355_fail(Y355_EINVAL, "null argument");
+    if (h->bf) return y355_fail(Y355_EINVAL, "bf16 nets have no activation exponents");
+    if (n != h->arch->ntensors) return y355_fail(Y355_EINVAL, "one exponent per tensor expected");
+    for (int i = 0; i < n; ++i)
+        if (sa[i] < -64 || sa[i] > 64) return y355_fail(Y355_EINVAL, "activation exponent out of range");
+    if (sa_in < -64 || sa_in > 64) return y355_fail(Y355_EINVAL, "activation exponent out of range");
+    h->sa_in = sa_in;
+    h->sa.assign(sa, sa + n);
+    for (int i = 0; i < h->arch->nops; ++i) {
+        const OpDef &o = h->arch->ops[i];
+        if (o.type == OP_POOL) h->sa[o.out] = h->sa[o.in];      // max-pool does not requantise
+    }
+    h->sa_ok = true;
+    for (auto &L : h->L) L.dirty = true;
+    return 0;
+}
+
+extern "C" int y355_net_get_act_exponents(y355_net *h, int32_t *sa_in, int32_t *sa, int n) {
+    if (!h || !sa_in || !sa || n != h->arch->ntensors) return y355_fail(Y355_EINVAL, "bad argument");
+    *sa_in = h->sa_in;
+    for (int i = 0; i < n; ++i) sa[i] = h->sa[i];
+    return 0;
+}
+
+static void act_fixed(int act, int *lk, int *neg_mul) {
+    // LeakyReLU slope as neg_mul / 2^lk: 0.125 exactly; 0.1 ~ 205 / 2048 (build-defined)
+    if (act == ACT_L125) { *lk = 3; *neg_mul = 1; }
+    else if (act == ACT_L100) { *lk = 11; *neg_mul = 205; }
+    else { *lk = 0; *neg_mul = 1; }
+}
+
+static int refresh_i8(y355_net *h) {
+    if (!h->sa_ok) return y355_fail(Y355_ENOTREADY, "activation exponents not set (calibrate first)");
+    for (int i = 0; i < h->arch->nops; ++i) {
+        const OpDef &o = h->arch->ops[i];
+        if (o.type != OP_CONV1 && o.type != OP_CONV) continue;
+        NLayer &L = h->L[o.layer];
+        if (!L.loaded) return y355_fail(Y355_ENOTREADY, "layer weights not loaded");
+        if (!L.dirty) continue;
+        const int sa_i = o.in < 0 ? h->sa_in : h->sa[o.in], sa_o = h->sa[o.out];
+        const int F = std::max(sa_i + L.e_w, L.e_b);
+        const int shl = F - sa_i - L.e_w, bshl = F - L.e_b;
+        int lk, nm;
+        act_fixed(o.act, &lk, &nm);
+        const int sh = F + lk - sa_o;
+        if (shl > 24 || bshl > 40 || sh > 62 || sh < -20) return y355_fail(Y355_ERANGE, "exponent gap too large for the fixed-point epilogue");
+        // worst case |t'| (through the slope and a left shift / the rounding add) must stay below 2^62
+        std::vector<long long> bw(L.cout_pad, 0);
+        long double bmax = 0;
+        for (int c = 0; c < L.cout; ++c) {
+            bw[c] = (long long)L.q_b[c] * (1ll << bshl);
+            bmax = std::max(bmax, (long double)std::llabs(bw[c]));
+        }
+        long double lim = ((long double)127 * 127 * o.ksize * o.ksize * o.cin) * std::ldexp(1.0L, shl) + bmax;
+        lim *= std::max(std::ldexp(1.0L, lk), (long double)nm);
+        lim = sh < 0 ? lim * std::ldexp(1.0L, -sh) : lim + std::ldexp(1.0L, sh);
+        if (lim >= std::ldexp(1.0L, 62)) return y355_fail(Y355_ERANGE, "fixed-point epilogue exceeds 62 bits");
+        L.rq.shl = shl;
+        L.rq.sh = sh;
+        L.rq.lk = lk;
+        L.rq.neg_mul = nm;
+        L.rq1 = Requant{};
+        L.rq1.shl = shl;
+        L.rq1.sh = sh;
+        L.rq1.leaky = (lk || nm != 1) ? 1 : 0;
+        L.rq1.lk = lk;
+        L.rq1.neg_mul = nm;
+        L.rq1.guard_log2 = 63;
+        L.rq1.wide = 1;
+        HIPCHK(hipMemcpyAsync(L.bias_w_dev, bw.data(), sizeof(long long) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        L.dirty = false;
+    }
     return 0;
 }
 
@@ -383,6 +576,26 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
     if (o.type == OP_CONV1) {
         const NLayer &L = h->L[o.layer];
         if (!L.loaded) return y355_fail(Y355_ENOTREADY, "layer weights not loaded");
+        if (!h->bf) {
+            Conv1Params p{};
+            p.x = x_dev;
+            p.out = (int8_t *)h->T[o.out].dev;
+            p.out_pb = (int)h->T[o.out].pb;
+            p.w = (const int8_t *)h->w0_dev;
+            p.bias_w = L.bias_w_dev;
+            p.ctr = h->ctr_dev + i;
+            p.B = B;
+            p.H = h->cfg.height;
+            p.W = h->cfg.width;
+            y355_conv1_tiles(p.H, p.W, &p.tiles_x, &p.tiles_y);
+            p.in_scale = std::ldexp(1.0f, h->sa_in);
+            p.rq = L.rq1;
+            p.mode = 0;
+            p.guard = 0;
+            y355_launch_conv1(p, s);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
         Conv1FParams p{};
         p.x = x_dev;
         p.out = h->T[o.out].dev;
@@ -398,41 +611,52 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
         const NLayer &L = h->L[o.layer];
         if (!L.loaded) return y355_fail(Y355_ENOTREADY, "layer weights not loaded");
         const Tensor &ti = h->T[o.in], &to = h->T[o.out];
-        const ConvGInfo &ki = *y355_convg_kernel(1, L.kid);
+        const ConvGInfo &ki = *y355_convg_kernel(h->bf, L.kid);
         ConvGParams p{};
         p.in = ti.dev;
         p.out = to.dev;
         p.w = L.w_dev;
         p.bias_f = L.bias_dev;
+        p.bias_w = L.bias_w_dev;
+        p.ctr = h->ctr_dev + i;
+        p.rq = L.rq;
         p.B = B;
         p.H = ti.H;
         p.W = ti.W;
         p.in_pb = (int)ti.pb;
-        p.nchunks = o.cin * h->es / ki.chb;
+        p.nchunks = ti.Cpad * h->es / ki.chb;
         p.out_pb = (int)to.pb;
-        p.out_off = o.choff * (to.pred ? 4 : h->es);
+        p.out_off = o.choff * ((to.pred && h->bf) ? 4 : h->es);
         p.out_halo = to.halo;
         p.tiles_x = (ti.W + ki.tw - 1) / ki.tw;
         p.tiles_y = (ti.H + ki.th - 1) / ki.th;
         p.nblk = L.cout_pad / ki.bn;
         p.taps = o.ksize * o.ksize;
         p.slope = act_slope(o.act);
-        p.out_f32 = to.pred;
+        p.out_f32 = to.pred && h->bf;
         ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, s);
     } else if (o.type == OP_POOL) {
         const Tensor &ti = h->T[o.in], &to = h->T[o.out];
         const int stride = o.pool ? 1 : 2;
         const size_t total = (size_t)B * to.H * to.W * (o.cin * h->es / 16);
         const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(pool_bf16_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb,
-                           o.cin * h->es, to.H, to.W, (int)to.pb, stride);
+        if (h->bf)
+            hipLaunchKernelGGL(pool_bf16_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb,
+                               o.cin * h->es, to.H, to.W, (int)to.pb, stride);
+        else
+            hipLaunchKernelGGL(pool_i8_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb,
+                               o.cin * h->es, to.H, to.W, (int)to.pb, stride);
     } else {
         const Tensor &ti = h->T[o.in], &to = h->T[o.out];
         const size_t total = (size_t)B * to.H * to.W * o.cin;
         const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
         const float ry = (float)(ti.H - 1) / (float)(to.H - 1), rx = (float)(ti.W - 1) / (float)(to.W - 1);
-        hipLaunchKernelGGL(upsample_bf16_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb, o.cin,
-                           (int)to.pb, o.choff * h->es, ry, rx);
+        if (h->bf)
+            hipLaunchKernelGGL(upsample_bf16_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb, o.cin,
+                               (int)to.pb, o.choff * h->es, ry, rx);
+        else
+            hipLaunchKernelGGL(upsample_i8_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb, o.cin,
+                               (int)to.pb, o.choff * h->es, ry, rx, std::ldexp(1.0f, h->sa[o.out] - h->sa[o.in]));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -445,13 +669,13 @@ static HeadParams net_head_params(y355_net *h, float *ob, float *os, int *oc, in
     for (int l = 0; l < A.nlev; ++l) {
         const Tensor &t = h->T[A.pred_t[l]];
         HeadLevel &lv = p.lev[l];
-        lv.pred = nullptr;
-        lv.pred_f = (const float *)t.dev;
+        lv.pred = h->bf ? nullptr : (const int8_t *)t.dev;
+        lv.pred_f = h->bf ? (const float *)t.dev : nullptr;
         lv.cstride = t.Cpad;
         lv.Hs = t.H;
         lv.Ws = t.W;
         lv.stride = A.stride[l];
-        lv.dq = 1.0f;
+        lv.dq = h->bf ? 1.0f : std::ldexp(1.0f, -h->sa[A.pred_t[l]]);
         for (int i = 0; i < 2 * h->cfg.num_anchors; ++i) lv.anchors[i] = h->cfg.anchors[l * 2 * h->cfg.num_anchors + i];
     }
     p.A = h->cfg.num_anchors;
@@ -482,6 +706,10 @@ extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int 
     HIPCHK(hipSetDevice(h->cfg.device_id));
     const bool prof = h->profile != 0;
     const int nops = h->arch->nops;
+    if (!h->bf) {
+        if (int rc = refresh_i8(h)) return rc;
+        HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * (nops + 1), h->stream));
+    }
     for (int i = 0; i < nops; ++i) {
         if (prof) HIPCHK(hipEventRecord(h->ev[i], h->stream));
         if (int rc = run_op(h, i, batch, x_dev)) return rc;
@@ -522,7 +750,9 @@ extern "C" int y355_net_get_tensor(y355_net *h, int idx, int batch, float *dst) 
                 for (int x = 0; x < t.W; ++x) {
                     const char *src = tmp.data() + (((size_t)b * Hp + y + t.halo) * Wp + x + t.halo) * t.pb;
                     float v;
-                    if (t.pred) {
+                    if (!h->bf) {
+                        v = std::ldexp((float)*(const signed char *)(src + c), -h->sa[idx]);
+                    } else if (t.pred) {
                         memcpy(&v, src + (size_t)c * 4, 4);
                     } else {
                         unsigned short hbits;
@@ -540,6 +770,7 @@ extern "C" int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *ou
     if (!h || !out_max || idx < 0 || idx >= h->arch->ntensors) return y355_fail(Y355_EINVAL, "bad argument");
     if (batch < 1 || batch > h->cfg.max_batch) return y355_fail(Y355_EINVAL, "batch out of range");
     const Tensor &t = h->T[idx];
+    if (!h->bf) return y355_fail(Y355_EINVAL, "absmax taps exist on bf16 nets (the calibration run)");
     if (t.pred) return y355_fail(Y355_EINVAL, "prediction maps are fp32: read them with y355_net_get_tensor");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemsetAsync(h->absmax_dev, 0, 16, h->stream));
@@ -550,6 +781,19 @@ extern "C" int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *ou
     HIPCHK(hipMemcpyAsync(&bits, h->absmax_dev, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(out_max, &bits, 4);
+    return 0;
+}
+
+// values clamped to +-127 in the last forward of an int8 net (input quantisation included); synchronous
+extern "C" int y355_net_counters(y355_net *h, int64_t *saturated) {
+    if (!h || !saturated) return y355_fail(Y355_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    std::vector<Counters> c(h->arch->nops + 1);
+    HIPCHK(hipMemcpyAsync(c.data(), h->ctr_dev, sizeof(Counters) * c.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int64_t s = 0;
+    for (auto &k : c) s += (int64_t)k.sat + (int64_t)k.in_sat;
+    *saturated = s;
     return 0;
 }
 

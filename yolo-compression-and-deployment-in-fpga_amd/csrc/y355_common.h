@@ -22,6 +22,9 @@ struct Requant {
     //   q  = ((t' << sh_l) + hm1 + bfe(t', sh_r, bw)) >> sh_r
     // with sh_r = max(sh,0), sh_l = max(-sh,0), hm1 = sh>0 ? 2^(sh-1)-1 : 0, bw = sh>0 ? 1 : 0
     int lk, sh_l, sh_r, hm1, bw;
+    // general LeakyReLU slope neg_mul / 2^lk (1 / 2^3 = the reference's 0.125); only the 64-bit
+    // epilogues (y355_pre) honour neg_mul != 1
+    int neg_mul;
 };
 
 // q before clamping, 32-bit, no branches (production kernels)
@@ -61,6 +64,7 @@ struct ConvParams {
 struct Conv1Params {
     const float *x;       // fp32 NCHW [B][3][H][W]
     int8_t *out;          // int8 NHWC16 with halo [B][H/2+2][W/2+2][16]
+    int out_pb;           // bytes per output pixel (0 = 16; wider: the extra bytes stay untouched)
     const int8_t *w;      // 64 lanes x 16 B fragment
     const int *bias_t;    // [16]
     const long long *bias_w;
@@ -84,7 +88,7 @@ __device__ __forceinline__ T y355_rne_shift(T t, int sh) {
 template <typename T>
 __device__ __forceinline__ T y355_pre(int acc, T bias, const Requant &rq) {
     T t = (T)acc * ((T)1 << rq.shl) + bias;
-    if (rq.leaky) t = max(t, t * 8);
+    if (rq.leaky) t = t >= 0 ? t * ((T)1 << rq.lk) : t * (T)rq.neg_mul;
     return t;
 }
 

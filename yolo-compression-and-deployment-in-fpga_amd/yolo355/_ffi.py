@@ -92,6 +92,10 @@ _SIGS = {
     "y355_net_layer_shape": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32)]),
     "y355_net_tensor_shape": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32)]),
     "y355_net_load_layer_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "y355_net_load_layer_i8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y355_net_set_act_exponents": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), C.c_int]),
+    "y355_net_get_act_exponents": (C.c_int, [C.c_void_p, P(C.c_int32), P(C.c_int32), C.c_int]),
+    "y355_net_counters": (C.c_int, [C.c_void_p, P(C.c_int64)]),
     "y355_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y355_net_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y355_net_get_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

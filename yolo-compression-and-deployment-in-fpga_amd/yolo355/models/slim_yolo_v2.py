@@ -172,36 +172,54 @@ class _NetModel(nn.Module):
         self.input_size = list(input_size)
         self.scale = np.array([[[input_size[1], input_size[0], input_size[1], input_size[0]]]])
 
-    def forward_batch(self, x):
+    def forward_batch(self, x, quantization=False):
+        """Every image of the batch.  quantization=True (YOLOv3tiny only) runs the int8 engine:
+        weights quantized per tensor to power-of-two int8 after the BN fold, activation exponents
+        frozen at the first quantized call from the bf16 run of that input -- the first-call rule of
+        AveragedRangeTracker (models/slim_yolo_v2.py:25-27) applied to this graph."""
         if self.trainable:
             raise NotImplementedError("yolo355 is an inference engine: the training branch is out of scope")
         if self.training and any(isinstance(m, nn.BatchNorm2d) for m in self.modules()):
             raise NotImplementedError("yolo355 folds BatchNorm with its running statistics: call .eval() first")
         net = self._get_net(int(x.shape[0]))
-        net.set_thresholds(self.conf_thresh, self.nms_thresh)
-        return net.forward(x)
+        if not quantization:
+            net.set_thresholds(self.conf_thresh, self.nms_thresh)
+            return net.forward(x)
+        if self.act_exponents is None:
+            self.act_exponents = net.calibration_exponents(x)
+        qnet = self._get_net(int(x.shape[0]), int8=True)
+        qnet.set_act_exponents(*self.act_exponents)
+        qnet.set_thresholds(self.conf_thresh, self.nms_thresh)
+        return qnet.forward(x)
 
     def _weights_version(self):
         t = list(self.parameters()) + list(self.buffers())
         return tuple(int(p._version) for p in t) + tuple(p.data_ptr() for p in t)
 
-    def _get_net(self, batch):
+    act_exponents = None      # (sa_in, [sa per tensor]) of the int8 path, frozen at the first quantized call
+
+    def _get_net(self, batch, int8=False):
+        slot = "q" if int8 else "f"
+        st = self.__dict__.setdefault("_nets", {}).setdefault(slot, dict(net=None, key=None, ver=None))
         key = (tuple(self.input_size), self.num_classes, tuple(map(tuple, self._flat_anchors())))
-        if self._net is None or self._net_key != key or self._net.max_batch < batch:
-            if self._net is not None:
-                self._net.close()
+        if st["net"] is None or st["key"] != key or st["net"].max_batch < batch:
+            if st["net"] is not None:
+                st["net"].close()
             dev = self.device if isinstance(self.device, (str, torch.device)) else "cuda:0"
-            self._net = Net(self._arch, self.input_size, self.num_classes, self._flat_anchors(), self.conf_thresh,
-                            self.nms_thresh, max_batch=max(batch, 1), device=dev, dtype="bf16")
-            self._net_key = key
-            self._loaded_version = None
+            st["net"] = Net(self._arch, self.input_size, self.num_classes, self._flat_anchors(), self.conf_thresh,
+                            self.nms_thresh, max_batch=max(batch, 1), device=dev, dtype="int8" if int8 else "bf16")
+            st["key"], st["ver"] = key, None
         ver = self._weights_version()
-        if self._loaded_version != ver:
-            for i, m in enumerate(self._conv_modules()):
-                w, b = folded_f32(m)
-                self._net.load_layer(i, w, b)
-            self._loaded_version = ver
-        return self._net
+        if st["ver"] != ver:
+            folded = [folded_f32(m) for m in self._conv_modules()]
+            if int8:
+                for i, q in enumerate(prep.quantize_folded(folded)):
+                    st["net"].load_layer_i8(i, q["q_w"], q["q_b"], q["e_w"], q["e_b"])
+            else:
+                for i, (w, b) in enumerate(folded):
+                    st["net"].load_layer(i, w, b)
+            st["ver"] = ver
+        return st["net"]
 
 
 class SlimYOLOv2(_NetModel):
@@ -239,9 +257,6 @@ class SlimYOLOv2(_NetModel):
         self.conv6 = Conv2d(256, 256, 3, 1, leakyReLU=True)
         self.conv7 = Conv2d(256, 256, 3, 1, leakyReLU=True)
         self.pred = nn.Conv2d(256, self.anchor_number * (1 + 4 + self.num_classes), 3, 1, padding=1)
-        self._net = None
-        self._net_key = None
-        self._loaded_version = None
 
     def _conv_modules(self):
         return [getattr(self, n).convs for n in _CONVS] + [self.pred]

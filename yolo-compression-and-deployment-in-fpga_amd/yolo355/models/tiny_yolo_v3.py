@@ -6,6 +6,7 @@ module names / state_dict keys and eval-mode return, backed by the MI355X engine
     net.load_state_dict(torch.load(...)); net.eval()
     bboxes, scores, cls_inds = net(x)            # numpy, image 0, anchor order (stride 16 level first)
     all_images = net.forward_batch(x)            # new: every image of the batch
+    bboxes, scores, cls_inds = net(x, quantization=True)   # new: int8 engine (power-of-two PTQ)
 """
 import numpy as np
 import torch
@@ -39,9 +40,6 @@ class YOLOv3tiny(_NetModel):
         self.pred_2 = nn.Conv2d(512, self.anchor_number * (1 + 4 + self.num_classes), 1)
         self.conv_set_1 = Conv2d(384, 256, 3, padding=1, leakyReLU=True)
         self.pred_1 = nn.Conv2d(256, self.anchor_number * (1 + 4 + self.num_classes), 1)
-        self._net = None
-        self._net_key = None
-        self._loaded_version = None
 
     def _conv_modules(self):
         """weight slots of csrc/net.hip, forward order (tiny_yolo_v3.py:176-200)."""
@@ -50,6 +48,7 @@ class YOLOv3tiny(_NetModel):
                 bb.conv_6.convs, bb.conv_7.convs, self.conv_set_2.convs, self.conv_1x1_2.convs,
                 self.conv_set_1.convs, self.extra_conv_2.convs, self.pred_2, self.pred_1]
 
-    def forward(self, x, target=None):
-        """Eval-mode return of the reference (:224-243): detections of image 0."""
-        return self.forward_batch(x)[0]
+    def forward(self, x, target=None, quantization=False):
+        """Eval-mode return of the reference (:224-243): detections of image 0.  quantization=True is
+        this build's int8 form of the model (the reference has none): see _NetModel.forward_batch."""
+        return self.forward_batch(x, quantization=quantization)[0]

@@ -83,6 +83,30 @@ class Net:
         _ffi.check(self._lib.y355_net_load_layer_f32(self._h, idx, w.ctypes.data, None if bb is None else bb.ctypes.data,
                                                      w.shape[0], w.shape[1], w.shape[2]))
 
+    def load_layer_i8(self, idx, q_w, q_b, e_w, e_b):
+        """int8 nets: q_w [cout,cin,k,k] (|q| <= 127, value q / 2^e_w), q_b int32 [cout] (value q / 2^e_b)."""
+        if np.abs(np.asarray(q_w)).max() > 127:
+            raise ValueError("|q_w| > 127")
+        qw = np.ascontiguousarray(q_w, dtype=np.int8)
+        qb = np.ascontiguousarray(q_b, dtype=np.int32)
+        _ffi.check(self._lib.y355_net_load_layer_i8(self._h, idx, qw.ctypes.data, qb.ctypes.data, qw.shape[0], qw.shape[1],
+                                                    qw.shape[2], int(e_w), int(e_b)))
+
+    def set_act_exponents(self, sa_in, sa):
+        arr = (C.c_int32 * len(sa))(*[int(v) for v in sa])
+        _ffi.check(self._lib.y355_net_set_act_exponents(self._h, int(sa_in), arr, len(sa)))
+
+    def get_act_exponents(self):
+        sa_in = C.c_int32()
+        arr = (C.c_int32 * self.num_tensors)()
+        _ffi.check(self._lib.y355_net_get_act_exponents(self._h, C.byref(sa_in), arr, self.num_tensors))
+        return sa_in.value, list(arr)
+
+    def counters(self):
+        s = C.c_int64()
+        _ffi.check(self._lib.y355_net_counters(self._h, C.byref(s)))
+        return s.value
+
     def set_thresholds(self, conf_thresh, nms_thresh):
         _ffi.check(self._lib.y355_net_set_thresholds(self._h, float(conf_thresh), float(nms_thresh)))
 
@@ -140,6 +164,26 @@ class Net:
         m = C.c_float()
         _ffi.check(self._lib.y355_net_tensor_absmax(self._h, idx, batch, C.byref(m)))
         return float(m.value)
+
+    def calibration_exponents(self, x):
+        """bf16 nets: run x and return (sa_in, [sa per tensor]) = floor(log2(127 / max|.|)) of the network
+        input and of every activation tensor -- the AveragedRangeTracker first-call rule
+        (models/slim_yolo_v2.py:22-33) applied to this graph.  Feeds set_act_exponents of the int8 net
+        (which overrides the entries of max-pool outputs with their inputs' exponents)."""
+        from .prep import RangeTracker
+        xd = self._dev_input(x)
+        B = xd.shape[0]
+        self.forward_device(xd)
+        sa_in = RangeTracker().update(float(xd.abs().max().item()), True)
+        sa = []
+        for t in range(self.num_tensors):
+            c, hh, ww = self.tensor_shape(t)
+            if t >= self.num_tensors - (2 if self.arch == "tiny_yolo_v3" else 1):
+                m = float(np.abs(self.get_tensor(t, B)).max())       # fp32 prediction maps
+            else:
+                m = self.tensor_absmax(t, B)
+            sa.append(RangeTracker().update(m, True))
+        return sa_in, sa
 
     def sync(self):
         _ffi.check(self._lib.y355_net_sync(self._h))

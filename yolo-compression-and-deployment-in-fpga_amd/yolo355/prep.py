@@ -91,6 +91,17 @@ def quantize_layers(bitwidth=8, rescale=True, retune=False):
             layer.bias[...] = qb * r / sb if rescale else qb
 
 
+def quantize_folded(folded):
+    """[(W fp32, b fp32)] of BN-folded convs -> [{q_w, e_w, q_b, e_b}]: the per-tensor power-of-two
+    int8 recipe of quantize_layers (retune_bias_quantize.py:111-119) for the y355_net graphs."""
+    out = []
+    for w, b in folded:
+        qw, ew = to_int8_pow2(torch.as_tensor(w))
+        qb, eb = to_int8_pow2(torch.as_tensor(b))
+        out.append(dict(q_w=qw, e_w=ew, q_b=qb, e_b=eb))
+    return out
+
+
 class RangeTracker:
     """Host mirror of AveragedRangeTracker's state (models/slim_yolo_v2.py:9-38) driven by the
     max|activation| the GPU reports.  scale / first_a are the checkpoint buffers."""
