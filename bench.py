@@ -84,6 +84,76 @@ def cpu_baseline(n_images=256):
                        "oracle/yolo_oracle.c with OpenMP, %.1f s" % (n_images, dt))
 
 
+# conv MMAC per image of YOLOv3tiny at 416x416, 20 classes (3090.17), graph order
+TINY_MMAC = [74.760192, 199.360512, 199.360512, 199.360512, 199.360512, 199.360512, 797.442048, 398.721024,
+             5.537792, 598.081536, 199.360512, 6.4896, 12.9792]
+PEAK_BF16_DENSE = 2.5e15
+
+
+def bench_net(args):
+    """configs[2] (SlimYOLOv2 fp32 weights on bf16 MFMA, batch 64) and configs[3] (YOLOv3tiny int8 /
+    bf16, batch 128) through the table-driven executor; one GPU."""
+    from yolo355.netengine import Net
+    arch = "slim_yolo_v2" if args.workload == "slim_fp32" else "tiny_yolo_v3"
+    dtype = "int8" if args.workload == "tiny_int8" else "bf16"
+    classes = 2 if arch == "slim_yolo_v2" else 20
+    B = args.batch if args.batch != PER_GPU_BATCH or arch == "slim_yolo_v2" else 128
+    anchors = synth.ANCHOR_SIZE_MASK if arch == "slim_yolo_v2" else synth.TINY_MULTI_ANCHOR_SIZE
+    A = len(anchors) if arch == "slim_yolo_v2" else len(anchors) // 2
+    dev = torch.device("cuda", 0)
+    layers = synth.make_fp32_model(arch, 5, classes, A, pred_gain=1.5, obj_bias=-2.0)
+    folded = []
+    for L in layers:
+        w, b = L["w"].astype(np.float64), L["b"].astype(np.float64)
+        if L["bn"] is not None:
+            g, be, mu, var = (a.astype(np.float64) for a in L["bn"])
+            sc = g / np.sqrt(var + 1e-5)
+            w, b = w * sc[:, None, None, None], (b - mu) * sc + be
+        folded.append((w.astype(np.float32), b.astype(np.float32)))
+    fnet = Net(arch, [H, W], classes, anchors, 0.01, 0.5, max_batch=B, device=dev, dtype="bf16")
+    for i, (w, b) in enumerate(folded):
+        fnet.load_layer(i, w, b)
+    net = fnet
+    if dtype == "int8":
+        sa_in, sa = fnet.calibration_exponents(synth.make_images(1, 1, H, W))
+        net = Net(arch, [H, W], classes, anchors, 0.01, 0.5, max_batch=B, device=dev, dtype="int8")
+        for i, q in enumerate(prep.quantize_folded(folded)):
+            net.load_layer_i8(i, q["q_w"], q["q_b"], q["e_w"], q["e_b"])
+        net.set_act_exponents(sa_in, sa)
+    x = torch.from_numpy(synth.make_images(1000, B, H, W)).to(dev)
+    for _ in range(args.warmup):
+        net.forward_device(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net.forward_device(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    net.profile(True)
+    acc = None
+    for _ in range(5):
+        net.forward_device(x)
+        ms = np.array(net.profile_ms())
+        acc = ms if acc is None else acc + ms
+    ms = acc / 5
+    mmac = sum(LAYER_MMAC) if arch == "slim_yolo_v2" else sum(TINY_MMAC)
+    peak = PEAK_I8_DENSE if dtype == "int8" else PEAK_BF16_DENSE
+    op_ms = float(ms[:-2].sum())
+    achieved = B * 2e6 * mmac / (op_ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "images/sec %s %s 416x416" % (arch, "int8" if dtype == "int8" else "fp32 weights on bf16 MFMA"),
+        "value": round(B * args.steps / dt, 1), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": "%s %s, batch %d, 416x416, %d classes, conf 0.01" % (arch, dtype, B, classes),
+                   "detections_per_step": int(out[3][:B].sum().item())},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                     "frac": round(achieved * 1e12 / peak, 4), "traffic": None,
+                     "kernel": "convg_kernel, all conv launches of the graph (%.1f MMAC/image)" % mmac,
+                     "op_ms": [round(float(v), 4) for v in ms[:-2]], "head_ms": round(float(ms[-2]), 4),
+                     "nms_ms": round(float(ms[-1]), 4)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +161,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="slim_int8", choices=["slim_int8", "slim_fp32", "tiny_int8", "tiny_bf16"],
+                    help="slim_int8 = the headline metric (BASELINE.json configs[1]); the others time "
+                         "configs[2] / configs[3] through y355_net (single GPU, no cpu_baseline)")
     args = ap.parse_args()
+    if args.workload != "slim_int8":
+        return bench_net(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

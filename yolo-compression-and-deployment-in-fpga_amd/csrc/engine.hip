@@ -253,7 +253,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.tiny, sizeof(int) * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.ntiny, sizeof(int) * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.keepw, 8 * 64 * (size_t)B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.rmask, sizeof(unsigned long long) * 64 * cap * B, false);
+    if (!rc) rc = dmalloc(h, &h->ws.rmask, sizeof(unsigned int) * 8 * (size_t)B, true);      // class flags
     if (!rc) rc = dmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_cls, sizeof(int) * N * B, false);

@@ -49,6 +49,7 @@ struct HeadWork {
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
     int *ntiny;           // [B]
     unsigned long long *keepw;    // [B][64]       resolved survivors among the conflicted
+    unsigned int *clsflag;        // [B][8]        bit per class: has at least one suppressing pair
 };
 
 #define PRUNE_MARGIN 1.001f
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         wk.keepw[(size_t)b * 64 + tid] = 0ull;
     }
     if (tid < 2) wk.nedges[b * 2 + tid] = 0;
+    if (tid < 8) wk.clsflag[b * 8 + tid] = 0u;
     __syncthreads();
 
     float box[4][4], score[4];
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     int *sbin = (int *)(plds + NMS_CAP * 20);                        // [CAP + 8]
     unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 20 + (NMS_CAP + 8) * 4);   // [WG_EDGE_CAP]
     __shared__ unsigned long long sconf[64];
+    __shared__ unsigned int sclsf[8];
     __shared__ int nedge_s, gbase_s;
     const int b = blockIdx.y;
     const int M = wk.count[b];
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         for (int q = tid; q < M; q += 1024) { sbox[q] = cbx4[q]; scls[q] = ccl[q]; }
         for (int q = tid; q <= A * HW; q += 1024) sbin[q] = bs[q];
         if (tid < 64) sconf[tid] = 0ull;
+        if (tid < 8) sclsf[tid] = 0u;
         if (tid == 0) nedge_s = 0;
     }
     __syncthreads();
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
                 else lost = true;
                 atomicOr(&sconf[i >> 6], 1ull << (i & 63));
                 atomicOr(&sconf[q >> 6], 1ull << (q & 63));
+                atomicOr(&sclsf[(ci >> 5) & 7], 1u << (ci & 31));
             }
         }
     };
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         else wk.nedges[b * 2 + 1] = 1;
     }
     if (tid < 64 && sconf[tid]) atomicOr(&wk.confl[(size_t)b * 64 + tid], sconf[tid]);
+    if (tid < 8 && sclsf[tid]) atomicOr(&wk.clsflag[b * 8 + tid], sclsf[tid]);
 }
 #define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
 
@@ -387,6 +393,8 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, float 
     __shared__ int nconf_s;
     const int b = blockIdx.y, cls = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // nothing of this class conflicts (and no edge list overflowed): everything is kept by emit_kernel
+    if (wk.nedges[b * 2 + 1] == 0 && ((wk.clsflag[b * 8 + ((cls >> 5) & 7)] >> (cls & 31)) & 1u) == 0u) return;
     const int M = wk.count[b];
     const float *cs = wk.cscore + (size_t)b * NMS_CAP;
     const int *cc = wk.ccls + (size_t)b * NMS_CAP;
@@ -634,6 +642,7 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     wk.tiny = (int *)ws.tiny;
     wk.ntiny = (int *)ws.ntiny;
     wk.keepw = (unsigned long long *)ws.keepw;
+    wk.clsflag = (unsigned int *)ws.rmask;
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);
     hipLaunchKernelGGL(pairs_kernel, dim3(NMS_CAP / 1024, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
