@@ -152,6 +152,8 @@ int y355_profile(y355_engine *h, int enable);
 int y355_profile_get(y355_engine *h, float *ms /*[Y355_NUM_TIMERS]*/);
 /* diagnostic builds (-DY355_DIAG=1): arm / read the s_memtime stamps of one conv layer */
 int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *out_host, int nwg);
+/* diagnostics (env Y355_NMS_STAMPS=1): s_memtime stamps [4 kernels][256 workgroups][8 slots] of the head / NMS kernels */
+int y355_debug_nms_stamps(unsigned long long *out_host);
 
 /* ------------------------------------------------------------------------------------------
  * y355_net: the other model families of the path, table-driven (csrc/net.hip).

@@ -6,7 +6,7 @@
 //   * the input patch is cut into 64-channel chunks; a 2-slot LDS ring of chunks is filled by
 //     LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip and no
 //     staging VALU) one chunk ahead of the MFMAs -- across tile boundaries too;
-//   * weights come through a 3-slot LDS ring of k-steps (one tap of one chunk, BN/16 1-KiB
+//   * weights come through a 4-slot LDS ring of k-steps (one tap of one chunk, BN/16 1-KiB
 //     B fragments), also by LDS-DMA, two k-steps ahead; for the two thin layers (K = 144 / 288)
 //     the whole layer's fragments stay resident in LDS instead;
 //   * one raw s_barrier per k-step behind a COUNTED s_waitcnt vmcnt(N) (never 0 inside a tile
@@ -17,6 +17,7 @@
 // 2x2 pooling-window order (4 LDS cycles instead of 8).  The DMA applies the XOR on its SOURCE
 // address, the MFMA side on its read address (LDS-DMA destinations are lane-linear).
 #include "y355_common.h"
+#include <cstdlib>
 
 // -DY355_DIAG=1 builds the ablation switches (ConvParams.mode bits 8..) and the s_memtime
 // stamps into the kernel; the production build has neither (they fragment the k-step into
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
     constexpr int WB = (BN / 16) * 1024;                           // weight bytes per k-step
     constexpr int NFR = BN / 16;                                   // fragments per k-step
     constexpr int WPW = (NFR + NW - 1) / NW;                       // weight pieces per wave per k-step
-    constexpr int WSLOTS = WRES ? KS : 3;
+    constexpr int WSLOTS = WRES ? KS : 4;
     constexpr int OFF_W = 2 * SLABB;
     constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;                 // 1 KiB sink for padding pieces
     constexpr int OFF_STG = OFF_DUMMY + 1024;                      // int8 output tile, row-major
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
     constexpr int NIT = (OROWS * (BN / 16) + NTHR - 1) / NTHR;     // output stores per thread per tile (static)
     constexpr int cap63 = 63;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-    static_assert(WRES || (SPC % 3 == 0), "weight ring slot must be static per tap");
     static_assert(WRES ? NCH == 1 : true, "resident weights only for single-chunk layers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
     int b, y0, x0, nb;
     decode(tile, b, y0, x0, nb);
     int sl = 0;                                                // slab slot of the current chunk
+    int wq = 0;                                                // weight ring slot of the current k-step
     // ---- prologue
     issue_slab(b, y0, x0, 0, 0);
     if constexpr (WRES) {
@@ -250,32 +251,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
                 const bool fine = Y355_DIAG && p.stamps && (p.mode >> 16) && c == 1;
                 if (fine) stamp();
                 // vmcnt is in-order: "at most N younger operations may still fly".  Younger than the
-                // data of this step are: the weight pieces of the following step(s), a slab issued
-                // at t = 0, and -- at a tile's first steps -- the NIT output stores of the previous
+                // data of this step are: the weight pieces of the following step(s), a slab issued one
+                // step earlier, and -- at a tile's first steps -- the NIT output stores of the previous
                 // tile (always issued, see the copy-out), so finished tiles do not stall the ring.
-                if (c == 0 && t == 0) {
-                    if (first) { if constexpr (WRES) wait_vmcnt<0>(); else wait_vmcnt<WPW>(); }
-                    else wait_vmcnt<(NIT + (WRES ? 0 : WPW) < cap63 ? NIT + (WRES ? 0 : WPW) : cap63)>();
-                } else if constexpr (!WRES) {
-                    if (c == 0 && t == 1 && !first) wait_vmcnt<(NIT + PPW + WPW < cap63 ? NIT + PPW + WPW : cap63)>();
-                    else if (t == 1) wait_vmcnt<WPW + PPW>();   // W(t+1) and the slab issued at t=0 may fly
+                if constexpr (WRES) {
+                    if (c == 0 && t == 0) {
+                        if (first) wait_vmcnt<0>();
+                        else wait_vmcnt<(NIT < cap63 ? NIT : cap63)>();
+                    }
+                } else {
+                    if (c == 0 && t <= 1 && !first) wait_vmcnt<(NIT + WPW < cap63 ? NIT + WPW : cap63)>();
+                    else if (t == 2) wait_vmcnt<WPW + PPW>();   // W(t+1) and the slab issued at t=1 may fly
                     else wait_vmcnt<WPW>();
                 }
                 if (fine) stamp();
                 if (!WRES || t == 0) __builtin_amdgcn_s_barrier();
                 if (Y355_DIAG && (fine || (c == 0 && t == 0 && !(p.mode >> 16)))) stamp();
-                // -- refill the rings (after the barrier: the slots' last readers are done)
-                if (t == 0) {
+                // -- refill the rings.  WAR rule for LDS-DMA (cdna_hip_programming.md, "Read a staged
+                // buffer one phase AFTER..."): a slot may be restaged TWO barriers after its last
+                // ds_read was issued (every wave has then executed a whole phase, whose own lgkmcnt
+                // waits retire the older reads), or one barrier after when an lgkmcnt(0) sat in front of
+                // it.  The weight ring therefore has 4 slots (step s refills the slot read in step s-2)
+                // and the next slab is issued at t = 1 (its slot was last read at t = 8 of the previous
+                // chunk).  Resident-weight kernels have one barrier per tile, right after the epilogue's
+                // lgkmcnt(0) + barrier, so their slab goes out at t = 0.
+                if (t == (WRES ? 0 : 1)) {
                     if (!lastc) issue_slab(b, y0, x0, c + 1, sl ^ 1);
                     else issue_slab(b2, y2, x2, 0, sl ^ 1);
                 }
                 if constexpr (!WRES) {
                     const int ks2 = c * SPC + t + 2;
-                    if (ks2 < KS) issue_w(nb, ks2, (t + 2) % 3);
-                    else issue_w(nb2, ks2 - KS, (t + 2) % 3);
+                    if (ks2 < KS) issue_w(nb, ks2, (wq + 2) & 3);
+                    else issue_w(nb2, ks2 - KS, (wq + 2) & 3);
                 }
                 // -- MFMAs of this k-step
-                const char *wb = smem + OFF_W + (WRES ? t : (t % 3)) * WB + (wn * NT) * 1024 + lane * 16;
+                const char *wb = smem + OFF_W + (WRES ? t : wq) * WB + (wn * NT) * 1024 + lane * 16;
+                if constexpr (!WRES) wq = (wq + 1) & 3;
                 int ko;
                 if constexpr (CC < 64) ko = kofs[t];
                 else ko = (t / 3) * PWL * 64;                   // row offset of the tap; its column picks the base
@@ -382,10 +393,14 @@ struct ConvInst2 {
     static constexpr int WB = (BN / 16) * 1024;
     static constexpr int MTT = (TH * TW + 15) / 16;
     static constexpr int SROWS = POOL ? ((MTT + WM - 1) / WM) * WM * 4 : ((MTT + WM - 1) / WM) * WM * 16;
-    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(WRES ? G::KS : 3) * WB + 1024 + (size_t)SROWS * (BN + 16);
+    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(WRES ? G::KS : 4) * WB + 1024 + (size_t)SROWS * (BN + 16);
+    static size_t lds_launch() {
+        static const bool solo = getenv("Y355_V2_SOLO") != nullptr;       // experiment: one workgroup per CU
+        return (solo && LDS < 84 * 1024) ? 84 * 1024 : LDS;
+    }
     static int prepare() {
         return (int)hipFuncSetAttribute((const void *)conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch());
     }
     static bool launch(const ConvParams &p, hipStream_t s) {
         if (WRES && p.nblk != 1) return false;     // resident weights = one n-block
@@ -394,7 +409,7 @@ struct ConvInst2 {
         per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
         int grid = 256 * per_cu;
         if (grid > total) grid = total;
-        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
+        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>), dim3(grid), dim3(WM * WN * 64), lds_launch(), s, p, total);
         return true;
     }
 };

@@ -127,8 +127,17 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
 }
 }  // namespace
 
+struct GraphKey {
+    const void *x, *boxes, *scores, *cls, *count;
+    int batch, flags;
+    float conf, nms;
+};
+struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
+
 struct y355_engine {
     y355_config cfg{};
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     Layer L[10];
@@ -172,6 +181,8 @@ extern "C" void y355_destroy(y355_engine *h) {
     if (h->ev_ok)
         for (auto &e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
 }
 
@@ -416,7 +427,8 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         if (mode == 0) p.mode |= v2dbg << 8;
         static const int fine = getenv("Y355_STAMP_FINE") ? 1 : 0;
         if (mode == 0 && fine) p.mode |= 1 << 16;
-        if (no_v2 || !y355_launch_conv_v2(L.kid, p, h->stream))
+        static const int no_v2_mask = getenv("Y355_NO_V2_MASK") ? atoi(getenv("Y355_NO_V2_MASK")) : 0;
+        if (no_v2 || ((no_v2_mask >> k) & 1) || !y355_launch_conv_v2(L.kid, p, h->stream))
             ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
     }
     HIPCHK(hipGetLastError());
@@ -513,16 +525,11 @@ static HeadParams head_params(y355_engine *h, int sa_pred, float *ob, float *os,
     return p;
 }
 
-extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev,
-                            float *scores_dev, int32_t *cls_dev, int32_t *count_dev) {
-    if (!h || !x_dev || !boxes_dev || !scores_dev || !cls_dev || !count_dev) return fail(Y355_EINVAL, "null argument");
-    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
-    HIPCHK(hipSetDevice(h->cfg.device_id));
-    for (int k = 0; k < 10; ++k)
-        if (int rc = refresh_layer(h, k, true)) return rc;
+// enqueue one forward on `s` (refresh_layer must have run)
+static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
+                           int32_t *cls_dev, int32_t *count_dev, bool prof) {
     HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * 10, h->stream));
     const int guard = (flags & Y355_F_GUARD) ? 1 : 0;
-    const bool prof = h->profile != 0;
     for (int k = 0; k < 10; ++k) {
         if (prof) HIPCHK(hipEventRecord(h->ev[k], h->stream));
         if (int rc = launch_layer(h, k, batch, 0, guard, x_dev)) return rc;
@@ -533,6 +540,58 @@ extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int f
     y355_launch_head_nms(hp, batch, h->ws, h->stream, prof ? h->ev[11] : nullptr);
     HIPCHK(hipGetLastError());
     if (prof) HIPCHK(hipEventRecord(h->ev[12], h->stream));
+    return 0;
+}
+
+extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev,
+                            float *scores_dev, int32_t *cls_dev, int32_t *count_dev) {
+    if (!h || !x_dev || !boxes_dev || !scores_dev || !cls_dev || !count_dev) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    bool changed = false;
+    for (int k = 0; k < 10; ++k) {
+        changed = changed || h->L[k].bias_dirty;
+        if (int rc = refresh_layer(h, k, true)) return rc;
+    }
+    const bool prof = h->profile != 0;
+    static const bool use_graph = getenv("Y355_GRAPH") != nullptr;
+    if (!use_graph || prof) return enqueue_forward(h, x_dev, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, prof);
+    // ---- the 14 launches of a step replayed as one hipGraph (same pointers, batch, thresholds)
+    if (changed) {
+        for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+        h->graphs.clear();
+    }
+    GraphKey key{x_dev, boxes_dev, scores_dev, cls_dev, count_dev, batch, flags, h->cfg.conf_thresh, h->cfg.nms_thresh};
+    for (auto &g : h->graphs)
+        if (!memcmp(&g.key, &key, sizeof key)) {
+            HIPCHK(hipGraphLaunch(g.exec, h->stream));
+            return 0;
+        }
+    if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    hipStream_t user = h->stream;
+    h->stream = h->cap_stream;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+    int rc = 0;
+    if (e == hipSuccess) {
+        rc = enqueue_forward(h, x_dev, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, false);
+        e = hipStreamEndCapture(h->cap_stream, &graph);
+    }
+    h->stream = user;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(Y355_EHIP, std::string("graph capture: ") + hipGetErrorString(e));
+    GraphEntry ge{};
+    memset(&ge.key, 0, sizeof ge.key);
+    ge.key = key;
+    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(Y355_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    if (h->graphs.size() >= 8) {
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back(ge);
+    HIPCHK(hipGraphLaunch(ge.exec, h->stream));
     return 0;
 }
 
@@ -626,6 +685,15 @@ extern "C" int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *
     }
     h->stamp_layer = layer;
     HIPCHK(hipMemset(h->stamps_dev, 0, 8 * 32 * 1024));
+    return 0;
+}
+
+extern unsigned long long *y355_nms_stamps_dev;
+// diagnostics: s_memtime stamps of the head / pairs / resolve kernels of the last run (Y355_NMS_STAMPS=1)
+extern "C" int y355_debug_nms_stamps(unsigned long long *out_host) {
+    if (!out_host || !y355_nms_stamps_dev) return fail(Y355_ENOTREADY, "set Y355_NMS_STAMPS=1 before the first forward");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, y355_nms_stamps_dev, 8 * 8 * 256 * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

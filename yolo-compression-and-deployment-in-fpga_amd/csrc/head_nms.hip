@@ -34,6 +34,7 @@
 #define MAXA Y355_HEAD_MAXA
 #define EDGE_CAP (NMS_CAP * 64)   // edges per image the global list holds (the old bit-matrix footprint / 2)
 #define WG_EDGE_CAP 8192         // edges one pairs workgroup buffers in LDS
+#define HEAD_STAGE_BYTES 57344   // int8 prediction maps of one image staged by head_kernel (416x416: 43 KiB)
 
 struct HeadWork {
     float *cbox;          // [B][CAP][4]  compacted candidates, (anchor, bin) order
@@ -48,10 +49,15 @@ struct HeadWork {
     float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
     int *ntiny;           // [B]
-    unsigned long long *keepw;    // [B][64]       resolved survivors among the conflicted
-    unsigned int *clsflag;        // [B][8]        bit per class: has at least one suppressing pair
+    unsigned long long *stamps;   // diagnostics or null
 };
 
+// diagnostics (Y355_NMS_STAMPS=1): s_memtime at the phase boundaries of the first 256 workgroups
+#define NSTAMP(k, wg, slot)                                                                        \
+    do {                                                                                          \
+        if (wk.stamps && threadIdx.x == 0 && (wg) < 256)                                          \
+            wk.stamps[(((k) * 256 + (wg)) * 8) + (slot)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
 #define PRUNE_MARGIN 1.001f
 #define PRUNE_EPS 1e-6f
 #define AREA_MIN 1e-10f
@@ -63,13 +69,27 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     __shared__ int wsum[16];
     __shared__ unsigned int sstat[MAXA][4];
     __shared__ int ntiny_s;
+    // int8 prediction maps of the image, staged with coalesced 16-byte loads (the decode below reads
+    // ~10 scattered bytes per anchor: from global memory that is a chain of dependent misses)
+    __shared__ __attribute__((aligned(16))) int8_t spred[HEAD_STAGE_BYTES];
     const int b = blockIdx.x, tid = threadIdx.x;
+    NSTAMP(0, blockIdx.x, 0);
     const int A = p.A, C = p.C;
     const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
     const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0;
     const int N = N0 + HW1 * A;
     const int HWb = p.Hb * p.Wb;
     for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
+    const int lb0 = HW0 * p.lev[0].cstride, lb1 = HW1 * (p.nlev > 1 ? p.lev[1].cstride : 0);
+    const bool staged = p.lev[0].pred != nullptr && lb0 + lb1 <= HEAD_STAGE_BYTES;
+    if (staged) {
+        const v4i *s0 = (const v4i *)(p.lev[0].pred + (size_t)b * lb0);
+        for (int i = tid; i < lb0 / 16; i += 1024) ((v4i *)spred)[i] = s0[i];
+        if (lb1) {
+            const v4i *s1 = (const v4i *)(p.lev[1].pred + (size_t)b * lb1);
+            for (int i = tid; i < lb1 / 16; i += 1024) ((v4i *)(spred + lb0))[i] = s1[i];
+        }
+    }
     if (tid < MAXA) {
         sstat[tid][0] = 0u;                 // wmax
         sstat[tid][1] = 0u;                 // hmax
@@ -79,11 +99,10 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     if (tid == 0) ntiny_s = 0;
     if (tid < 64) {
         wk.confl[(size_t)b * 64 + tid] = 0ull;
-        wk.keepw[(size_t)b * 64 + tid] = 0ull;
     }
     if (tid < 2) wk.nedges[b * 2 + tid] = 0;
-    if (tid < 8) wk.clsflag[b * 8 + tid] = 0u;
     __syncthreads();
+    NSTAMP(0, blockIdx.x, 1);
 
     float box[4][4], score[4];
     int cls[4], orig[4], key[4], rk[4];
@@ -106,7 +125,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             const int kt = lv * A + a;                 // anchor type: own bins and extents
             const int gy = cell / L.Ws, gx = cell % L.Ws;
             const size_t po = ((size_t)(b * L.Hs + gy) * L.Ws + gx) * L.cstride;
-            const int8_t *pq = L.pred ? L.pred + po : nullptr;
+            const int8_t *pq = staged ? spred + lv * lb0 + (gy * L.Ws + gx) * L.cstride : (L.pred ? L.pred + po : nullptr);
             const float *pf = L.pred_f + po;
             const float dq = L.dq;
             auto ld = [&](int c) -> float { return pq ? (float)pq[c] * dq : pf[c]; };
@@ -159,6 +178,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         }
     }
     __syncthreads();
+    NSTAMP(0, blockIdx.x, 2);
     // ---- exclusive scan of the bin counts: 4 consecutive bins per thread
     const int lane = tid & 63, wave = tid >> 6;
     int c4[4], mine = 0;
@@ -175,12 +195,14 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
+    NSTAMP(0, blockIdx.x, 3);
     if (tid == 0) {
         int s = 0;
         for (int w = 0; w < 16; ++w) { const int t = wsum[w]; wsum[w] = s; s += t; }
         wk.count[b] = s;
     }
     __syncthreads();
+    NSTAMP(0, blockIdx.x, 4);
     int run = wsum[wave] + incl - mine;
     int *bs = wk.binstart + (size_t)b * (NMS_CAP + 8);
 #pragma unroll
@@ -191,6 +213,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     }
     if (tid == 1023) bs[NMS_CAP] = run;
     __syncthreads();
+    NSTAMP(0, blockIdx.x, 5);
     // ---- scatter into (anchor, bin) order
     float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
     float *cs = wk.cscore + (size_t)b * NMS_CAP;
@@ -214,7 +237,9 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         for (int k = 0; k < 4; ++k) as[k] = __uint_as_float(sstat[tid][k]);
     }
     __syncthreads();
+    NSTAMP(0, blockIdx.x, 6);
     if (tid == 0) wk.ntiny[b] = ntiny_s;
+    NSTAMP(0, blockIdx.x, 7);
 }
 
 // ---- the reference's suppression test (slim_yolo_v2.py:159-171), same class assumed
@@ -262,11 +287,11 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     int *sbin = (int *)(plds + NMS_CAP * 20);                        // [CAP + 8]
     unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 20 + (NMS_CAP + 8) * 4);   // [WG_EDGE_CAP]
     __shared__ unsigned long long sconf[64];
-    __shared__ unsigned int sclsf[8];
     __shared__ int nedge_s, gbase_s;
     const int b = blockIdx.y;
+    NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 0);
     const int M = wk.count[b];
-    if ((int)blockIdx.x * 1024 >= M) return;
+    if ((int)blockIdx.x * 64 >= M) return;
     const int tid = threadIdx.x;
     const int A = p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // anchor types, bin grid
     const int N0 = p.lev[0].Hs * p.lev[0].Ws * p.A;
@@ -277,11 +302,14 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         for (int q = tid; q < M; q += 1024) { sbox[q] = cbx4[q]; scls[q] = ccl[q]; }
         for (int q = tid; q <= A * HW; q += 1024) sbin[q] = bs[q];
         if (tid < 64) sconf[tid] = 0ull;
-        if (tid < 8) sclsf[tid] = 0u;
         if (tid == 0) nedge_s = 0;
     }
     __syncthreads();
-    const int i = blockIdx.x * 1024 + tid;
+    NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 1);
+    // 64-candidate runs are dealt round-robin to the image's workgroups: neighbours in (anchor, bin)
+    // order have windows of similar size, so a wave stays uniform while every workgroup gets the same
+    // mix of cheap and expensive waves
+    const int i = (((tid >> 6) * (int)gridDim.x + (int)blockIdx.x) << 6) + (tid & 63);
     const bool vi = i < M;
     const bool fast = thr >= 1e-4f && thr < 1e4f;
     const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
@@ -314,12 +342,17 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
             if (fast && den > 1e-30f && den < 1e30f && (qv > q_hi || qv < q_lo)) s = qv > q_hi;
             else s = !(inter / den <= thr);
             if (s) {
+                const unsigned int ed = ((unsigned int)i << 12) | (unsigned int)q;
                 const int e = atomicAdd(&nedge_s, 1);
-                if (e < WG_EDGE_CAP) sedge[e] = ((unsigned int)i << 12) | (unsigned int)q;
-                else lost = true;
+                if (e < WG_EDGE_CAP) {
+                    sedge[e] = ed;
+                } else {                                 // LDS buffer full: straight to the image's list
+                    const int g = atomicAdd(&wk.nedges[b * 2], 1);
+                    if (g < EDGE_CAP) wk.edges[(size_t)b * EDGE_CAP + g] = ed;
+                    else lost = true;
+                }
                 atomicOr(&sconf[i >> 6], 1ull << (i & 63));
                 atomicOr(&sconf[q >> 6], 1ull << (q & 63));
-                atomicOr(&sclsf[(ci >> 5) & 7], 1u << (ci & 31));
             }
         }
     };
@@ -354,6 +387,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         }
     }
     __syncthreads();
+    NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 2);
     const int ne = min(nedge_s, WG_EDGE_CAP);
     if (tid == 0) {
         gbase_s = atomicAdd(&wk.nedges[b * 2], ne);
@@ -361,6 +395,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     }
     if (lost) wk.nedges[b * 2 + 1] = 1;
     __syncthreads();
+    NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 3);
     const int gb = gbase_s;
     unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
     for (int e = tid; e < ne; e += 1024) {
@@ -368,65 +403,105 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         else wk.nedges[b * 2 + 1] = 1;
     }
     if (tid < 64 && sconf[tid]) atomicOr(&wk.confl[(size_t)b * 64 + tid], sconf[tid]);
-    if (tid < 8 && sclsf[tid]) atomicOr(&wk.clsflag[b * 8 + tid], sclsf[tid]);
+    NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 7);
 }
 #define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
 
-// ---- resolve_kernel: grid (classes, batch), one workgroup per (image, class).
-// Conflicts only exist inside a class, so every class is an independent greedy walk.  The
-// class's conflicted candidates are sorted by (score desc, anchor index asc) and every one
-// gets the list of its conflicting candidates that come EARLIER in that order (u16 ranks in
-// LDS).  The walk takes 64 ranks per step, one per lane: a lane is suppressed if one of its
-// earlier neighbours from a previous step was kept (parallel check against the kept bit-set);
-// neighbours inside the same step are settled by a scalar find-first-set loop over the few
-// lanes that have any.
-#define RES_EDGE_CAP 36864          // earlier-neighbour edges kept in LDS (u16 ranks, 72 KiB)
+// ---- resolve_emit_kernel: one workgroup per image.
+// Greedy NMS = for every candidate, "kept unless an EARLIER (score desc, anchor index asc) kept
+// candidate suppresses it".  With the suppressing pairs known, that is settled without sorting, by
+// rounds over the edge list held in LDS (each thread owns a strided set of slots and compacts it in
+// place):
+//   A  for every live edge (a earlier -> b): a kept -> b is dead, edge retires; a dead -> edge
+//      retires; a undecided -> b is blocked this round;
+//   B  every undecided candidate that is neither dead nor blocked is kept.
+// A candidate is decided one round after its last earlier neighbour, so the number of rounds is the
+// longest chain of alternating decisions (16-17 on the benchmark's images), each a few hundred
+// cycles.  Classes need no special handling: edges only join candidates of one class.
+// Survivors are then written in anchor-index order into the padded outputs.
+// Fallback (an edge list overflowed, or more edges than the LDS list holds): the textbook walk over
+// the candidates sorted by score, with the reference's predicate evaluated on the fly.
+#define LDS_EDGE_CAP 28672          // edges of one image held in LDS (112 KiB)
 
-__global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, float thr) {
-    __shared__ unsigned long long keys[NMS_CAP];      // gathered, then sorted
-    __shared__ unsigned short rank_of[NMS_CAP];
-    __shared__ int eoff[NMS_CAP + 1];                 // per rank: start of its earlier-neighbour list
-    __shared__ int efill[NMS_CAP];                    // per rank: count, then insertion cursor
-    __shared__ unsigned short edges[RES_EDGE_CAP];
-    __shared__ unsigned long long keptw[64];          // kept ranks, 64 per word
-    __shared__ int wsum[16];
-    __shared__ int nconf_s;
-    const int b = blockIdx.y, cls = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // nothing of this class conflicts (and no edge list overflowed): everything is kept by emit_kernel
-    if (wk.nedges[b * 2 + 1] == 0 && ((wk.clsflag[b * 8 + ((cls >> 5) & 7)] >> (cls & 31)) & 1u) == 0u) return;
+__global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, const HeadWork wk, float thr) {
+    __shared__ __attribute__((aligned(16))) unsigned int sedge[LDS_EDGE_CAP];   // (early << 12) | late
+    __shared__ unsigned char state[NMS_CAP];          // 0 undecided, 1 kept, 2 dead
+    __shared__ unsigned char blocked[NMS_CAP];
+    __shared__ unsigned long long keepn[64];          // survivors by anchor index
+    __shared__ int wbase[64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    NSTAMP(2, blockIdx.x, 0);
     const int M = wk.count[b];
+    const float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
     const float *cs = wk.cscore + (size_t)b * NMS_CAP;
     const int *cc = wk.ccls + (size_t)b * NMS_CAP;
     const int *co = wk.corig + (size_t)b * NMS_CAP;
     const unsigned long long *cf = wk.confl + (size_t)b * 64;
-    const int ne_img = min(wk.nedges[b * 2], EDGE_CAP);
-    const bool lossy = wk.nedges[b * 2 + 1] != 0;     // some edge list overflowed: brute-force path
+    const int ne = wk.nedges[b * 2];
+    const bool brute = wk.nedges[b * 2 + 1] != 0 || ne > LDS_EDGE_CAP;
     const unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
-    if (tid == 0) nconf_s = 0;
-    if (tid < 64) keptw[tid] = 0ull;
-    for (int i = tid; i < NMS_CAP; i += 1024) efill[i] = 0;
-    __syncthreads();
-    for (int pos = tid; pos < M; pos += 1024) {
-        const bool conflicted = lossy || ((cf[pos >> 6] >> (pos & 63)) & 1ull);
-        if (conflicted && cc[pos] == cls) {
-            const int k = atomicAdd(&nconf_s, 1);
-            keys[k] = ((unsigned long long)(~__float_as_uint(cs[pos])) << 32) |
-                      ((unsigned long long)(unsigned int)co[pos] << 12) | (unsigned int)pos;
+    for (int pos = tid; pos < NMS_CAP; pos += 1024) {
+        const bool conflicted = pos < M && (brute || ((cf[pos >> 6] >> (pos & 63)) & 1ull));
+        state[pos] = conflicted ? 0 : 1;
+        blocked[pos] = 0;
+    }
+    if (tid < 64) keepn[tid] = 0ull;
+    int mine = 0;                                     // live edges in my slots tid, tid + 1024, ...
+    if (!brute) {
+        // orient every pair by the NMS order
+        for (int e = tid; e < ne; e += 1024) {
+            const unsigned int pq = ge[e];
+            const int i = (int)(pq >> 12), q = (int)(pq & 0xfffu);
+            const float si = cs[i], sq = cs[q];
+            const bool i_first = si > sq || (si == sq && co[i] < co[q]);
+            sedge[tid + mine * 1024] = i_first ? pq : (((unsigned int)q << 12) | (unsigned int)i);
+            ++mine;
         }
     }
     __syncthreads();
-    const int nconf = nconf_s;
-    if (nconf == 0) return;
-    // ---- sort by (score desc, anchor index asc)
-    {
-        int P2 = 1;
-        while (P2 < nconf) P2 <<= 1;
-        for (int i = nconf + tid; i < P2; i += 1024) keys[i] = ~0ull;
+    NSTAMP(2, blockIdx.x, 1);
+    if (!brute) {
+        for (;;) {
+            int n2 = 0;
+            for (int k0 = 0; k0 < mine; k0 += 4) {                  // 4 edges per trip: the LDS reads overlap
+                unsigned int ed[4];
+                int sa[4], sc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ed[u] = sedge[tid + min(k0 + u, mine - 1) * 1024];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { sa[u] = state[ed[u] >> 12]; sc[u] = state[ed[u] & 0xfffu]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u >= mine || sc[u] == 2 || sa[u] == 2) continue;
+                    const int c = (int)(ed[u] & 0xfffu);
+                    if (sa[u] == 1) { state[c] = 2; continue; }
+                    blocked[c] = 1;
+                    sedge[tid + n2 * 1024] = ed[u];
+                    ++n2;
+                }
+            }
+            mine = n2;
+            __syncthreads();
+            int pending = 0;
+            for (int pos = tid; pos < M; pos += 1024) {
+                if (state[pos] == 0) {
+                    if (!blocked[pos]) state[pos] = 1;
+                    else { blocked[pos] = 0; pending = 1; }
+                }
+            }
+            if (!__syncthreads_or(pending)) break;
+        }
+    } else {
+        // ---- fallback: sort all candidates by (score desc, anchor index asc), walk them one at a time
+        unsigned long long *keys = (unsigned long long *)sedge;       // [NMS_CAP]
+        for (int i = tid; i < NMS_CAP; i += 1024)
+            keys[i] = i < M ? (((unsigned long long)(~__float_as_uint(cs[i])) << 32) | ((unsigned long long)(unsigned int)co[i] << 12) |
+                               (unsigned int)i)
+                            : ~0ull;
         __syncthreads();
-        for (int k = 2; k <= P2; k <<= 1) {
+        for (int k = 2; k <= NMS_CAP; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P2; i += 1024) {
+                for (int i = tid; i < NMS_CAP; i += 1024) {
                     const int ixj = i ^ j;
                     if (ixj > i) {
                         const unsigned long long x = keys[i], y = keys[ixj];
@@ -437,158 +512,30 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const HeadWork wk, float 
                 __syncthreads();
             }
         }
-    }
-    const float *cbx = wk.cbox + (size_t)b * NMS_CAP * 4;
-    if (lossy) {
-        // ---- fallback (an edge list overflowed): the textbook walk, one kept candidate at a time
-        __shared__ unsigned char dead[NMS_CAP];
-        for (int r = tid; r < nconf; r += 1024) dead[r] = 0;
-        __syncthreads();
-        for (int r = 0; r < nconf; ++r) {
-            if (dead[r]) continue;                                  // uniform: read after the barrier below
+        for (int r = 0; r < M; ++r) {
             const int pi = (int)(keys[r] & 0xfffu);
-            if (tid == 0) atomicOr(&wk.keepw[(size_t)b * 64 + (pi >> 6)], 1ull << (pi & 63));
-            const float4 bi = *(const float4 *)(cbx + (size_t)pi * 4);
+            if (state[pi] == 2) continue;                           // uniform: written before the last barrier
+            const float4 bi = *(const float4 *)(cb + (size_t)pi * 4);
             const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-            for (int r2 = r + 1 + tid; r2 < nconf; r2 += 1024) {
-                if (!dead[r2]) {
-                    const int pj = (int)(keys[r2] & 0xfffu);
-                    const float4 bj = *(const float4 *)(cbx + (size_t)pj * 4);
+            const int ci = cc[pi];
+            for (int r2 = r + 1 + tid; r2 < M; r2 += 1024) {
+                const int pj = (int)(keys[r2] & 0xfffu);
+                if (state[pj] != 2 && cc[pj] == ci) {
+                    const float4 bj = *(const float4 *)(cb + (size_t)pj * 4);
                     const float aj = (bj.z - bj.x) * (bj.w - bj.y);
-                    if (suppresses_exact(bi, ai, bj, aj, thr)) dead[r2] = 1;
+                    if (suppresses_exact(bi, ai, bj, aj, thr)) state[pj] = 2;
                 }
             }
             __syncthreads();
         }
-        return;
-    }
-    for (int r = tid; r < nconf; r += 1024) rank_of[(int)(keys[r] & 0xfffu)] = (unsigned short)r;
-    __syncthreads();
-    // ---- per rank: the conflicting candidates that come EARLIER in the order (CSR in LDS)
-    for (int e = tid; e < ne_img; e += 1024) {
-        const unsigned int pq = ge[e];
-        const int pi = (int)(pq >> 12), pj = (int)(pq & 0xfffu);
-        if (cc[pi] == cls) {
-            const int ri = rank_of[pi], rj = rank_of[pj];
-            atomicAdd(&efill[max(ri, rj)], 1);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the counts in rank order (rank = tid + t*1024: scan per t, chained)
-    constexpr int RPT = NMS_CAP / 1024;
-    int base = 0;
-#pragma unroll 1
-    for (int t = 0; t < RPT; ++t) {
-        const int r = tid + t * 1024;
-        const int c = r < nconf ? efill[r] : 0;
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int wb = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; if (w < wave) wb += v; tot += v; }
-        if (r < nconf) { eoff[r] = base + wb + incl - c; efill[r] = base + wb + incl - c; }
-        base += tot;
+        for (int pos = tid; pos < M; pos += 1024)
+            if (state[pos] == 0) state[pos] = 1;
         __syncthreads();
     }
-    if (tid == 0) eoff[nconf] = base;
-    const bool big = base > RES_EDGE_CAP;               // same value in every thread
-    if (!big) {
-        for (int e = tid; e < ne_img; e += 1024) {
-            const unsigned int pq = ge[e];
-            const int pi = (int)(pq >> 12), pj = (int)(pq & 0xfffu);
-            if (cc[pi] == cls) {
-                const int ri = rank_of[pi], rj = rank_of[pj];
-                edges[atomicAdd(&efill[max(ri, rj)], 1)] = (unsigned short)min(ri, rj);
-            }
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    // ---- ordered walk, 64 ranks per step.  sup: an earlier neighbour of an earlier step is kept;
-    //      own: earlier neighbours inside this step, settled by the scalar loop
-    const int nblk = (nconf + 63) >> 6;
-    for (int k = 0; k < nblk; ++k) {
-        const int r = k * 64 + lane;
-        const bool v = r < nconf;
-        const int pos = v ? (int)(keys[r] & 0xfffu) : 0;
-        bool sup = false;
-        unsigned long long own = 0ull;
-        if (!big) {
-            const int e0 = v ? eoff[r] : 0, e1 = v ? eoff[r + 1] : 0;
-            for (int e = e0; e < e1; e += 4) {          // 4 edges per trip: the LDS reads overlap
-                int rq[4];
-                unsigned long long kw[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rq[u] = edges[min(e + u, RES_EDGE_CAP - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) kw[u] = keptw[(rq[u] >> 6) & 63];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (e + u < e1) {
-                        const unsigned long long bit = 1ull << (rq[u] & 63);
-                        if ((rq[u] >> 6) < k) sup = sup || (kw[u] & bit) != 0ull;
-                        else own |= bit;
-                    }
-                }
-            }
-        } else {
-            // more earlier-neighbour edges than LDS holds: scan the image's edge list (slow, exact)
-            for (int e = 0; e < ne_img; ++e) {
-                const unsigned int pq = ge[e];
-                const int pi = (int)(pq >> 12), pj = (int)(pq & 0xfffu);
-                if (v && (pi == pos || pj == pos)) {
-                    const int rq = rank_of[pi == pos ? pj : pi];
-                    if (rq < r) {
-                        const unsigned long long bit = 1ull << (rq & 63);
-                        if ((rq >> 6) < k) sup = sup || (keptw[rq >> 6] & bit) != 0ull;
-                        else own |= bit;
-                    }
-                }
-            }
-        }
-        const unsigned long long alive = __ballot(v && !sup);
-        unsigned long long keptk = __ballot(v && !sup && own == 0ull);
-        unsigned long long hard = alive & ~keptk;
-        while (hard) {
-            const int u = __ffsll((long long)hard) - 1;
-            hard &= hard - 1;
-            const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)own, u);
-            const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(own >> 32), u);
-            if (((((unsigned long long)hi << 32) | lo) & keptk) == 0ull) keptk |= 1ull << u;
-        }
-        if (lane == 0) keptw[k] = keptk;
-        __builtin_amdgcn_wave_barrier();
-        if (v && ((keptk >> lane) & 1ull)) atomicOr(&wk.keepw[(size_t)b * 64 + (pos >> 6)], 1ull << (pos & 63));
-    }
-}
-
-// ---- emit_kernel: one workgroup per image: survivors = conflict-free candidates + resolved
-// ones, written in anchor-index order into the padded outputs.
-__global__ __launch_bounds__(1024) void emit_kernel(const HeadParams p, const HeadWork wk) {
-    __shared__ unsigned long long keepw[64];        // by compact position
-    __shared__ unsigned long long keepn[64];        // by anchor index
-    __shared__ int wbase[64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int M = wk.count[b];
-    const int nw = (M + 63) >> 6;
-    const float *cb = wk.cbox + (size_t)b * NMS_CAP * 4;
-    const float *cs = wk.cscore + (size_t)b * NMS_CAP;
-    const int *cc = wk.ccls + (size_t)b * NMS_CAP;
-    const int *co = wk.corig + (size_t)b * NMS_CAP;
-    if (tid < 64) {
-        const unsigned long long vm = tid < nw ? ((tid == nw - 1 && (M & 63)) ? ((1ull << (M & 63)) - 1ull) : ~0ull) : 0ull;
-        const unsigned long long cf = tid < nw ? wk.confl[(size_t)b * 64 + tid] : 0ull;
-        keepw[tid] = (vm & ~cf) | (wk.keepw[(size_t)b * 64 + tid] & cf & vm);
-        keepn[tid] = 0ull;
-    }
-    __syncthreads();
+    NSTAMP(2, blockIdx.x, 2);
+    // ---- emit: survivors in anchor-index order
     for (int pos = tid; pos < M; pos += 1024) {
-        if ((keepw[pos >> 6] >> (pos & 63)) & 1ull) {
+        if (state[pos] == 1) {
             const int n = co[pos];
             atomicOr(&keepn[n >> 6], 1ull << (n & 63));
         }
@@ -610,7 +557,7 @@ __global__ __launch_bounds__(1024) void emit_kernel(const HeadParams p, const He
     float *os = p.out_score + (size_t)b * p.max_det;
     int *oc = p.out_cls + (size_t)b * p.max_det;
     for (int pos = tid; pos < M; pos += 1024) {
-        if ((keepw[pos >> 6] >> (pos & 63)) & 1ull) {
+        if (state[pos] == 1) {
             const int n = co[pos];
             const unsigned long long bits = keepn[n >> 6];
             const int dst = wbase[n >> 6] + __popcll(bits & ((1ull << (n & 63)) - 1ull));
@@ -621,7 +568,10 @@ __global__ __launch_bounds__(1024) void emit_kernel(const HeadParams p, const He
             }
         }
     }
+    NSTAMP(2, blockIdx.x, 7);
 }
+
+unsigned long long *y355_nms_stamps_dev = nullptr;
 
 int y355_prepare_head(void) {
     return (int)hipFuncSetAttribute((const void *)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
@@ -641,11 +591,16 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     wk.astat = (float *)ws.astat;
     wk.tiny = (int *)ws.tiny;
     wk.ntiny = (int *)ws.ntiny;
-    wk.keepw = (unsigned long long *)ws.keepw;
-    wk.clsflag = (unsigned int *)ws.rmask;
+    static unsigned long long *g_stamps = nullptr;
+    static const bool want = getenv("Y355_NMS_STAMPS") != nullptr;
+    if (want && !g_stamps) {
+        if (hipMalloc((void **)&g_stamps, 8 * 8 * 256 * 4) != hipSuccess) g_stamps = nullptr;
+        else (void)hipMemset(g_stamps, 0, 8 * 8 * 256 * 4);
+    }
+    wk.stamps = g_stamps;
+    y355_nms_stamps_dev = g_stamps;
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);
     hipLaunchKernelGGL(pairs_kernel, dim3(NMS_CAP / 1024, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
-    hipLaunchKernelGGL(resolve_kernel, dim3(p.C, batch), dim3(1024), 0, s, wk, p.nms_thresh);
-    hipLaunchKernelGGL(emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
+    hipLaunchKernelGGL(resolve_emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk, p.nms_thresh);
 }

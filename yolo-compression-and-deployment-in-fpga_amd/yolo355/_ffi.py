@@ -80,6 +80,7 @@ _SIGS = {
     "y355_conv3x3_i8_raw": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, P(C.c_int32)]),
     "y355_debug_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "y355_debug_nms_stamps": (C.c_int, [C.c_void_p]),
     "y355_head_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y355_sync": (C.c_int, [C.c_void_p]),
     "y355_profile": (C.c_int, [C.c_void_p, C.c_int]),
