@@ -220,3 +220,49 @@ def test_full_batch_properties():
         for a, b in zip(d16[i], dets[i]):
             assert np.array_equal(a, b)
     eng.close()
+
+
+def test_two_engines_concurrent():
+    """Two engine handles on two HIP streams, forwards interleaved (bench.py's configuration): every
+    result must equal the handle's stand-alone result.  Regression test for the LDS-DMA restage hazard
+    of the production conv kernel, which only showed under memory contention from the other stream
+    (rare wrong tiles of the prediction layer)."""
+    import torch
+    B = 64
+    dev = torch.device("cuda", 0)
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    engs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            e = Engine([416, 416], 2, synth.ANCHOR_SIZE_MASK, max_batch=B, device=dev)
+            e.load_quantized(ql)
+        engs.append(e)
+    sa = engs[0].calibrate(synth.make_images(1, 1, 416, 416), [RangeTracker() for _ in range(11)])
+    for e in engs:
+        e.set_act_exponents(sa)
+    x = torch.from_numpy(synth.make_images(1000, B, 416, 416)).to(dev)
+    # zero-filled outputs: entries past count[b] are never written, so whole tensors compare equal
+    bufs = [tuple(torch.zeros_like(t) for t in engs[0]._buffers(B)) for _ in range(3)]
+    torch.cuda.synchronize()
+
+    def same(a, b):
+        return all(torch.equal(u, v) for u, v in zip(a, b))
+    engs[0].forward_device(x, 0, bufs[0])
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in bufs[0]]
+    pred_ref = engs[0].get_feature(9, B).copy()
+    assert int(ref[3].sum()) > 0
+    engs[1].forward_device(x, 0, bufs[1])
+    torch.cuda.synchronize()
+    assert same(ref, bufs[1])
+    for it in range(300):
+        engs[0].forward_device(x, 0, bufs[0])
+        engs[1].forward_device(x, 0, bufs[1])
+        engs[0].forward_device(x, 0, bufs[2])
+        torch.cuda.synchronize()
+        if not (same(ref, bufs[1]) and same(ref, bufs[2])):
+            diff = int((engs[1].get_feature(9, B) != pred_ref).sum())
+            raise AssertionError("iteration %d: concurrent result differs (%d prediction values)" % (it, diff))
+    for e in engs:
+        e.close()

@@ -263,6 +263,9 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.tiny, sizeof(int) * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.ntiny, sizeof(int) * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.dbox, sizeof(float) * 4 * cap * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.dscore, sizeof(float) * cap * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.dcls, sizeof(int) * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.keepw, 8 * 64 * (size_t)B, true);
     if (!rc) rc = dmalloc(h, &h->ws.rmask, sizeof(unsigned int) * 8 * (size_t)B, true);      // class flags
     if (!rc) rc = dmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);

@@ -13,7 +13,8 @@
 //
 // Greedy NMS is a walk over the "i suppresses j" relation in score order.  The relation is
 // sparse (a box only interacts with boxes of similar size whose centre is close), so:
-//   head_kernel  one workgroup per image: decode, threshold, and counting-sort the candidates
+//   decode_kernel one thread per anchor: grid/anchor decode, sigmoid / softmax score, best class;
+//   head_kernel  one workgroup per image: threshold and counting-sort the candidates
 //                into (anchor, centre-bin) order -- bins are the Hs x Ws grid over the CLAMPED
 //                box centres -- plus per-anchor extents (max w/h, min/max area);
 //   pairs_kernel one thread per candidate walks only the bins a suppressor can sit in
@@ -34,7 +35,6 @@
 #define MAXA Y355_HEAD_MAXA
 #define EDGE_CAP (NMS_CAP * 64)   // edges per image the global list holds (the old bit-matrix footprint / 2)
 #define WG_EDGE_CAP 8192         // edges one pairs workgroup buffers in LDS
-#define HEAD_STAGE_BYTES 57344   // int8 prediction maps of one image staged by head_kernel (416x416: 43 KiB)
 
 struct HeadWork {
     float *cbox;          // [B][CAP][4]  compacted candidates, (anchor, bin) order
@@ -49,6 +49,9 @@ struct HeadWork {
     float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
     int *ntiny;           // [B]
+    float *dbox;          // [B][CAP][4]  decode of every anchor, (level, anchor, cell) order
+    float *dscore;        // [B][CAP]
+    int *dcls;            // [B][CAP]
     unsigned long long *stamps;   // diagnostics or null
 };
 
@@ -64,32 +67,76 @@ struct HeadWork {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- decode_kernel: grid (ceil(N / 256), batch), one anchor per thread, in the (level, anchor, cell)
+// enumeration the sort below consumes.  The decode is ~500 VALU instructions per anchor (9 expf, ~14
+// IEEE divisions): spread over every CU instead of the 64 workgroups of the per-image sort.
+__global__ __launch_bounds__(256) void decode_kernel(const HeadParams p, const HeadWork wk) {
+    const int b = blockIdx.y;
+    const int np = blockIdx.x * 256 + threadIdx.x;
+    const int A = p.A, C = p.C;
+    const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
+    const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0;
+    const int N = N0 + HW1 * A;
+    if (np >= N) return;
+    const int lv = np >= N0 ? 1 : 0;
+    const HeadLevel &L = p.lev[lv];
+    const int npl = np - lv * N0, HWl = lv ? HW1 : HW0;
+    const int a = npl / HWl, cell = npl % HWl;
+    const int n = lv * N0 + cell * A + a;      // the reference's anchor index (:337-341)
+    const int gy = cell / L.Ws, gx = cell % L.Ws;
+    const size_t po = ((size_t)(b * L.Hs + gy) * L.Ws + gx) * L.cstride;
+    const int8_t *pq = L.pred ? L.pred + po : nullptr;
+    const float *pf = L.pred_f + po;
+    const float dq = L.dq;
+    auto ld = [&](int c) -> float { return pq ? (float)pq[c] * dq : pf[c]; };
+    const float conf = ld(a);
+    const float obj = sigmoidf_(conf);
+    const int c0 = A + a * C;
+    float m = -3.0e38f;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, ld(c0 + c));
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(ld(c0 + c) - m);
+    float best = -1.f;
+    int bc = 0;
+    for (int c = 0; c < C; ++c) {
+        const float s = (expf(ld(c0 + c) - m) / sum) * obj;
+        if (s > best) { best = s; bc = c; }
+    }
+    const int t0 = A * (1 + C) + a * 4;
+    const float tx = ld(t0), tyy = ld(t0 + 1), tw = ld(t0 + 2), th = ld(t0 + 3);
+    const float cx = (sigmoidf_(tx) + (float)gx) * L.stride;
+    const float cy = (sigmoidf_(tyy) + (float)gy) * L.stride;
+    const float bw = (expf(tw) * L.anchors[2 * a]) * p.wh_mul;
+    const float bh = (expf(th) * L.anchors[2 * a + 1]) * p.wh_mul;
+    float4 bx4;
+    bx4.x = fminf(fmaxf((cx - bw / 2) / p.in_w, 0.f), 1.f);
+    bx4.y = fminf(fmaxf((cy - bh / 2) / p.in_h, 0.f), 1.f);
+    bx4.z = fminf(fmaxf((cx + bw / 2) / p.in_w, 0.f), 1.f);
+    bx4.w = fminf(fmaxf((cy + bh / 2) / p.in_h, 0.f), 1.f);
+    const size_t o = (size_t)b * NMS_CAP + np;
+    ((float4 *)wk.dbox)[o] = bx4;
+    wk.dscore[o] = best;
+    wk.dcls[o] = bc;
+    if (p.cand_score) {      // full per-anchor tap (parity tests)
+        p.cand_score[(size_t)b * N + n] = best;
+        p.cand_cls[(size_t)b * N + n] = bc;
+        *(float4 *)(p.cand_box + ((size_t)b * N + n) * 4) = bx4;
+    }
+}
+
 __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const HeadWork wk) {
     __shared__ int hist[NMS_CAP];          // bin counts -> bin starts
     __shared__ int wsum[16];
     __shared__ unsigned int sstat[MAXA][4];
     __shared__ int ntiny_s;
-    // int8 prediction maps of the image, staged with coalesced 16-byte loads (the decode below reads
-    // ~10 scattered bytes per anchor: from global memory that is a chain of dependent misses)
-    __shared__ __attribute__((aligned(16))) int8_t spred[HEAD_STAGE_BYTES];
     const int b = blockIdx.x, tid = threadIdx.x;
     NSTAMP(0, blockIdx.x, 0);
-    const int A = p.A, C = p.C;
+    const int A = p.A;
     const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
     const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0;
     const int N = N0 + HW1 * A;
     const int HWb = p.Hb * p.Wb;
     for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
-    const int lb0 = HW0 * p.lev[0].cstride, lb1 = HW1 * (p.nlev > 1 ? p.lev[1].cstride : 0);
-    const bool staged = p.lev[0].pred != nullptr && lb0 + lb1 <= HEAD_STAGE_BYTES;
-    if (staged) {
-        const v4i *s0 = (const v4i *)(p.lev[0].pred + (size_t)b * lb0);
-        for (int i = tid; i < lb0 / 16; i += 1024) ((v4i *)spred)[i] = s0[i];
-        if (lb1) {
-            const v4i *s1 = (const v4i *)(p.lev[1].pred + (size_t)b * lb1);
-            for (int i = tid; i < lb1 / 16; i += 1024) ((v4i *)(spred + lb0))[i] = s1[i];
-        }
-    }
     if (tid < MAXA) {
         sstat[tid][0] = 0u;                 // wmax
         sstat[tid][1] = 0u;                 // hmax
@@ -107,61 +154,37 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     float box[4][4], score[4];
     int cls[4], orig[4], key[4], rk[4];
     bool valid[4];
+    {
+        // this thread's four anchors np = 4 tid .. 4 tid + 3 of the decode (NMS_CAP is a multiple of 4)
+        const size_t o4 = (size_t)b * NMS_CAP + (size_t)tid * 4;
+        float4 d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = ((const float4 *)wk.dbox)[o4 + u];
+        const float4 sc4 = *(const float4 *)(wk.dscore + o4);
+        const int4 cl4 = *(const int4 *)(wk.dcls + o4);
+        const float scs[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+        const int cls4[4] = {cl4.x, cl4.y, cl4.z, cl4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            box[u][0] = d[u].x; box[u][1] = d[u].y; box[u][2] = d[u].z; box[u][3] = d[u].w;
+            score[u] = scs[u];
+            cls[u] = cls4[u];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int np = tid * 4 + u;          // (level, anchor, cell) enumeration
         valid[u] = false;
-        score[u] = 0.f;
-        cls[u] = 0;
         orig[u] = 0;
         key[u] = 0;
         rk[u] = 0;
         if (np < N) {
             const int lv = np >= N0 ? 1 : 0;
-            const HeadLevel &L = p.lev[lv];
             const int npl = np - lv * N0, HWl = lv ? HW1 : HW0;
             const int a = npl / HWl, cell = npl % HWl;
-            const int n = lv * N0 + cell * A + a;      // the reference's anchor index (:337-341)
+            orig[u] = lv * N0 + cell * A + a;
             const int kt = lv * A + a;                 // anchor type: own bins and extents
-            const int gy = cell / L.Ws, gx = cell % L.Ws;
-            const size_t po = ((size_t)(b * L.Hs + gy) * L.Ws + gx) * L.cstride;
-            const int8_t *pq = staged ? spred + lv * lb0 + (gy * L.Ws + gx) * L.cstride : (L.pred ? L.pred + po : nullptr);
-            const float *pf = L.pred_f + po;
-            const float dq = L.dq;
-            auto ld = [&](int c) -> float { return pq ? (float)pq[c] * dq : pf[c]; };
-            const float conf = ld(a);
-            const float obj = sigmoidf_(conf);
-            const int c0 = A + a * C;
-            float m = -3.0e38f;
-            for (int c = 0; c < C; ++c) m = fmaxf(m, ld(c0 + c));
-            float sum = 0.f;
-            for (int c = 0; c < C; ++c) sum += expf(ld(c0 + c) - m);
-            float best = -1.f;
-            int bc = 0;
-            for (int c = 0; c < C; ++c) {
-                const float s = (expf(ld(c0 + c) - m) / sum) * obj;
-                if (s > best) { best = s; bc = c; }
-            }
-            const int t0 = A * (1 + C) + a * 4;
-            const float tx = ld(t0), tyy = ld(t0 + 1), tw = ld(t0 + 2), th = ld(t0 + 3);
-            const float cx = (sigmoidf_(tx) + (float)gx) * L.stride;
-            const float cy = (sigmoidf_(tyy) + (float)gy) * L.stride;
-            const float bw = (expf(tw) * L.anchors[2 * a]) * p.wh_mul;
-            const float bh = (expf(th) * L.anchors[2 * a + 1]) * p.wh_mul;
-            box[u][0] = fminf(fmaxf((cx - bw / 2) / p.in_w, 0.f), 1.f);
-            box[u][1] = fminf(fmaxf((cy - bh / 2) / p.in_h, 0.f), 1.f);
-            box[u][2] = fminf(fmaxf((cx + bw / 2) / p.in_w, 0.f), 1.f);
-            box[u][3] = fminf(fmaxf((cy + bh / 2) / p.in_h, 0.f), 1.f);
-            score[u] = best;
-            cls[u] = bc;
-            orig[u] = n;
-            valid[u] = best >= p.conf_thresh;
-            if (p.cand_score) {      // full per-anchor tap (parity tests)
-                p.cand_score[(size_t)b * N + n] = best;
-                p.cand_cls[(size_t)b * N + n] = bc;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) p.cand_box[((size_t)b * N + n) * 4 + k] = box[u][k];
-            }
+            valid[u] = score[u] >= p.conf_thresh;
             if (valid[u]) {
                 // bin of the clamped centre; per-anchor extents of the clamped boxes
                 const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
@@ -599,6 +622,14 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     }
     wk.stamps = g_stamps;
     y355_nms_stamps_dev = g_stamps;
+    wk.dbox = (float *)ws.dbox;
+    wk.dscore = (float *)ws.dscore;
+    wk.dcls = (int *)ws.dcls;
+    {
+        int n = 0;
+        for (int l = 0; l < p.nlev; ++l) n += p.lev[l].Hs * p.lev[l].Ws * p.A;
+        hipLaunchKernelGGL(decode_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, s, p, wk);
+    }
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);
     hipLaunchKernelGGL(pairs_kernel, dim3(NMS_CAP / 1024, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);

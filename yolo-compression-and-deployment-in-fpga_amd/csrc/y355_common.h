@@ -188,7 +188,7 @@ struct HeadParams {
 // head_nms.hip workspace, per image: cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP], corig i32[CAP],
 // count i32, mask u64[CAP][64], rowvalid u64[CAP], confl u64[64], binstart i32[CAP+8],
 // astat f32[16][4], tiny i32[CAP], ntiny i32, keepw u64[64], rmask = class flags u32[8].
-struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *mask, *rowvalid, *confl, *binstart, *astat, *tiny, *ntiny, *keepw, *rmask; };
+struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *mask, *rowvalid, *confl, *binstart, *astat, *tiny, *ntiny, *keepw, *rmask, *dbox, *dscore, *dcls; };
 int y355_prepare_head(void);
 // decode + compact, pruned suppression bit-matrix, ordered scan.  `mid` (optional) is recorded
 // between decode and NMS.
