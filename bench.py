@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="engine handles (HIP streams) per GPU; steps alternate")
+    ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
     ap.add_argument("--workload", default="slim_int8", choices=["slim_int8", "slim_fp32", "tiny_int8", "tiny_bf16"],
                     help="slim_int8 = the headline metric (BASELINE.json configs[1]); the others time "
                          "configs[2] / configs[3] through y355_net (single GPU, no cpu_baseline)")
