@@ -309,8 +309,8 @@ static const ConvKernelInfo g_kernels[Y355_K_COUNT] = {
     ConvInst<64, 64, 26, 26, true, 4, 1>::info(),     // conv3_2  104x104
     ConvInst<64, 128, 13, 26, false, 2, 2>::info(),   // conv4_1  52x52
     ConvInst<128, 64, 26, 26, true, 4, 1>::info(),    // conv4_2  52x52
-    ConvInst<128, 256, 13, 13, false, 1, 4>::info(),  // conv5    26x26
-    ConvInst<256, 256, 13, 13, false, 1, 4>::info(),  // conv6/7  26x26
+    ConvInst<128, 128, 13, 26, false, 2, 2>::info(),  // conv5    26x26  (13x26 strip x 128 channels: see conv3x3_v2.hip)
+    ConvInst<256, 128, 13, 26, false, 2, 2>::info(),  // conv6/7  26x26
     ConvInst<256, 64, 13, 13, false, 4, 1>::info(),   // pred     26x26
     // generic small-tile variants (operator-level API, any shape)
     ConvInst<16, 64, 8, 16, false, 4, 1>::info(),

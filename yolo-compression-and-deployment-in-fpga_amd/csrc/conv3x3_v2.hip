@@ -25,6 +25,9 @@
 #ifndef Y355_DIAG
 #define Y355_DIAG 0
 #endif
+#ifndef Y355_SLAB_AUX
+#define Y355_SLAB_AUX 2
+#endif
 
 template <int CIN>
 struct KGeom2 {
@@ -38,6 +41,12 @@ struct KGeom2 {
 __device__ __forceinline__ void glds16(const void *g, void *lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+// non-temporal form (aux = 2) for the activation slabs: read once per tile, they should not push
+// the layer's weights (re-read by every tile) out of the XCD's L2
+__device__ __forceinline__ void glds16_nt(const void *g, void *lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, Y355_SLAB_AUX);
 }
 
 template <int N>
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
                 src = inb + ((size_t)gy * (W + 2) + gx) * CIN + pwithin[j];
             }
             char *dst = (q < NPIECE) ? smem + slot * SLABB + q * 1024 : smem + OFF_DUMMY;
-            glds16(src, dst);
+            glds16_nt(src, dst);
         }
     };
     auto issue_w = [&](int nb, int ks, int slot) {
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
     } else {
         issue_w(nb, 0, 0);
         issue_w(nb, 1, 1);
+        issue_w(nb, 2, 2);
     }
 
     if (dbg & 8) { wait_vmcnt<0>(); return; }
@@ -238,6 +248,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){0, 0, 0, 0};
 
+        // Ring kernels keep the B fragments of a k-step in registers ONE PHASE EARLY: step s multiplies
+        // with the fragments it read (from LDS) during step s-1 and reads those of step s+1 while its
+        // MFMAs run, so nothing waits for LDS right behind a barrier.  The barrier of step s therefore
+        // publishes W(s+1), and the DMA runs three steps ahead (W(s+3) refills the slot read in step
+        // s-2: two barriers after its last read, the LDS-DMA WAR rule).  bfb[s & 1] is static because
+        // both loops are unrolled; a tile starts with a "pre" phase that publishes and reads W(0).
+        v4i bfb[2][NT];
+        v4i afp[2];                                              // A fragments 0, 1 of the next step (same chunk)
+        if constexpr (!WRES) {
+            if (first) wait_vmcnt<2 * WPW>();
+            else wait_vmcnt<(2 * WPW + NIT < cap63 ? 2 * WPW + NIT : cap63)>();
+            __builtin_amdgcn_s_barrier();
+            const char *wb0 = smem + OFF_W + wq * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) bfb[0][tt] = *(const v4i *)(wb0 + tt * 1024);
+        }
+#pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const bool lastc = (c == NCH - 1);
             int aaddr[MT][(CC == 64) ? 3 : 1];                   // slot base + row base (bytes); taps are immediates
@@ -247,13 +274,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
                 for (int dx = 0; dx < ((CC == 64) ? 3 : 1); ++dx) aaddr[m][dx] = sl * SLABB + abase[m][dx];
 #pragma unroll
             for (int t = 0; t < SPC; ++t) {
-                // -- data of this k-step has landed (own DMAs) -> barrier -> everybody's has
                 const bool fine = Y355_DIAG && p.stamps && (p.mode >> 16) && c == 1;
                 if (fine) stamp();
-                // vmcnt is in-order: "at most N younger operations may still fly".  Younger than the
-                // data of this step are: the weight pieces of the following step(s), a slab issued one
-                // step earlier, and -- at a tile's first steps -- the NIT output stores of the previous
-                // tile (always issued, see the copy-out), so finished tiles do not stall the ring.
+                // vmcnt is in-order: "at most N younger operations may still fly".  Ring kernels wait
+                // for W(s+1); younger than it are W(s+2), a slab issued one step earlier, and -- at a
+                // tile's first steps -- the NIT output stores of the previous tile (always issued, see
+                // the copy-out), so finished tiles do not stall the ring.
                 if constexpr (WRES) {
                     if (c == 0 && t == 0) {
                         if (first) wait_vmcnt<0>();
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
                     }
                 } else {
                     if (c == 0 && t <= 1 && !first) wait_vmcnt<(NIT + WPW < cap63 ? NIT + WPW : cap63)>();
-                    else if (t == 2) wait_vmcnt<WPW + PPW>();   // W(t+1) and the slab issued at t=1 may fly
+                    else if (t == 2) wait_vmcnt<WPW + PPW>();   // W(s+2) and the slab issued at t=1 may fly
                     else wait_vmcnt<WPW>();
                 }
                 if (fine) stamp();
@@ -271,44 +297,73 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
                 // buffer one phase AFTER..."): a slot may be restaged TWO barriers after its last
                 // ds_read was issued (every wave has then executed a whole phase, whose own lgkmcnt
                 // waits retire the older reads), or one barrier after when an lgkmcnt(0) sat in front of
-                // it.  The weight ring therefore has 4 slots (step s refills the slot read in step s-2)
-                // and the next slab is issued at t = 1 (its slot was last read at t = 8 of the previous
+                // it.  The next slab is issued at t = 1 (its slot was last read at t = 8 of the previous
                 // chunk).  Resident-weight kernels have one barrier per tile, right after the epilogue's
                 // lgkmcnt(0) + barrier, so their slab goes out at t = 0.
                 if (t == (WRES ? 0 : 1)) {
                     if (!lastc) issue_slab(b, y0, x0, c + 1, sl ^ 1);
                     else issue_slab(b2, y2, x2, 0, sl ^ 1);
                 }
+                constexpr int dummy_guard = 0;
+                (void)dummy_guard;
+                const int s_idx = c * SPC + t;                  // k-step of the tile (compile-time: both loops unrolled)
                 if constexpr (!WRES) {
-                    const int ks2 = c * SPC + t + 2;
-                    if (ks2 < KS) issue_w(nb, ks2, (wq + 2) & 3);
-                    else issue_w(nb2, ks2 - KS, (wq + 2) & 3);
+                    const int ks3 = s_idx + 3;
+                    if (ks3 < KS) issue_w(nb, ks3, (wq + 3) & 3);
+                    else issue_w(nb2, ks3 - KS, (wq + 3) & 3);
                 }
-                // -- MFMAs of this k-step
-                const char *wb = smem + OFF_W + (WRES ? t : wq) * WB + (wn * NT) * 1024 + lane * 16;
-                if constexpr (!WRES) wq = (wq + 1) & 3;
                 int ko;
                 if constexpr (CC < 64) ko = kofs[t];
                 else ko = (t / 3) * PWL * 64;                   // row offset of the tap; its column picks the base
-                // software pipeline inside the step: B fragments and A[0], A[1] first, then the read of
-                // A[m+2] is issued between the MFMA groups of A[m] and A[m+1] (counted lgkmcnt), so
-                // the LDS latency hides under the matrix pipe instead of in front of it
                 const int acol = (CC == 64) ? (t % 3) : 0;
-                v4i bf[NT];
+                v4i bres[NT];                                    // resident-weight kernels read B in the step
+                if constexpr (WRES) {
+                    const char *wb = smem + OFF_W + t * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) bf[tt] = *(const v4i *)(wb + tt * 1024);
+                    for (int tt = 0; tt < NT; ++tt) bres[tt] = *(const v4i *)(wb + tt * 1024);
+                }
+                const int cur = s_idx & 1;
+                // A fragments 0, 1: prefetched by the previous step of the chunk, else read now
                 v4i af[MT];
-                af[0] = *(const v4i *)(smem + aaddr[0][acol] + ko);
-                if constexpr (MT > 1) af[1] = *(const v4i *)(smem + aaddr[1][acol] + ko);
+                if (WRES || t == 0) {
+                    af[0] = *(const v4i *)(smem + aaddr[0][acol] + ko);
+                    if constexpr (MT > 1) af[1] = *(const v4i *)(smem + aaddr[1][acol] + ko);
+                } else {
+                    af[0] = afp[0];
+                    if constexpr (MT > 1) af[1] = afp[1];
+                }
+                if constexpr (!WRES) {
+                    // B fragments of step s+1 (published by this step's barrier), under this step's MFMAs
+                    if (s_idx + 1 < KS) {
+                        const char *wbn = smem + OFF_W + ((wq + 1) & 3) * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
+                    }
+                    wq = (wq + 1) & 3;
+                }
                 if (!(dbg & 4)) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + aaddr[m + 2][acol] + ko);
+                    if constexpr (!WRES) {
+                        if (m == MT - 1 && t + 1 < SPC) {        // next step's first A fragments (same slab)
+                            const int ko2 = (CC < 64) ? kofs[t + 1 < SPC ? t + 1 : t] : ((t + 1) / 3) * PWL * 64;
+                            const int acol2 = (CC == 64) ? ((t + 1) % 3) : 0;
+                            afp[0] = *(const v4i *)(smem + aaddr[0][acol2] + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + aaddr[1][acol2] + ko2);
+                        }
+                    }
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-                        acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // ... then this row's MFMAs
+                    for (int tt = 0; tt < NT; ++tt) {
+                        if constexpr (WRES)
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bres[tt], acc[m][tt], 0, 0, 0);
+                        else
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                    }
+                    if constexpr (WRES) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read ...
+                        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // ... then this row's MFMAs
+                    }
                 }
                 }
             }
@@ -420,8 +475,10 @@ using V2_CONV3_1 = ConvInst2<32, 64, 13, 26, false, 4, 2, true>;
 using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 8, 1, false>;
 using V2_CONV4_1 = ConvInst2<64, 128, 13, 26, false, 4, 2, false>;
 using V2_CONV4_2 = ConvInst2<128, 64, 26, 26, true, 8, 1, false>;
-using V2_CONV5 = ConvInst2<128, 256, 13, 13, false, 2, 4, false>;
-using V2_CONV67 = ConvInst2<256, 256, 13, 13, false, 2, 4, false>;
+// conv5..7 at batch 64: 256 work items either way, but a 13x26 strip x 128 channels fetches 36 % fewer
+// bytes per CU than a 13x13 tile x 256 channels (the weight stream is what these layers wait for)
+using V2_CONV5 = ConvInst2<128, 128, 13, 26, false, 4, 2, false>;
+using V2_CONV67 = ConvInst2<256, 128, 13, 26, false, 4, 2, false>;
 using V2_PRED = ConvInst2<256, 64, 13, 13, false, 8, 1, false>;
 
 int y355_prepare_conv_v2(void) {

@@ -73,6 +73,8 @@ int y355_prepare_kernels() {
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(head): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_v2())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(v2): ") + hipGetErrorString((hipError_t)e));
+    if (int e = y355_prepare_conv_ring())
+        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(ring): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_convg())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(convg): ") + hipGetErrorString((hipError_t)e));
     kernels_prepared = 1;
@@ -431,6 +433,11 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         static const int fine = getenv("Y355_STAMP_FINE") ? 1 : 0;
         if (mode == 0 && fine) p.mode |= 1 << 16;
         static const int no_v2_mask = getenv("Y355_NO_V2_MASK") ? atoi(getenv("Y355_NO_V2_MASK")) : 0;
+        static const int no_ring_mask = getenv("Y355_NO_RING_MASK") ? atoi(getenv("Y355_NO_RING_MASK")) : 0;
+        if (!no_v2 && !((no_ring_mask >> k) & 1) && y355_launch_conv_ring(L.kid, p, h->stream)) {
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
         if (no_v2 || ((no_v2_mask >> k) & 1) || !y355_launch_conv_v2(L.kid, p, h->stream))
             ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
     }

@@ -150,6 +150,9 @@ enum {
 // production conv kernels (conv3x3_v2.hip): false = not available for this launch, use ki.launch
 bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_v2(void);
+// deep-prefetch ring kernels (conv3x3_ring.hip), layers with >= 64 input channels
+bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s);
+int y355_prepare_conv_ring(void);
 
 void y355_launch_conv1(const Conv1Params &p, hipStream_t s);
 void y355_conv1_tiles(int H, int W, int *tx, int *ty);
