@@ -1,0 +1,26 @@
+import sys, os, numpy as np, ctypes as C
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0]=[ROOT, os.path.join(ROOT,"yolo-compression-and-deployment-in-fpga_amd")]
+import torch
+from yolo355 import synth, prep, _ffi
+from yolo355.engine import Engine
+import bench
+B=64
+eng = Engine([416,416], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+eng.load_quantized(bench.quantized_layers(2))
+eng.calibrate(synth.make_images(1,1,416,416), [prep.RangeTracker() for _ in range(11)])
+x = torch.from_numpy(synth.make_images(1000,B,416,416)).cuda()
+lib=_ffi.lib()
+lib.y355_debug_stamps.argtypes=[C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+np.set_printoptions(linewidth=250)
+for layer in [int(a) for a in sys.argv[1:]]:
+    for it in range(3): eng.forward_device(x)
+    lib.y355_debug_stamps(eng._h, layer, None, 0)
+    eng.forward_device(x); eng.sync()
+    buf = np.zeros((1024,32), np.uint64)
+    lib.y355_debug_stamps(eng._h, -1, buf.ctypes.data, 1024)
+    t = buf[buf[:,0]>0].astype(np.int64)
+    rel = t - t[:,0:1]; rel[t==0] = -1
+    print("layer", layer, "wgs", len(t))
+    for w in [0, 200, len(t)-1]:
+        r = rel[w]; print("  wg", w, r[:22].tolist())

@@ -29,6 +29,16 @@
 #define Y355_SLAB_AUX 2
 #endif
 
+// LDS row pitch in pixels.  64-byte pixels: a multiple of 8, so the chunk XOR depends on the patch
+// column only.  32- and 16-byte pixels: the pitch that makes the A-fragment ds_read_b128 conflict-free
+// under gfx950's 4 x 16 lane grouping (scratch/bank_sim.py: 6 -> 4 and 8 -> 4.9 LDS cycles per read):
+// pitch = 2 (mod 8) for 32-byte pixels, pitch = 8 (mod 16) for 16-byte pixels.
+constexpr int y355_lds_pitch(int cc, int pw) {
+    if (cc == 64) return (pw + 7) / 8 * 8;
+    if (cc == 32) { int p = pw; while (p % 8 != 2) ++p; return p; }
+    int p = pw; while (p % 16 != 8) ++p; return p;
+}
+
 template <int CIN>
 struct KGeom2 {
     static constexpr int CC = CIN < 64 ? CIN : 64;                // channels per chunk
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
     constexpr int PW = TW + 2, PH = TH + 2;
     // LDS row pitch in pixels: a multiple of 8 for 64-byte pixels, so that the chunk XOR depends
     // on the patch column only and every tap stays an immediate offset
-    constexpr int PWL = (CC == 64) ? (PW + 7) / 8 * 8 : PW;
+    constexpr int PWL = y355_lds_pitch(CC, PW);
     constexpr int NPIX = PH * PWL;
     constexpr int BM = TH * TW;
     constexpr int MT_TOT = (BM + 15) / 16;
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES>
 struct ConvInst2 {
     using G = KGeom2<CIN>;
-    static constexpr int PWL = (G::CC == 64) ? (TW + 2 + 7) / 8 * 8 : TW + 2;
+    static constexpr int PWL = y355_lds_pitch(G::CC, TW + 2);
     static constexpr int SLABB = ((TH + 2) * PWL * G::STRIDE + 1023) / 1024 * 1024;
     static constexpr int WB = (BN / 16) * 1024;
     static constexpr int MTT = (TH * TW + 15) / 16;
@@ -460,8 +470,11 @@ struct ConvInst2 {
     static bool launch(const ConvParams &p, hipStream_t s) {
         if (WRES && p.nblk != 1) return false;     // resident weights = one n-block
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
+        // persistent grid = what is actually co-resident: 8-wave workgroups take > 128 VGPRs per wave, so
+        // only one fits a CU whatever its LDS (a 512-workgroup grid would run as two sequential rounds)
         int per_cu = (int)((160 * 1024) / LDS);
         per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+        if (WM * WN == 8) per_cu = 1;
         int grid = 256 * per_cu;
         if (grid > total) grid = total;
         hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>), dim3(grid), dim3(WM * WN * 64), lds_launch(), s, p, total);
