@@ -38,13 +38,13 @@ PEAK_I8_DENSE = 5.0e15                          # MI355X dense int8 MFMA (2x bf1
 LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7", "pred"]
 
 
-DOMINANT_KERNEL = "conv3x3_i8_v2_kernel<256, 256, 13, 13, false, 2, 4, false>"
+DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, false, false>"
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/, collected with
     rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE runs at this workload); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
     try:
         with open(path) as f:
             for name, v in json.load(f)["kernels"].items():
