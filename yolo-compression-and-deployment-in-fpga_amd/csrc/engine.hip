@@ -268,7 +268,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.dbox, sizeof(float) * 4 * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.dscore, sizeof(float) * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.dcls, sizeof(int) * cap * B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.keepw, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.keepw, sizeof(int) * cap * B, true);          // candidate groups
     if (!rc) rc = dmalloc(h, &h->ws.rmask, sizeof(unsigned int) * 8 * (size_t)B, true);      // class flags
     if (!rc) rc = dmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
@@ -518,6 +518,9 @@ static HeadParams head_params(y355_engine *h, int sa_pred, float *ob, float *os,
     p.A = h->cfg.num_anchors;
     p.C = h->cfg.num_classes;
     p.wh_mul = 16.0f;                        // anchors in grid units (:126)
+    // int8 logits keep exp(tw) in a narrow range: the anchor is a good size class (measured: pairs 52 us
+    // vs 80 us with area octaves on the benchmark batch)
+    p.group_by_area = 0;
     p.Hb = h->Hs;
     p.Wb = h->Ws;
     p.in_w = (float)h->cfg.width;

@@ -15,8 +15,8 @@
 // sparse (a box only interacts with boxes of similar size whose centre is close), so:
 //   decode_kernel one thread per anchor: grid/anchor decode, sigmoid / softmax score, best class;
 //   head_kernel  one workgroup per image: threshold and counting-sort the candidates
-//                into (anchor, centre-bin) order -- bins are the Hs x Ws grid over the CLAMPED
-//                box centres -- plus per-anchor extents (max w/h, min/max area);
+//                into (area octave, centre-bin) order -- bins are a <= 16 x 16 grid over the CLAMPED
+//                box centres -- plus per-group extents (max w/h, min/max area);
 //   pairs_kernel one thread per candidate walks only the bins a suppressor can sit in
 //                (|dcx| < (1-thr)(wi+wj)/2, same in y, area ratio > thr), each unordered pair
 //                once, and appends the suppressing pairs to the image's edge list;
@@ -33,6 +33,7 @@
 #define NMS_CAP Y355_NMS_CAP   // max anchors per image handled by this head (416x416: 3380)
 #define NBLK (NMS_CAP / 64)
 #define MAXA Y355_HEAD_MAXA
+#define NGROUP 16                 // candidate groups (area octaves) of the sort; NGROUP * Hb * Wb <= NMS_CAP
 #define EDGE_CAP (NMS_CAP * 64)   // edges per image the global list holds (the old bit-matrix footprint / 2)
 #define WG_EDGE_CAP 8192         // edges one pairs workgroup buffers in LDS
 
@@ -49,6 +50,7 @@ struct HeadWork {
     float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
     int *ntiny;           // [B]
+    int *ctype;           // [B][CAP]     candidate group of compact position p
     float *dbox;          // [B][CAP][4]  decode of every anchor, (level, anchor, cell) order
     float *dscore;        // [B][CAP]
     int *dcls;            // [B][CAP]
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     NSTAMP(0, blockIdx.x, 1);
 
     float box[4][4], score[4];
-    int cls[4], orig[4], key[4], rk[4];
+    int cls[4], orig[4], key[4], rk[4], ktu[4];
     bool valid[4];
     {
         // this thread's four anchors np = 4 tid .. 4 tid + 3 of the decode (NMS_CAP is a multiple of 4)
@@ -178,20 +180,26 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         orig[u] = 0;
         key[u] = 0;
         rk[u] = 0;
+        ktu[u] = 0;
         if (np < N) {
             const int lv = np >= N0 ? 1 : 0;
             const int npl = np - lv * N0, HWl = lv ? HW1 : HW0;
             const int a = npl / HWl, cell = npl % HWl;
             orig[u] = lv * N0 + cell * A + a;
-            const int kt = lv * A + a;                 // anchor type: own bins and extents
             valid[u] = score[u] >= p.conf_thresh;
             if (valid[u]) {
-                // bin of the clamped centre; per-anchor extents of the clamped boxes
+                // candidate group: the anchor type, or (group_by_area) the octave of the clamped box's
+                // area -- boxes with IoU > thr have areas within 1/thr of each other, so a group only
+                // meets its neighbours; with wide-ranging exp(tw) the anchor says little about the
+                // size.  Per-group extents, bin of the clamped centre inside the group.
                 const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
+                const int ex = (int)((__float_as_uint(ar) >> 23) & 0xffu) - 127;     // floor(log2 area), area <= 1
+                const int kt = p.group_by_area ? min(NGROUP - 1, max(0, -ex - 1)) : lv * A + a;
                 const float ccx = 0.5f * (box[u][0] + box[u][2]), ccy = 0.5f * (box[u][1] + box[u][3]);
                 const int bx = min(p.Wb - 1, max(0, (int)(ccx * (float)p.Wb)));
                 const int by = min(p.Hb - 1, max(0, (int)(ccy * (float)p.Hb)));
                 key[u] = kt * HWb + by * p.Wb + bx;
+                ktu[u] = kt;
                 rk[u] = atomicAdd(&hist[key[u]], 1);
                 atomicMax(&sstat[kt][0], __float_as_uint(w));
                 atomicMax(&sstat[kt][1], __float_as_uint(h));
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             cs[pos] = score[u];
             cc[pos] = cls[u];
             co[pos] = orig[u];
+            wk.ctype[(size_t)b * NMS_CAP + pos] = ktu[u];
             if ((box[u][2] - box[u][0]) * (box[u][3] - box[u][1]) < AREA_MIN) tl[atomicAdd(&ntiny_s, 1)] = pos;
         }
     }
@@ -316,8 +325,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     const int M = wk.count[b];
     if ((int)blockIdx.x * 64 >= M) return;
     const int tid = threadIdx.x;
-    const int A = p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // anchor types, bin grid
-    const int N0 = p.lev[0].Hs * p.lev[0].Ws * p.A;
+    const int A = p.group_by_area ? NGROUP : p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // candidate groups, bin grid
     {
         const float4 *cbx4 = (const float4 *)(wk.cbox + (size_t)b * NMS_CAP * 4);
         const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
@@ -381,8 +389,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     };
     if (vi) {
         // own anchor and bin (same formula as head_kernel)
-        const int n_i = wk.corig[(size_t)b * NMS_CAP + i];
-        const int a_i = n_i < N0 ? n_i % p.A : p.A + (n_i - N0) % p.A;
+        const int a_i = wk.ctype[(size_t)b * NMS_CAP + i];
         const int by_i = min(Hs - 1, max(0, (int)(cyi * (float)Hs)));
         for (int a2 = a_i; a2 < A; ++a2) {              // lower anchors only hold positions < i
             const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1], amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
@@ -622,6 +629,7 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     }
     wk.stamps = g_stamps;
     y355_nms_stamps_dev = g_stamps;
+    wk.ctype = (int *)ws.keepw;
     wk.dbox = (float *)ws.dbox;
     wk.dscore = (float *)ws.dscore;
     wk.dcls = (int *)ws.dcls;

@@ -174,7 +174,8 @@ struct HeadParams {
     int nlev;
     int A, C;             // anchors per level, classes
     float wh_mul;         // w = exp(tw) * aw * wh_mul   (16: anchors in grid units; 1: pixels)
-    int Hb, Wb;           // bin grid of the candidate sort (level 0's grid)
+    int Hb, Wb;           // bin grid of the candidate sort
+    int group_by_area;    // 0: candidates grouped by anchor type (bins = level 0's grid); 1: by area octave (<= 16 x 16 bins)
     float in_w, in_h;     // network input size in pixels
     float conf_thresh, nms_thresh;
     float *cand_box;      // [B][N][4]
