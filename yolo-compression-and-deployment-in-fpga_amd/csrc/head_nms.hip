@@ -20,11 +20,9 @@
 //   pairs_kernel one thread per candidate walks only the bins a suppressor can sit in
 //                (|dcx| < (1-thr)(wi+wj)/2, same in y, area ratio > thr), each unordered pair
 //                once, and appends the suppressing pairs to the image's edge list;
-//   resolve_kernel one workgroup per (image, class): candidates without conflicts are kept
-//                outright; the others are sorted by (score desc, index asc), get CSR lists of
-//                their EARLIER conflicting ranks from the edge list, and are settled 64 ranks
-//                per step;
-//   emit_kernel  survivors in anchor-index order into the padded outputs.
+//   resolve_emit_kernel one workgroup per image: the endpoints of the edges are settled by rounds
+//                ("an earlier kept neighbour kills, an earlier undecided one blocks") over the edge
+//                list in LDS; survivors go out in anchor-index order into the padded outputs.
 // The pruning is exact: a pair is skipped only when real IoU < 0.999*thr and the union is not
 // degenerate, where the fp32 formula of the reference cannot exceed thr.
 #include "y355_common.h"
@@ -45,7 +43,6 @@ struct HeadWork {
     int *count;           // [B]          candidates per image
     unsigned int *edges;  // [B][EDGE_CAP] suppressing pairs (p << 12) | q with p < q (compact positions)
     int *nedges;          // [B][2]        number of edges; overflow flag (a list did not fit)
-    unsigned long long *confl;    // [B][64]       bit per compact position: has a nonzero row
     int *binstart;        // [B][CAP+8]   first compact position of bin (a*HW + by*Ws + bx)
     float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
@@ -146,9 +143,6 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         sstat[tid][3] = 0u;                 // amax
     }
     if (tid == 0) ntiny_s = 0;
-    if (tid < 64) {
-        wk.confl[(size_t)b * 64 + tid] = 0ull;
-    }
     if (tid < 2) wk.nedges[b * 2 + tid] = 0;
     __syncthreads();
     NSTAMP(0, blockIdx.x, 1);
@@ -318,7 +312,6 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     int *scls = (int *)(plds + NMS_CAP * 16);                        // [CAP]
     int *sbin = (int *)(plds + NMS_CAP * 20);                        // [CAP + 8]
     unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 20 + (NMS_CAP + 8) * 4);   // [WG_EDGE_CAP]
-    __shared__ unsigned long long sconf[64];
     __shared__ int nedge_s, gbase_s;
     const int b = blockIdx.y;
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 0);
@@ -332,7 +325,6 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         const int *bs = wk.binstart + (size_t)b * (NMS_CAP + 8);
         for (int q = tid; q < M; q += 1024) { sbox[q] = cbx4[q]; scls[q] = ccl[q]; }
         for (int q = tid; q <= A * HW; q += 1024) sbin[q] = bs[q];
-        if (tid < 64) sconf[tid] = 0ull;
         if (tid == 0) nedge_s = 0;
     }
     __syncthreads();
@@ -351,9 +343,19 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
     const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
     bool lost = false;
-    auto visit = [&](int q) {
-        const float4 bj = sbox[q];
-        const int cj = scls[q];
+    unsigned int eb0 = 0, eb1 = 0, eb2 = 0, eb3 = 0;
+    int ne_l = 0;
+    auto push = [&](unsigned int ed) {                   // one edge, straight to the lists
+        const int e = atomicAdd(&nedge_s, 1);
+        if (e < WG_EDGE_CAP) {
+            sedge[e] = ed;
+        } else {                                         // LDS buffer full: the image's global list
+            const int g = atomicAdd(&wk.nedges[b * 2], 1);
+            if (g < EDGE_CAP) wk.edges[(size_t)b * EDGE_CAP + g] = ed;
+            else lost = true;
+        }
+    };
+    auto test = [&](int q, const float4 bj, const int cj) {
         const float wj = bj.z - bj.x, hj = bj.w - bj.y, aj = wj * hj;
         bool cand = (q > i) && (cj == ci);
         if (fast) {
@@ -373,18 +375,32 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
             if (fast && den > 1e-30f && den < 1e30f && (qv > q_hi || qv < q_lo)) s = qv > q_hi;
             else s = !(inter / den <= thr);
             if (s) {
+                // a candidate has a couple of suppressing partners on average: keep the first four in
+                // registers and append them wave-wide after the walk (one LDS atomic per wave and slot
+                // instead of thousands of serialised same-address atomics inside the divergent loop)
                 const unsigned int ed = ((unsigned int)i << 12) | (unsigned int)q;
-                const int e = atomicAdd(&nedge_s, 1);
-                if (e < WG_EDGE_CAP) {
-                    sedge[e] = ed;
-                } else {                                 // LDS buffer full: straight to the image's list
-                    const int g = atomicAdd(&wk.nedges[b * 2], 1);
-                    if (g < EDGE_CAP) wk.edges[(size_t)b * EDGE_CAP + g] = ed;
-                    else lost = true;
-                }
-                atomicOr(&sconf[i >> 6], 1ull << (i & 63));
-                atomicOr(&sconf[q >> 6], 1ull << (q & 63));
+                if (ne_l == 0) eb0 = ed;
+                else if (ne_l == 1) eb1 = ed;
+                else if (ne_l == 2) eb2 = ed;
+                else if (ne_l == 3) eb3 = ed;
+                else push(ed);
+                ++ne_l;
             }
+        }
+    };
+    auto walk = [&](int q0, int q1) {
+        for (int q = q0; q < q1; q += 4) {
+            float4 bj[4];
+            int cj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = min(q + u, q1 - 1);
+                bj[u] = sbox[qq];
+                cj[u] = scls[qq];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q + u < q1) test(q + u, bj[u], cj[u]);
         }
     };
     if (vi) {
@@ -404,16 +420,46 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
                 by1 = min(Hs - 1, (int)floorf((cyi + ry) * (float)Hs));
             }
             if (a2 == a_i) by0 = max(by0, by_i);               // earlier bin rows of my anchor are < i
-            for (int by = by0; by <= by1; ++by) {
+            // two bin rows per trip and four partners per trip: the LDS reads of a trip are independent,
+            // so their latency overlaps (one dependent read per partner made this loop latency-bound)
+            for (int by = by0; by <= by1; by += 2) {
                 const int k0 = a2 * HW + by * Ws;
-                const int q0 = max(sbin[k0 + bx0], i + 1), q1 = sbin[k0 + bx1 + 1];
-                for (int q = q0; q < q1; ++q) visit(q);
+                const bool two = by + 1 <= by1;
+                const int ra = sbin[k0 + bx0], rb = sbin[k0 + bx1 + 1];
+                const int rc = two ? sbin[k0 + Ws + bx0] : 0, rd = two ? sbin[k0 + Ws + bx1 + 1] : 0;
+                walk(max(ra, i + 1), rb);
+                if (two) walk(max(rc, i + 1), rd);
             }
         }
         if (fast && ai < AREA_MIN) {                               // degenerate boxes see each other
             const int nt = wk.ntiny[b];
             const int *tl = wk.tiny + (size_t)b * NMS_CAP;
-            for (int t = 0; t < nt; ++t) visit(tl[t]);
+            for (int t = 0; t < nt; ++t) { const int q = tl[t]; test(q, sbox[q], scls[q]); }
+        }
+    }
+    // buffered edges: slot k of every lane that has one, appended with one atomic per wave
+    {
+        const int lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool has = ne_l > k;
+            const unsigned long long m = __ballot(has);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&nedge_s, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (has) {
+                    const int e = base + __popcll(m & ((1ull << lane) - 1ull));
+                    const unsigned int ed = k == 0 ? eb0 : k == 1 ? eb1 : k == 2 ? eb2 : eb3;
+                    if (e < WG_EDGE_CAP) {
+                        sedge[e] = ed;
+                    } else {
+                        const int g = atomicAdd(&wk.nedges[b * 2], 1);
+                        if (g < EDGE_CAP) wk.edges[(size_t)b * EDGE_CAP + g] = ed;
+                        else lost = true;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -432,7 +478,6 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         if (gb + e < EDGE_CAP) ge[gb + e] = sedge[e];
         else wk.nedges[b * 2 + 1] = 1;
     }
-    if (tid < 64 && sconf[tid]) atomicOr(&wk.confl[(size_t)b * 64 + tid], sconf[tid]);
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 7);
 }
 #define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
@@ -466,16 +511,15 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     const float *cs = wk.cscore + (size_t)b * NMS_CAP;
     const int *cc = wk.ccls + (size_t)b * NMS_CAP;
     const int *co = wk.corig + (size_t)b * NMS_CAP;
-    const unsigned long long *cf = wk.confl + (size_t)b * 64;
     const int ne = wk.nedges[b * 2];
     const bool brute = wk.nedges[b * 2 + 1] != 0 || ne > LDS_EDGE_CAP;
     const unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
     for (int pos = tid; pos < NMS_CAP; pos += 1024) {
-        const bool conflicted = pos < M && (brute || ((cf[pos >> 6] >> (pos & 63)) & 1ull));
-        state[pos] = conflicted ? 0 : 1;
+        state[pos] = (pos < M && brute) ? 0 : 1;          // kept unless it is an endpoint of an edge (below)
         blocked[pos] = 0;
     }
     if (tid < 64) keepn[tid] = 0ull;
+    __syncthreads();
     int mine = 0;                                     // live edges in my slots tid, tid + 1024, ...
     if (!brute) {
         // orient every pair by the NMS order
@@ -485,6 +529,8 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
             const float si = cs[i], sq = cs[q];
             const bool i_first = si > sq || (si == sq && co[i] < co[q]);
             sedge[tid + mine * 1024] = i_first ? pq : (((unsigned int)q << 12) | (unsigned int)i);
+            state[i] = 0;                                 // both endpoints are undecided
+            state[q] = 0;
             ++mine;
         }
     }
@@ -616,7 +662,6 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     wk.count = (int *)ws.count;
     wk.edges = (unsigned int *)ws.mask;
     wk.nedges = (int *)ws.rowvalid;
-    wk.confl = (unsigned long long *)ws.confl;
     wk.binstart = (int *)ws.binstart;
     wk.astat = (float *)ws.astat;
     wk.tiny = (int *)ws.tiny;
