@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
+    ap.add_argument("--input", default="f32", choices=["f32", "u8"],
+                    help="f32 = the headline configuration (fp32 NCHW tensor resident in HBM); u8 = uint8 HWC BGR "
+                         "frames with BaseTransform fused into the first layer (SURVEY 8f-1), same detections")
     ap.add_argument("--workload", default="slim_int8", choices=["slim_int8", "slim_fp32", "tiny_int8", "tiny_bf16"],
                     help="slim_int8 = the headline metric (BASELINE.json configs[1]); the others time "
                          "configs[2] / configs[3] through y355_net (single GPU, no cpu_baseline)")
@@ -205,6 +208,7 @@ def main():
 
     # rank r owns global images [r*B, (r+1)*B)
     x = torch.from_numpy(synth.make_images(1000 + rank, B, H, W)).to(dev)
+    frames = torch.from_numpy(synth.make_frames_u8(1000 + rank, B, H, W)).to(dev) if args.input == "u8" else None
     nbuf = 2 * nstreams
     bufs = [tuple(torch.empty_like(t) for t in eng._buffers(B)) for _ in range(nbuf)]
     torch.cuda.synchronize()
@@ -215,7 +219,10 @@ def main():
             for w in pending[k]:
                 w.wait()
             streams[i % nstreams].wait_stream(torch.cuda.current_stream())
-        out = engines[i % nstreams].forward_device(x, 0, bufs[k])
+        if frames is not None:
+            out = engines[i % nstreams].forward_frames_device(frames, 0, bufs[k])
+        else:
+            out = engines[i % nstreams].forward_device(x, 0, bufs[k])
         if world > 1:
             torch.cuda.current_stream().wait_stream(streams[i % nstreams])
             _g, works = shard.allgather_detections(*[t[:B] for t in out], async_op=True)
@@ -251,7 +258,10 @@ def main():
     acc = np.zeros(12)
     nprof = max(5, min(args.steps, 20))
     for i in range(nprof):
-        eng.forward_device(x, 0, bufs[0])
+        if frames is not None:
+            eng.forward_frames_device(frames, 0, bufs[0])
+        else:
+            eng.forward_device(x, 0, bufs[0])
         acc += np.array(eng.profile_ms())
     eng.profile(False)
     layer_ms = acc / nprof
@@ -274,7 +284,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "slim_yolo_v2_q_bf int8, batch %d per GPU, 416x416, 2 classes, conf 0.01" % B,
                        "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
-                       "streams_per_gpu": nstreams,
+                       "streams_per_gpu": nstreams, "input": args.input,
                        "detections_per_step_rank0": ndet},
             "roofline": {"bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": round(dom_tops * 1e12 / PEAK_I8_DENSE, 4),

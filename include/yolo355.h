@@ -110,6 +110,15 @@ int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst_host);
 #define Y355_F_TAP 2     /* also keep the per-anchor decode (y355_get_candidates) */
 int y355_forward(y355_engine *h, const float *x_dev, int batch, int flags,
                  float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev);
+/* the step in front of the path: camera frames as cv2 delivers them, uint8 HWC BGR
+ * [B][H][W][3] already at the network size (device pointer).  BaseTransform's (u/255 - mean)/std, the
+ * BGR->RGB swap and the HWC->CHW permute (data/__init__.py:30-56, test.py:79) are fused into the first
+ * layer's load with the reference's fp32 operations, so the outputs equal y355_forward on the
+ * normalised tensor bit for bit while the layer reads a quarter of the bytes.
+ * y355_set_normalization: mean / std in the reference's BGR order (defaults data/__init__.py:50). */
+int y355_set_normalization(y355_engine *h, const float *mean_bgr, const float *std_bgr);
+int y355_forward_u8(y355_engine *h, const uint8_t *frames_dev, int batch, int flags,
+                    float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev);
 /* same, host pointers in and out (copies through engine-owned staging buffers); synchronous. */
 int y355_forward_host(y355_engine *h, const float *x_host, int batch, int flags,
                       float *boxes, float *scores, int32_t *cls, int32_t *count);

@@ -266,3 +266,31 @@ def test_two_engines_concurrent():
             raise AssertionError("iteration %d: concurrent result differs (%d prediction values)" % (it, diff))
     for e in engs:
         e.close()
+
+
+def test_forward_frames_equals_normalised_tensor():
+    """y355_forward_u8 (uint8 HWC BGR frames, BaseTransform fused into the first layer) == y355_forward on
+    the tensor the reference's BaseTransform + channel swap + permute produce (data/__init__.py:30-56,
+    test.py:79): identical int8 feature maps and detections, fused path and fp32 staging path (find)."""
+    B, H, W = 3, 224, 320
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2, pred_gain=400.0, obj_bias=-4.0))
+    eng = Engine([H, W], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+    eng.load_quantized(ql)
+    frames = synth.make_frames_u8(5, B, H, W, "blocks")
+    x = synth.normalize_frames(frames)
+    eng.calibrate(x[:1], [RangeTracker() for _ in range(11)])
+    ref = eng.forward(x)
+    ctr_ref = eng.counters()
+    feat_ref = [eng.get_feature(k, B).copy() for k in (0, 9)]
+    got = eng.forward_frames(frames)
+    assert eng.counters() == ctr_ref                       # clamped inputs / outputs counted identically
+    for k, f in zip((0, 9), feat_ref):
+        assert np.array_equal(eng.get_feature(k, B), f)
+    for a, b in zip(ref, got):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    got2 = eng.forward_frames(frames, find=True)          # guard flag: normalise kernel + fp32 path
+    for a, b in zip(ref, got2):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    eng.close()

@@ -137,7 +137,10 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
 // ---- production variant: same arithmetic (32-bit epilogue, no statistics / guard), organised so
 // that nothing in the hot loops needs an integer division: waves quantise whole patch rows (lanes
 // along x) and own whole rows of pooling windows, so LDS addresses advance by constants.
-template <int TW>
+// U8: the input is the camera frame itself (uint8 HWC BGR); BaseTransform's (u/255 - mean)/std, the
+// BGR->RGB swap and the HWC->CHW permute (data/__init__.py:30-56, test.py:79) happen in the load, with
+// the reference's fp32 operations in the reference's order, so the quantised pixels are identical.
+template <int TW, bool U8>
 __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
     constexpr int TH = 16;
     constexpr int PW = TW + 2, PH = TH + 2;
@@ -163,10 +166,63 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
     unsigned int nsat_in = 0;
 
     // ---- quantise the patch: wave w takes patch rows w, w+4, ...; lanes run along x
-    const float *xb = p.x + (size_t)b * 3 * H * W;
+    const float *xb = U8 ? nullptr : p.x + (size_t)b * 3 * H * W;
     const size_t plane = (size_t)H * W;
     constexpr int XP = (PW + 63) / 64;             // passes along a row
     constexpr int RPW = (PH + 3) / 4;              // patch rows per wave
+    if constexpr (U8) {
+        // normalise + quantise is a function of the byte: one 256-entry table per channel, built by the
+        // workgroup with the reference's fp32 operations in the reference's order ((u/255 - mean)/std,
+        // data/__init__.py:43-45; round(x * 2^sa), slim_yolo_v2.py:35), bit 8 = "was clamped"
+        __shared__ unsigned short lut[3 * 256];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = (float)tid;
+            t /= 255.0f;
+            t -= p.nmean[c];
+            t /= p.nstd[c];
+            const float r = rintf(t * sc);
+            const float rc = fminf(fmaxf(r, -127.f), 127.f);
+            lut[c * 256 + tid] = (unsigned short)(((int)rc & 0xff) | (rc != r ? 0x100 : 0));
+        }
+        const uint8_t *fb = p.x_u8 + (size_t)b * H * W * 3;
+        unsigned char raw[RPW][XP][3];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int py = wave + 4 * k;
+            const int gy = y0 + py - 1;
+            const size_t ro = (size_t)min(max(gy, 0), H - 1) * W;
+#pragma unroll
+            for (int xp = 0; xp < XP; ++xp) {
+                const int gx = x0 + xp * 64 + lane - 1;
+                const size_t o = (ro + min(max(gx, 0), W - 1)) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) raw[k][xp][c] = fb[o + (2 - c)];      // RGB channel c = BGR byte 2 - c
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int py = wave + 4 * k;
+            const int gy = y0 + py - 1;
+            const bool rowin = gy >= 0 && gy < H && py < PH;
+#pragma unroll
+            for (int xp = 0; xp < XP; ++xp) {
+                const int px = xp * 64 + lane;
+                const int gx = x0 + px - 1;
+                const bool inside = rowin && gx >= 0 && gx < W;
+                const bool own = inside && py >= 1 && py <= TH && px >= 1 && px <= TW;
+                unsigned int w = 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned int e = lut[c * 256 + raw[k][xp][c]];
+                    nsat_in += (own && (e & 0x100u)) ? 1u : 0u;
+                    w |= (inside ? (e & 0xffu) : 0u) << (8 * c);
+                }
+                if (px < PW && py < PH) patch[py * PW + px] = w;
+            }
+        }
+    } else {
     // all of a wave's rows are loaded before any is quantised: RPW * XP * 3 loads in flight
     float v[RPW][XP][3];
 #pragma unroll
@@ -204,6 +260,7 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
             }
             if (px < PW && py < PH) patch[py * PW + px] = w;
         }
+    }
     }
     if (tid < 8) patch[PH * PW + tid] = 0;
     __syncthreads();
@@ -262,8 +319,13 @@ void y355_launch_conv1(const Conv1Params &p, hipStream_t s) {
     const int n = p.tiles_x * p.tiles_y * p.B;
     const bool big = conv1_tw(p.W) == 104;
     if (p.mode == 0 && !p.rq.wide && !p.guard && !p.out_pb) {
-        if (big) hipLaunchKernelGGL((conv1_fast_kernel<104>), dim3(n), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv1_fast_kernel<32>), dim3(n), dim3(256), 0, s, p);
+        if (p.x) {
+            if (big) hipLaunchKernelGGL((conv1_fast_kernel<104, false>), dim3(n), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv1_fast_kernel<32, false>), dim3(n), dim3(256), 0, s, p);
+        } else {
+            if (big) hipLaunchKernelGGL((conv1_fast_kernel<104, true>), dim3(n), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv1_fast_kernel<32, true>), dim3(n), dim3(256), 0, s, p);
+        }
         return;
     }
     if (p.rq.wide) {
@@ -309,4 +371,31 @@ void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStr
     int blocks = (int)((n / 4 + 255) / 256);
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, out_bits);
+}
+
+// ---- BaseTransform on the GPU for the paths that take fp32 (statistics / 64-bit epilogue / guard) ------
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t *frames, float *x, int B, int H, int W, float m0, float m1,
+                                                           float m2, float s0, float s1, float s2) {
+    const size_t n = (size_t)B * H * W;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / ((size_t)H * W), r = i % ((size_t)H * W);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = (float)frames[i * 3 + (2 - c)];
+            t /= 255.0f;
+            t -= mean[c];
+            t /= sd[c];
+            x[(b * 3 + c) * (size_t)H * W + r] = t;
+        }
+    }
+}
+
+void y355_launch_normalize_u8(const uint8_t *frames, float *x, int B, int H, int W, const float *mean_rgb, const float *std_rgb,
+                              hipStream_t s) {
+    const size_t n = (size_t)B * H * W;
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > 8192 ? 8192 : blocks;
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3(blocks), dim3(256), 0, s, frames, x, B, H, W, mean_rgb[0], mean_rgb[1], mean_rgb[2],
+                       std_rgb[0], std_rgb[1], std_rgb[2]);
 }

@@ -146,6 +146,9 @@ struct y355_engine {
     int sa[11];
     bool sa_set[11];
     int retune[10];
+    float nmean[3] = {0.485f, 0.456f, 0.406f};   // BaseTransform constants, RGB order (data/__init__.py:50 lists BGR)
+    float nstd[3] = {0.229f, 0.224f, 0.225f};
+    const uint8_t *x_u8 = nullptr;  // uint8 frames of the forward being enqueued (y355_forward_u8)
     int8_t *w0_dev = nullptr;       // conv1 fragment
     Counters *ctr_dev = nullptr;    // [10]
     unsigned int *absmax_dev = nullptr;
@@ -391,6 +394,8 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
     if (k == 0) {
         Conv1Params p{};
         p.x = x_dev;
+        p.x_u8 = x_dev ? nullptr : h->x_u8;
+        for (int c = 0; c < 3; ++c) { p.nmean[c] = h->nmean[c]; p.nstd[c] = h->nstd[c]; }
         p.out = L.out_dev;
         p.w = h->w0_dev;
         p.bias_t = L.bias_dev;
@@ -606,6 +611,45 @@ extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int f
     h->graphs.push_back(ge);
     HIPCHK(hipGraphLaunch(ge.exec, h->stream));
     return 0;
+}
+
+// BaseTransform constants of the uint8 path, in the reference's BGR order (data/__init__.py:50)
+extern "C" int y355_set_normalization(y355_engine *h, const float *mean_bgr, const float *std_bgr) {
+    if (!h || !mean_bgr || !std_bgr) return fail(Y355_EINVAL, "null argument");
+    for (int c = 0; c < 3; ++c) {
+        if (!(std_bgr[2 - c] > 0.f)) return fail(Y355_EINVAL, "std must be positive");
+        h->nmean[c] = mean_bgr[2 - c];
+        h->nstd[c] = std_bgr[2 - c];
+    }
+    return 0;
+}
+
+// The step in front of the path: frames as cv2 delivers them, uint8 HWC BGR [B][H][W][3]
+// already at the network size; BaseTransform + BGR->RGB + HWC->CHW (data/__init__.py:30-56, test.py:79)
+// are fused into the first layer's load (4x fewer input bytes than the fp32 tensor).  Same outputs as
+// y355_forward on the normalised tensor, bit for bit.
+extern "C" int y355_forward_u8(y355_engine *h, const uint8_t *frames_dev, int batch, int flags, float *boxes_dev,
+                               float *scores_dev, int32_t *cls_dev, int32_t *count_dev) {
+    if (!h || !frames_dev || !boxes_dev || !scores_dev || !cls_dev || !count_dev) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    for (int k = 0; k < 10; ++k)
+        if (int rc = refresh_layer(h, k, true)) return rc;
+    const bool fused = !h->L[0].rq.wide && !(flags & Y355_F_GUARD);
+    if (!fused) {
+        // 64-bit epilogue / guard runs take the fp32 tensor: normalise into the staging buffer first
+        const size_t xin = (size_t)3 * h->cfg.height * h->cfg.width;
+        if (!h->x_stage) {
+            if (int rc = dmalloc(h, (void **)&h->x_stage, sizeof(float) * xin * h->cfg.max_batch, false)) return rc;
+        }
+        y355_launch_normalize_u8(frames_dev, h->x_stage, batch, h->cfg.height, h->cfg.width, h->nmean, h->nstd, h->stream);
+        HIPCHK(hipGetLastError());
+        return enqueue_forward(h, h->x_stage, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, h->profile != 0);
+    }
+    h->x_u8 = frames_dev;
+    const int rc = enqueue_forward(h, nullptr, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, h->profile != 0);
+    h->x_u8 = nullptr;
+    return rc;
 }
 
 extern "C" int y355_forward_host(y355_engine *h, const float *x_host, int batch, int flags, float *boxes,

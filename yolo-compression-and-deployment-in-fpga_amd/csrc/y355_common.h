@@ -63,6 +63,8 @@ struct ConvParams {
 
 struct Conv1Params {
     const float *x;       // fp32 NCHW [B][3][H][W]
+    const uint8_t *x_u8;  // or (x == nullptr) camera frames uint8 HWC BGR [B][H][W][3], normalised on the fly
+    float nmean[3], nstd[3];  // BaseTransform constants per RGB channel (data/__init__.py:50)
     int8_t *out;          // int8 NHWC16 with halo [B][H/2+2][W/2+2][16]
     int out_pb;           // bytes per output pixel (0 = 16; wider: the extra bytes stay untouched)
     const int8_t *w;      // 64 lanes x 16 B fragment
@@ -198,6 +200,9 @@ int y355_prepare_head(void);
 // between decode and NMS.
 void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid);
 void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStream_t s);
+// uint8 HWC BGR frames -> fp32 NCHW RGB, BaseTransform arithmetic (data/__init__.py:30-56, test.py:79)
+void y355_launch_normalize_u8(const uint8_t *frames, float *x, int B, int H, int W, const float *mean_rgb, const float *std_rgb,
+                              hipStream_t s);
 
 // ---- generic chunked conv (convg.hip): bf16 nets and the int8 layers conv3x3.hip cannot hold --
 struct RequantG {

@@ -169,6 +169,43 @@ class Engine:
                                           oc.data_ptr(), on.data_ptr()))
         return ob, os_, oc, on
 
+    def forward_frames_device(self, frames, flags=0, out=None):
+        """Asynchronous batched forward on camera frames: CUDA uint8 [B,H,W,3] BGR at the network size
+        (BaseTransform fused into the first layer, y355_forward_u8)."""
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3 or \
+                list(frames.shape[1:3]) != self.input_size or not frames.is_cuda:
+            raise ValueError("expected a CUDA uint8 tensor [B,%d,%d,3]" % tuple(self.input_size))
+        frames = frames.contiguous()
+        B = frames.shape[0]
+        if B > self.max_batch:
+            raise ValueError("batch %d > max_batch %d" % (B, self.max_batch))
+        ob, os_, oc, on = out if out is not None else self._buffers(B)
+        _ffi.check(self._lib.y355_forward_u8(self._h, frames.data_ptr(), B, int(flags), ob.data_ptr(), os_.data_ptr(),
+                                             oc.data_ptr(), on.data_ptr()))
+        return ob, os_, oc, on
+
+    def forward_frames(self, frames, find=False):
+        """frames: uint8 [B,H,W,3] BGR (numpy or torch).  Same return as forward(normalised tensor)."""
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(frames)
+        fd = frames.to(self.device)
+        B = fd.shape[0]
+        ob, os_, oc, on = self.forward_frames_device(fd, _ffi.F_GUARD if find else 0)
+        n = on[:B].cpu().numpy()
+        if find:
+            sat, guard = self.counters()
+            if guard:
+                print("too high!!!")
+                raise AssertionError("conv output exceeds the 16-bit head-room (find=True): %d positions" % guard)
+        boxes, scores, cls = ob[:B].cpu().numpy(), os_[:B].cpu().numpy(), oc[:B].cpu().numpy()
+        return [(boxes[i, :n[i]].copy(), scores[i, :n[i]].copy(), cls[i, :n[i]].astype(np.int64))
+                for i in range(B)]
+
+    def set_normalization(self, mean_bgr, std_bgr):
+        m = (C.c_float * 3)(*[float(v) for v in mean_bgr])
+        sd = (C.c_float * 3)(*[float(v) for v in std_bgr])
+        _ffi.check(self._lib.y355_set_normalization(self._h, m, sd))
+
     def forward(self, x, find=False, tap=False):
         """list of (bboxes float32 [n,4], scores float32 [n], cls_inds int64 [n]) per image,
         in anchor-index order: the reference's eval-mode return for every image of the batch."""

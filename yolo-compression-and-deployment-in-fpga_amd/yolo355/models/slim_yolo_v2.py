@@ -119,6 +119,19 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
         eng.set_thresholds(self.conf_thresh, self.nms_thresh)
         return eng.forward(x, find=find)
 
+    def forward_frames(self, frames, find=False):
+        """New: detections for camera frames, uint8 [B,H,W,3] BGR at the network size --
+        BaseTransform + BGR->RGB + HWC->CHW (data/__init__.py:30-56, test.py:79) run inside the first
+        layer.  Element i equals forward(x_i) for the tensor the reference's transform makes of frame i.
+        The trackers must be calibrated (one forward on a normalised tensor) beforehand."""
+        eng = self._get_engine(int(frames.shape[0]), find)
+        trackers = self._tracker_states()
+        if any(t.first_a == 0 for t in trackers):
+            raise RuntimeError("yolo355: calibrate the trackers with one forward(x, quantization=True) first")
+        eng.set_act_exponents([t.exponent() for t in trackers])
+        eng.set_thresholds(self.conf_thresh, self.nms_thresh)
+        return eng.forward_frames(frames, find=find)
+
     # ------------------------------------------------------------------ engine plumbing
     def _weights_version(self):
         return tuple(int(p._version) for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
