@@ -105,24 +105,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
     const int li = lane & 15, g = lane >> 4;
     const int H = p.H, W = p.W;
 
-    int abase[MT][3];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        int row = (wm * MT + m) * 16 + li;
-        row = min(row, BM - 1);
-        int oy, ox;
-        if constexpr (POOL) {
-            const int w = row >> 2, r = row & 3;
-            oy = 2 * (w / (TW / 2)) + (r >> 1);
-            ox = 2 * (w % (TW / 2)) + (r & 1);
-        } else {
-            oy = row / TW;
-            ox = row % TW;
-        }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ (((ox + dx) >> 1) & 3)) << 4);
-    }
     // slab DMA pieces of this wave: piece q = wave + NW*j covers LDS bytes [q*1024, +1024); lane l owns
     // the 16 bytes at pixel q*16 + l/4, XOR-swizzled 16-byte group (l&3) ^ ((l>>3)&3).  Piece j is
     // NW*16/PWL patch rows below piece 0, so one (row, column) pair describes them all.
@@ -180,6 +162,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
     for (int k = 0; k <= PF; ++k) {
         if (k < KS) issue_w(nb, k, k);
         else issue_w(nb, k - KS, k);                           // KS > PF for every layer here; keeps counts static
+    }
+    // per-lane A-fragment bases (integer divisions): computed while the prologue's DMAs are in flight
+    int abase[MT][3];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int row = (wm * MT + m) * 16 + li;
+        row = min(row, BM - 1);
+        int oy, ox;
+        if constexpr (POOL) {
+            const int w = row >> 2, r = row & 3;
+            oy = 2 * (w / (TW / 2)) + (r >> 1);
+            ox = 2 * (w % (TW / 2)) + (r & 1);
+        } else {
+            oy = row / TW;
+            ox = row % TW;
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ (((ox + dx) >> 1) & 3)) << 4);
     }
     const Requant rq = p.rq;
     unsigned int nsat = 0;
