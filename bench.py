@@ -154,6 +154,23 @@ def bench_net(args):
                      "nms_ms": round(float(ms[-1]), 4)}}))
 
 
+def cpu_baseline_torch(n_images=16):
+    """the reference's PyTorch CPU route -- the same forward restated with stock torch CPU
+    ops (oracle/yolo_oracle.py: conv2d on the fake-quantised operands, numpy NMS), pinned bit-equal to the
+    imported reference by tests/golden/e2e.npz.  Checker code, timed here only as a reported baseline."""
+    from oracle import yolo_oracle as O
+    ql = O.quantize_layers(synth.make_weights(2, num_classes=NUM_CLASSES))
+    tr = [O.RangeTracker() for _ in range(11)]
+    O.detect(synth.make_images(1, 1, H, W), ql, tr, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES)
+    x = synth.make_images(1000, n_images, H, W)
+    t0 = time.perf_counter()
+    O.detect(x, ql, tr, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES, 0.01, 0.5)
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_images / dt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample="%d images, 416x416, whole path through oracle/yolo_oracle.py (torch CPU conv2d + numpy "
+                       "head/NMS), %.1f s" % (n_images, dt))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,6 +317,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline_pytorch"] = cpu_baseline_torch()
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

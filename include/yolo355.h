@@ -21,6 +21,7 @@
 #ifndef YOLO355_H
 #define YOLO355_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -147,6 +148,13 @@ int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const int8_t *q_w, 
 int y355_conv3x3_i8_raw(int device_id, const int8_t *q_in, const int8_t *q_w, const int32_t *q_b,
                         int batch, int cin, int cout, int height, int width,
                         int sa_in, int e_w, int e_b, int flags, int64_t *out, int32_t *frac_bits);
+/* the two element-wise ops of the path in stand-alone form (the fused layers absorb them); host
+ * pointers, synchronous, NCHW:
+ *   y355_quantize_input_f32_i8: AveragedRangeTracker.quantize_activation on the network input
+ *     (models/slim_yolo_v2.py:33-38): q = clamp(RNE(x * 2^sa), +-127); *clamped = values that hit the clamp
+ *   y355_maxpool2x2_i8: nn.MaxPool2d(2, 2) (:61,65,71,77) on int8 [B][C][H][W] -> [B][C][H/2][W/2] */
+int y355_quantize_input_f32_i8(int device_id, const float *x, size_t n, int sa, int8_t *q, int64_t *clamped);
+int y355_maxpool2x2_i8(int device_id, const int8_t *in, int batch, int channels, int height, int width, int8_t *out);
 /* head only: pred int8 [B][A*(5+C)][Hs][Ws] NCHW host -> detections (host), synchronous.
  * Replaces slim_yolo_v2.py:330-358 (decode, score, threshold, per-class NMS). */
 int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred,

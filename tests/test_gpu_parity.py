@@ -294,3 +294,46 @@ def test_forward_frames_equals_normalised_tensor():
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
     eng.close()
+
+
+def test_elementwise_operators():
+    """stand-alone input fake-quant and 2x2 max-pool against the oracle's restatement"""
+    from yolo355.engine import quantize_input_f32_i8, maxpool2x2_i8
+    x = synth.make_images(9, 2, 64, 96) * np.float32(3.0)            # some values beyond +-127 / 2^sa
+    for sa in (4, 5, 6):
+        q, clamped = quantize_input_f32_i8(x, sa)
+        r = np.rint(x * np.float32(2.0 ** sa))
+        assert np.array_equal(q, np.clip(r, -127, 127).astype(np.int8))
+        assert clamped == int((np.abs(r) > 127).sum())
+    q, _ = quantize_input_f32_i8(x, 4)
+    p = maxpool2x2_i8(q)
+    B, C_, H, W = q.shape
+    assert np.array_equal(p, q.reshape(B, C_, H // 2, 2, W // 2, 2).max(axis=(3, 5)))
+
+
+def test_errors_are_loud():
+    """wrong shapes, missing weights / exponents, oversize batches: negative status + message, no
+    silent result (errors of the reference are Python exceptions)."""
+    from yolo355 import _ffi
+    from yolo355.engine import maxpool2x2_i8
+    eng = Engine([96, 96], 2, synth.ANCHOR_SIZE_MASK, max_batch=2)
+    x = synth.make_images(1, 1, 96, 96)
+    with pytest.raises(_ffi.Y355Error) as e:
+        eng.forward(x)                                  # nothing loaded
+    assert e.value.code == -3                           # Y355_ENOTREADY
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
+    eng.load_quantized(ql)
+    with pytest.raises(_ffi.Y355Error) as e:
+        eng.forward(x)                                  # not calibrated
+    assert e.value.code == -3
+    with pytest.raises(_ffi.Y355Error):
+        eng.load_layer(3, ql[2]["q_w"], ql[2]["q_b"], 9, 9)      # wrong layer shape
+    with pytest.raises(ValueError):
+        eng.forward(synth.make_images(1, 3, 96, 96))    # batch > max_batch
+    with pytest.raises(ValueError):
+        eng.forward(synth.make_images(1, 1, 64, 96))    # wrong input size
+    with pytest.raises(_ffi.Y355Error):
+        Engine([100, 96], 2, synth.ANCHOR_SIZE_MASK)    # not a multiple of 16
+    with pytest.raises(_ffi.Y355Error):
+        maxpool2x2_i8(np.zeros((1, 1, 3, 4), np.int8))  # odd height
+    eng.close()

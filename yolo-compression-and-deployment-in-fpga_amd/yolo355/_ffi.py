@@ -81,6 +81,8 @@ _SIGS = {
                                         C.c_void_p, P(LayerStats)]),
     "y355_conv3x3_i8_raw": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, P(C.c_int32)]),
+    "y355_quantize_input_f32_i8": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, P(C.c_int64)]),
+    "y355_maxpool2x2_i8": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y355_debug_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "y355_debug_nms_stamps": (C.c_int, [C.c_void_p]),
     "y355_head_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -297,3 +297,27 @@ def conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=True, device_id=0):
                                        H, W, int(sa_in), int(e_w), int(e_b), _ffi.OP_LEAKY if leaky else 0,
                                        out.ctypes.data, C.byref(fb)))
     return out, fb.value
+
+
+def quantize_input_f32_i8(x, sa, device_id=0):
+    """Stand-alone input fake-quant (y355_quantize_input_f32_i8): (q int8 like x, clamped count)."""
+    lib = _ffi.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("yolo355 needs a GPU; there is no CPU fallback")
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    q = np.empty(xf.shape, np.int8)
+    c = C.c_int64()
+    _ffi.check(lib.y355_quantize_input_f32_i8(int(device_id), xf.ctypes.data, xf.size, int(sa), q.ctypes.data, C.byref(c)))
+    return q, c.value
+
+
+def maxpool2x2_i8(q, device_id=0):
+    """Stand-alone 2x2 / stride 2 max-pool on int8 NCHW (y355_maxpool2x2_i8)."""
+    lib = _ffi.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("yolo355 needs a GPU; there is no CPU fallback")
+    qi = np.ascontiguousarray(q, dtype=np.int8)
+    B, Cc, H, W = qi.shape
+    out = np.empty((B, Cc, H // 2, W // 2), np.int8)
+    _ffi.check(lib.y355_maxpool2x2_i8(int(device_id), qi.ctypes.data, B, Cc, H, W, out.ctypes.data))
+    return out
