@@ -123,6 +123,7 @@ class Engine:
         m = C.c_float()
         _ffi.check(lib.y355_input_absmax(h, xd.data_ptr(), B, C.byref(m)))
         sa = [trackers[0].update(m.value, freeze)]
+        self.calib_max = [float(m.value)]                 # max|.| seen by each tracker in this calibration
         _ffi.check(lib.y355_set_act_exponent(h, 0, sa[0]))
         st = _ffi.LayerStats()
         for k in range(NUM_LAYERS):
@@ -132,6 +133,7 @@ class Engine:
             # max|y| as the fp32 value the reference's activation.abs().max() returns
             ymax = np.float32(st.absmax_t) * np.float32(2.0 ** (-st.frac_bits))
             sa.append(trackers[k + 1].update(ymax, freeze))
+            self.calib_max.append(float(ymax))
             _ffi.check(lib.y355_set_act_exponent(h, k + 1, sa[-1]))
             _ffi.check(lib.y355_run_layer(h, k, B, 0, xp))
         return sa
