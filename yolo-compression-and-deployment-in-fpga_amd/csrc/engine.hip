@@ -261,9 +261,8 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
     if (!rc) rc = dmalloc(h, &h->ws.corig, sizeof(int) * cap * B, false);
     if (!rc) rc = dmalloc(h, &h->ws.count, sizeof(int) * B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.mask, sizeof(unsigned long long) * 64 * cap * B, false);
-    if (!rc) rc = dmalloc(h, &h->ws.rowvalid, 8 * cap * (size_t)B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.confl, 8 * 64 * (size_t)B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.edges, sizeof(unsigned int) * 64 * cap * B, false);      // EDGE_CAP pairs per image
+    if (!rc) rc = dmalloc(h, &h->ws.nedges, sizeof(int) * 2 * (size_t)B, true);
     if (!rc) rc = dmalloc(h, &h->ws.binstart, sizeof(int) * (cap + 8) * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.tiny, sizeof(int) * cap * B, true);
@@ -271,8 +270,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.dbox, sizeof(float) * 4 * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.dscore, sizeof(float) * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.dcls, sizeof(int) * cap * B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.keepw, sizeof(int) * cap * B, true);          // candidate groups
-    if (!rc) rc = dmalloc(h, &h->ws.rmask, sizeof(unsigned int) * 8 * (size_t)B, true);      // class flags
+    if (!rc) rc = dmalloc(h, &h->ws.ctype, sizeof(int) * cap * B, true);          // candidate groups
     if (!rc) rc = dmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
     if (!rc) rc = dmalloc(h, (void **)&h->cand_cls, sizeof(int) * N * B, false);

@@ -32,7 +32,7 @@
 #define NBLK (NMS_CAP / 64)
 #define MAXA Y355_HEAD_MAXA
 #define NGROUP 16                 // candidate groups (area octaves) of the sort; NGROUP * Hb * Wb <= NMS_CAP
-#define EDGE_CAP (NMS_CAP * 64)   // edges per image the global list holds (the old bit-matrix footprint / 2)
+#define EDGE_CAP (NMS_CAP * 64)   // suppressing pairs per image the global list holds
 #define WG_EDGE_CAP 8192         // edges one pairs workgroup buffers in LDS
 
 struct HeadWork {
@@ -660,8 +660,8 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     wk.ccls = (int *)ws.ccls;
     wk.corig = (int *)ws.corig;
     wk.count = (int *)ws.count;
-    wk.edges = (unsigned int *)ws.mask;
-    wk.nedges = (int *)ws.rowvalid;
+    wk.edges = (unsigned int *)ws.edges;
+    wk.nedges = (int *)ws.nedges;
     wk.binstart = (int *)ws.binstart;
     wk.astat = (float *)ws.astat;
     wk.tiny = (int *)ws.tiny;
@@ -674,7 +674,7 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     }
     wk.stamps = g_stamps;
     y355_nms_stamps_dev = g_stamps;
-    wk.ctype = (int *)ws.keepw;
+    wk.ctype = (int *)ws.ctype;
     wk.dbox = (float *)ws.dbox;
     wk.dscore = (float *)ws.dscore;
     wk.dcls = (int *)ws.dcls;

@@ -192,12 +192,13 @@ struct HeadParams {
 #define Y355_NMS_CAP 4096   // anchors per image the NMS workspace is sized for
 #define Y355_HEAD_MAXA 16
 // head_nms.hip workspace, per image: cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP], corig i32[CAP],
-// count i32, mask u64[CAP][64], rowvalid u64[CAP], confl u64[64], binstart i32[CAP+8],
-// astat f32[16][4], tiny i32[CAP], ntiny i32, keepw u64[64], rmask = class flags u32[8].
-struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *mask, *rowvalid, *confl, *binstart, *astat, *tiny, *ntiny, *keepw, *rmask, *dbox, *dscore, *dcls; };
+// count i32, edges u32[64*CAP] (suppressing pairs), nedges i32[2] (count, overflow flag),
+// binstart i32[CAP+8], astat f32[16][4], tiny i32[CAP], ntiny i32, ctype i32[CAP] (candidate group),
+// dbox f32[CAP][4] / dscore f32[CAP] / dcls i32[CAP] (decode of every anchor).
+struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *edges, *nedges, *binstart, *astat, *tiny, *ntiny, *ctype, *dbox, *dscore, *dcls; };
 int y355_prepare_head(void);
-// decode + compact, pruned suppression bit-matrix, ordered scan.  `mid` (optional) is recorded
-// between decode and NMS.
+// decode, candidate sort, pruned pair walk (edge list), rounds + output.  `mid` (optional) is recorded
+// between the candidate sort and the pair walk.
 void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid);
 void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStream_t s);
 // uint8 HWC BGR frames -> fp32 NCHW RGB, BaseTransform arithmetic (data/__init__.py:30-56, test.py:79)
