@@ -20,6 +20,18 @@
 #ifndef Y355_DIAG
 #define Y355_DIAG 0
 #endif
+#ifndef Y355_RING_AORDER
+#define Y355_RING_AORDER 0       // 0: compiler-placed LDS reads/waits; 1: hand-placed step (volatile asm)
+#endif
+#ifndef Y355_ABL
+#define Y355_ABL 0               // timing ablations (WRONG RESULTS): 1 no A reads, 2 no B reads, 4 no refill DMAs, 8 no barriers
+#endif
+#ifndef Y355_RING_DMA_AT2
+#define Y355_RING_DMA_AT2 -2     // >= 0: the younger half of the workgroup (waves NW/2..) refills after this m-tile instead
+#endif
+#ifndef Y355_RING_DMA_AT
+#define Y355_RING_DMA_AT -1      // m-tile after whose MFMAs a step's refill DMAs go out (-1: right after the barrier)
+#endif
 
 __device__ __forceinline__ void rglds16(const void *g, void *lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -45,6 +57,53 @@ __device__ __forceinline__ void rwait_vmcnt_dyn(int n) {
         RW_CASE(55) RW_CASE(56) RW_CASE(57) RW_CASE(58) RW_CASE(59) RW_CASE(60) RW_CASE(61) RW_CASE(62) RW_CASE(63)
     }
 #undef RW_CASE
+}
+
+// LDS reads and waits the compiler does not see (Y355_RING_AORDER): the reads carry no latency
+// information for it, the waits are tied to the registers they publish so no MFMA moves above them
+__device__ __forceinline__ void rds128(v4i &d, unsigned addr) {
+#if defined(Y355_ABL) && (Y355_ABL & 32)
+    return;
+#endif
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void rds128_o(v4i &d, unsigned addr) {
+#if defined(Y355_ABL) && (Y355_ABL & 32)
+    return;
+#endif
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+#ifndef Y355_RING_BUILTIN_MFMA
+#define Y355_RING_BUILTIN_MFMA 0
+#endif
+#ifndef Y355_RING_SAFEWAIT
+#define Y355_RING_SAFEWAIT 0
+#endif
+__device__ __forceinline__ void rwait_lgkm(int n) {
+    if (Y355_RING_SAFEWAIT) n = 0;
+#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
+        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
+    }
+#undef RL_CASE
+}
+__device__ __forceinline__ void rwait_lgkm2(int n, v4i &a, v4i &b) {
+#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(a), "+v"(b) :: "memory"); break;
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
+        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
+    }
+#undef RL_CASE
+}
+__device__ __forceinline__ void rwait_lgkm4(int n, v4i &a, v4i &b, v4i &c, v4i &d) {
+#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); break;
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
+        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
+    }
+#undef RL_CASE
 }
 
 // slab pieces issued in steps lo..hi (step u issues one when 1 <= (u mod 9) <= ppw); negative steps
@@ -146,7 +205,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
     int nstamp = 0;
     auto stamp = [&]() {
         if constexpr (Y355_DIAG) {
+#if Y355_DIAG == 2
+            if (p.stamps && lane == 0 && blockIdx.x < 1024 / NW && nstamp < 32)
+                p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
+#else
             if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
+#endif
         }
     };
     stamp();
@@ -255,54 +319,161 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
                             const int n_slab2 = n_slab + (c == 0 ? NIT : 0);
                             if (n_slab2 < n_later) n_later = n_slab2;
                         }
-                        if (first) rwait_vmcnt_dyn(n_first);
+                        // one wait where the two agree (every step past the tile's first PF): a branch diamond
+                        // here would end the scheduling region between the MFMAs and the next step's setup
+                        if (n_first == n_later) rwait_vmcnt_dyn(n_later);
+                        else if (first) rwait_vmcnt_dyn(n_first);
                         else rwait_vmcnt_dyn(n_later);
                     }
                     if (fine) stamp();
                 }
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(Y355_ABL & 8)) __builtin_amdgcn_s_barrier();
                 if (Y355_DIAG && first && c == (NCH > 1 ? 1 : 0)) stamp();
                 // ---- refill: one slab piece (t = 1..PPW) into the slot that died two barriers ago,
                 // W(s+1+PF) into the ring slot read in step s-2
-                if (t >= 1 && t <= PPW) {
-                    issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
-                }
-                {
+                const int wqs = wq;
+                auto refill = [&]() {
+                    if constexpr (Y355_ABL & 4) return;
+                    if (t >= 1 && t <= PPW) {
+                        issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
+                    }
                     const int ksn = s_idx + 1 + PF;
                     const bool nxt = ksn >= KS;
-                    issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wq + PF + 1));
-                }
+                    issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wqs + PF + 1));
+                };
+                if constexpr (Y355_RING_DMA_AT < 0 && !(Y355_ABL & 4)) refill();
                 const int ko = (t / 3) * PWL * 64;
                 const int acol = t % 3;
                 constexpr int dummy3 = 0;
                 (void)dummy3;
                 const int cur = ROLL ? (t & 1) : (s_idx & 1);     // rolled: every chunk starts with its B fragments in bfb[0]
                 v4i af[MT];
-                if (t == 0) {
-                    af[0] = *(const v4i *)(smem + abase[0][acol] + soff + ko);
-                    if constexpr (MT > 1) af[1] = *(const v4i *)(smem + abase[1][acol] + soff + ko);
-                } else {
-                    af[0] = afp[0];
-                    if constexpr (MT > 1) af[1] = afp[1];
-                }
-                if (s_idx + 1 < KS) {                            // B fragments of step s+1, under this step's MFMAs
-                    const char *wbn = smem + OFF_W + wrap(wq + 1) * WB + (wn * NT) * 1024 + lane * 16;
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
-                }
                 wq = wrap(wq + 1);
+                if constexpr (Y355_RING_AORDER == 0) {
+                    if (t == 0 && (!(Y355_ABL & 1) || c == 0)) {
+                        af[0] = *(const v4i *)(smem + abase[0][acol] + soff + ko);
+                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + abase[1][acol] + soff + ko);
+                    } else {
+                        af[0] = afp[0];
+                        if constexpr (MT > 1) af[1] = afp[1];
+                    }
+                    if constexpr (Y355_ABL & 1) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
-                    if (m == MT - 1 && t + 1 < SPC) {            // next step's first A fragments (same slab)
-                        const int ko2 = ((t + 1) / 3) * PWL * 64;
-                        const int acol2 = (t + 1) % 3;
-                        afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
-                        if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                        for (int m = 2; m < MT; ++m) af[m] = af[m & 1];
+                        afp[0] = af[0];
+                        if constexpr (MT > 1) afp[1] = af[1];
+                    }
+                    if ((Y355_ABL & 2) && s_idx + 1 < KS) {
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = bfb[cur][tt];
+                    }
+                    if (!(Y355_ABL & 2) && s_idx + 1 < KS) {     // B fragments of step s+1, under this step's MFMAs
+                        const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
                     }
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-                        acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m) {
+                        if (!(Y355_ABL & 1) && m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
+                        if (!(Y355_ABL & 1) && m == MT - 1 && t + 1 < SPC) {   // next step's first A fragments (same slab)
+                            const int ko2 = ((t + 1) / 3) * PWL * 64;
+                            const int acol2 = (t + 1) % 3;
+                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                        if constexpr (Y355_RING_DMA_AT >= 0) {
+                            if constexpr (Y355_RING_DMA_AT2 >= 0) {
+                                const int at = wave >= NW / 2 ? Y355_RING_DMA_AT2 : Y355_RING_DMA_AT;
+                                if (m == 0 || m == Y355_RING_DMA_AT2 || m == Y355_RING_DMA_AT) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (m == (at < MT ? at : MT - 1)) refill();
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            } else if (m == (Y355_RING_DMA_AT < MT ? Y355_RING_DMA_AT : MT - 1)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                refill();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                } else {
+                    // Hand-placed step (all of it volatile asm, so it executes in the order written).  Measured
+                    // with scratch/ubench/mfma_clean.hip on this part: a ds_read_b128 issued beside MFMAs costs
+                    // the SIMD ~9 cycles when the reads are spread one per MFMA and 17-28 when they go out in a
+                    // bunch (24 MFMAs + 10 reads + barrier: 917-932 cycles spread, 1082 bunched, 804 without
+                    // reads), and hipcc waits lgkmcnt(0) before the first MFMA that uses any of them.  Here one
+                    // read follows each of the step's first MFMAs -- this step's later A fragments, then B(s+1),
+                    // then the next step's first two A fragments -- and every m-tile waits (counted, LDS returns
+                    // in order) only for its own fragment.
+                    static_assert(Y355_RING_AORDER == 0 || MT == 6 || MT == 2, "hand-placed step: 6 or 2 m-tiles");
+                    const bool has_b = s_idx + 1 < KS;
+                    const bool has_a = t + 1 < SPC;
+                    unsigned abs_off = (unsigned)(soff + ko);
+                    asm volatile("" : "+s"(abs_off));             // opaque: keeps the per-read address adds next to the reads
+                    unsigned off2 = (unsigned)(soff + ((t + 1) / 3) * PWL * 64);
+                    asm volatile("" : "+s"(off2));
+                    const int acol2 = (t + 1) % 3;
+                    const unsigned wbn = (unsigned)(OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024) + lane * 16;
+                    // read queue of the step: af[G0..MT-1], then B(s+1)[0..3], then afp[0..G0-1]; entry k goes out
+                    // right after the step's k-th MFMA.  Everything below is constant after unrolling.
+                    constexpr int G0 = MT < 2 ? MT : 2;
+                    constexpr int NA = MT - G0;
+                    const int nbq = has_b ? NT : 0;
+                    const int Q = NA + nbq + (has_a ? G0 : 0);
+                    const int pre = (t == 0) ? G0 : 0;          // new slab: af[0..G0-1] were not prefetched
+                    if (t == 0) {
+#pragma unroll
+                        for (int m = 0; m < G0; ++m) rds128(af[m], (unsigned)abase[m][acol] + abs_off);
+                    } else {
+                        af[0] = afp[0];
+                        if constexpr (MT > 1) af[1] = afp[1];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        if (t == 0 || m >= G0) {
+                            const int done = NT * m < Q ? NT * m : Q;          // queue entries issued before this m-tile
+                            const int posm = (t == 0) ? m : m - G0;            // issue index of af[m]
+                            rwait_lgkm(pre + done - posm - 1);                // no register tie: a tie makes hipcc copy the
+                                                                              // fragment BEFORE the wait (stale data)
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) {
+#if Y355_RING_BUILTIN_MFMA
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (!(Y355_ABL & 16)) acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                            else asm volatile("" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bfb[cur][tt]));
+                            __builtin_amdgcn_sched_barrier(0);
+#else
+                            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bfb[cur][tt]));
+#endif
+                            const int k = m * NT + tt;
+                            if (k < Q) {
+                                if (k < NA) {
+                                    rds128(af[G0 + (k < NA ? k : 0)], (unsigned)abase[G0 + (k < NA ? k : 0)][acol] + abs_off);
+                                } else if (has_b && k - NA < NT) {
+                                    const int k2 = k - NA;
+                                    if (k2 == 0) rds128_o<0>(bfb[cur ^ 1][0], wbn);
+                                    else if (k2 == 1) rds128_o<1024>(bfb[cur ^ 1][1], wbn);
+                                    else if (k2 == 2) rds128_o<2048>(bfb[cur ^ 1][2], wbn);
+                                    else rds128_o<3072>(bfb[cur ^ 1][3], wbn);
+                                } else {
+                                    const int k3 = (k - NA - nbq) & (G0 - 1);
+                                    rds128(afp[k3], (unsigned)abase[k3][acol2] + off2);
+                                }
+                            }
+                        }
+                        if constexpr (Y355_RING_DMA_AT >= 0) {
+                            if constexpr (Y355_RING_DMA_AT2 >= 0) {
+                                const int at = wave >= NW / 2 ? Y355_RING_DMA_AT2 : Y355_RING_DMA_AT;
+                                if (m == (at < MT ? at : MT - 1)) refill();
+                            } else if (m == (Y355_RING_DMA_AT < MT ? Y355_RING_DMA_AT : MT - 1)) refill();
+                        }
+                    }
+                    // B(s+1) and the next step's first A fragments are in registers before the barrier
+                    if (has_b || has_a) rwait_lgkm(0);
                 }
             }
             // 9 steps: the last one (cur = 0) read the next chunk's first fragments into bfb[1]
@@ -322,6 +493,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
 #pragma unroll
             for (int t = 0; t < NT; ++t) bias[t] = p.bias_t[nb * BN + ncol + t];
             constexpr int RPM = POOL ? 1 : 4;                   // staged rows per m-tile and lane
+            // sh_l (a left requant shift; sh_r = 0 then) folded into the accumulator shift and the bias:
+            // ((t' << sh_l) + hm1 + rb) >> sh_r with t' = max(t, t << lk) equals the same form on T = t << sh_l
+            const int shl2 = rq.shl + rq.sh_l;
+            int bias2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bias2[t] = bias[t] << rq.sh_l;
+            auto requant = [&](int v, int t) {
+                int x = (v << shl2) + bias2[t];
+                x = max(x, x << rq.lk);
+                const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
+                return (x + rq.hm1 + rb) >> rq.sh_r;
+            };
+            unsigned int satx = 0;                              // sum of (clamped ^ unclamped): non-zero iff something saturated
             if (Y355_DIAG && first) stamp();
             char *stg = smem + (sl ^ 1) * SLABB;
             const int halo = p.out_halo;
@@ -374,7 +558,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
                     const int m = ps * MH + mm;
 #pragma unroll
                     for (int r = 0; r < RPM; ++r) {
-                        const int srow = POOL ? (wm * MT + m) * 4 + g : (wm * MT + m) * 16 + 4 * g + r;
                         const int lrow = POOL ? (wm * MH + mm) * 4 + g : (wm * MH + mm) * 16 + 4 * g + r;
                         unsigned int w = 0;
 #pragma unroll
@@ -386,9 +569,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
                             } else {
                                 v = acc[m][t][r];
                             }
-                            const int qq = y355_requant_fast(v, bias[t], rq);
+                            const int qq = requant(v, t);
                             const int q = y355_clamp8<int>(qq);
-                            nsat += (srow < OROWS && q != qq) ? 1u : 0u;
+                            satx += (unsigned int)(q ^ qq);         // v_xad_u32; the exact count is taken below, rarely
                             w |= (unsigned int)(q & 0xff) << (8 * t);
                         }
                         *(unsigned int *)(stg + lrow * SSTR + ncol) = w;
@@ -407,6 +590,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
                     if (!(row < OROWS && oy < Ho && ox < Wo)) dst = p.sink + tid * 16;
                     *(v4i *)dst = v;
                 }
+            }
+            if (satx) {                                         // cold: count the clamped outputs of real rows exactly
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < RPM; ++r) {
+                        const int srow = POOL ? (wm * MT + m) * 4 + g : (wm * MT + m) * 16 + 4 * g + r;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            int v;
+                            if constexpr (POOL) {
+                                const v4i a = acc[m][t];
+                                v = max(max(a[0], a[1]), max(a[2], a[3]));
+                            } else {
+                                v = acc[m][t][r];
+                            }
+                            const int qq = requant(v, t);
+                            nsat += (srow < OROWS && y355_clamp8<int>(qq) != qq) ? 1u : 0u;
+                        }
+                    }
             }
         }
         }
