@@ -249,6 +249,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
     const Requant rq = p.rq;
     unsigned int nsat = 0;
     bool first = true;
+#if defined(Y355_RING_PRIO)
+    if (Y355_RING_PRIO == 1 ? wave >= NW / 2 : wave < NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
     for (;;) {
         int ntile = tile + gridDim.x;

@@ -389,6 +389,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
 #pragma unroll
             for (int t = 0; t < NT; ++t) bias[t] = p.bias_t[nb * BN + ncol + t];
             char *stg = smem + OFF_STG;
+            // sh_l (a left requant shift; sh_r = 0 then) folded into the accumulator shift and the bias;
+            // saturation is detected with one v_xad per output and counted exactly only when it happened
+            const int shl2 = rq.shl + rq.sh_l;
+            int bias2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bias2[t] = bias[t] << rq.sh_l;
+            auto requant = [&](int v, int t) {
+                int x = (v << shl2) + bias2[t];
+                x = max(x, x << rq.lk);
+                const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
+                return (x + rq.hm1 + rb) >> rq.sh_r;
+            };
+            unsigned int satx = 0;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if constexpr (POOL) {
@@ -398,9 +411,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
                     for (int t = 0; t < NT; ++t) {
                         const v4i a = acc[m][t];
                         const int vmax = max(max(a[0], a[1]), max(a[2], a[3]));
-                        const int qq = y355_requant_fast(vmax, bias[t], rq);
+                        const int qq = requant(vmax, t);
                         q[t] = y355_clamp8<int>(qq);
-                        nsat += (srow < OROWS && q[t] != qq) ? 1u : 0u;
+                        satx += (unsigned int)(q[t] ^ qq);
                     }
                     store_bytes2<NT>((int8_t *)stg + srow * SSTR + ncol, q);
                 } else {
@@ -410,13 +423,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
                         int q[NT];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
-                            const int qq = y355_requant_fast(acc[m][t][r], bias[t], rq);
+                            const int qq = requant(acc[m][t][r], t);
                             q[t] = y355_clamp8<int>(qq);
-                            nsat += (srow < OROWS && q[t] != qq) ? 1u : 0u;
+                            satx += (unsigned int)(q[t] ^ qq);
                         }
                         store_bytes2<NT>((int8_t *)stg + srow * SSTR + ncol, q);
                     }
                 }
+            }
+            if (satx) {                                          // cold: exact count over the tile's real rows
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < (POOL ? 1 : 4); ++r) {
+                        const int srow = POOL ? (wm * MT + m) * 4 + g : (wm * MT + m) * 16 + 4 * g + r;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            int v;
+                            if constexpr (POOL) {
+                                const v4i a = acc[m][t];
+                                v = max(max(a[0], a[1]), max(a[2], a[3]));
+                            } else {
+                                v = acc[m][t][r];
+                            }
+                            const int qq = requant(v, t);
+                            nsat += (srow < OROWS && y355_clamp8<int>(qq) != qq) ? 1u : 0u;
+                        }
+                    }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stamp();
