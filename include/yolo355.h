@@ -155,6 +155,21 @@ int y355_conv3x3_i8_raw(int device_id, const int8_t *q_in, const int8_t *q_w, co
  *   y355_maxpool2x2_i8: nn.MaxPool2d(2, 2) (:61,65,71,77) on int8 [B][C][H][W] -> [B][C][H/2][W/2] */
 int y355_quantize_input_f32_i8(int device_id, const float *x, size_t n, int sa, int8_t *q, int64_t *clamped);
 int y355_maxpool2x2_i8(int device_id, const int8_t *in, int batch, int channels, int height, int width, int8_t *out);
+/* operator API of the wider model families, stand-alone: host pointers, fp32 NCHW, synchronous.
+ *   y355_reorg_f32: utils.modules.reorg_layer.forward (utils/modules.py:43-57), [B][C][H][W] -> [B][C*s*s][H/s][W/s]
+ *     with out channel (sy*s+sx)*C + c; data movement, bit-exact
+ *   y355_spp_f32: utils.modules.SPP.forward (:59-72), [B][C][H][W] -> [B][4C][H][W] =
+ *     cat(x, max_pool2d(x,5,1,2), max_pool2d(x,9,1,4), max_pool2d(x,13,1,6)); bit-exact
+ *   y355_conv2d_bf16: utils.modules.Conv2d.forward (:6-18) / backbone.darknet.Conv_BN_LeakyReLU (darknet.py:12-22) /
+ *     one resblock branch (:24-38) with BatchNorm folded into (w, bias) by the caller: conv (ksize 1, or 3 with
+ *     padding 1; stride 1, or 2 with ksize 3) + bias + LeakyReLU(neg_slope) [+ residual]; w [cout][cin][k][k];
+ *     residual (or NULL) and out are [B][cout][Ho][Wo].  Operands are rounded to bf16 (RNE), accumulation is
+ *     fp32 on the bf16 MFMA, the result is rounded to bf16: parity with the fp32 reference is a tolerance. */
+int y355_reorg_f32(int device_id, const float *x, int batch, int channels, int height, int width, int stride, float *out);
+int y355_spp_f32(int device_id, const float *x, int batch, int channels, int height, int width, float *out);
+int y355_conv2d_bf16(int device_id, const float *x, const float *w, const float *bias, const float *residual,
+                     int batch, int cin, int cout, int height, int width, int ksize, int stride, float neg_slope,
+                     float *out);
 /* head only: pred int8 [B][A*(5+C)][Hs][Ws] NCHW host -> detections (host), synchronous.
  * Replaces slim_yolo_v2.py:330-358 (decode, score, threshold, per-class NMS). */
 int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred,

@@ -37,3 +37,54 @@ def fp32_setup(case):
     layers = synth.make_fp32_model(arch, wseed, classes, A, pred_gain=pg, obj_bias=ob)
     x = np.concatenate([synth.make_images(s, 1, size[0], size[1], pattern=pattern) for s in iseeds])
     return layers, anchors, A, x
+
+
+# ---- operator-level cases of the wider model families: (tag, kind, params)
+#   reorg:  (B, C, H, W, stride)
+#   spp:    (B, C, H, W)
+#   conv:   (module, B, Cin, Cout, H, W, ksize, stride, leaky)   module in {"Conv2d", "Conv_BN_LeakyReLU"}
+#   resblock: (B, ch, H, W, nblocks)
+OPS_CASES = [
+    ("reorg_2", "reorg", (2, 6, 8, 12, 2)),
+    ("reorg_26", "reorg", (1, 64, 26, 26, 2)),
+    ("spp_13", "spp", (2, 5, 13, 13)),
+    ("spp_7x9", "spp", (1, 3, 7, 9)),
+    ("conv_3x3_l", "conv", ("Conv2d", 2, 40, 70, 13, 13, 3, 1, True)),
+    ("conv_1x1_relu", "conv", ("Conv2d", 1, 64, 32, 26, 26, 1, 1, False)),
+    ("conv_thin", "conv", ("Conv_BN_LeakyReLU", 1, 3, 32, 32, 48, 3, 1, True)),
+    ("conv_s2", "conv", ("Conv_BN_LeakyReLU", 2, 32, 64, 32, 32, 3, 2, True)),
+    ("conv_s2_odd", "conv", ("Conv_BN_LeakyReLU", 1, 64, 96, 15, 21, 3, 2, True)),
+    ("resblock_64", "resblock", (1, 64, 16, 16, 2)),
+]
+
+
+def ops_inputs(tag, kind, prm):
+    """Deterministic operands of an operator case from the build-owned generator (no torch RNG)."""
+    import numpy as np
+    from yolo355 import synth
+    seed = 7000 + sum(ord(ch) for ch in tag)
+    if kind == "reorg":
+        B, C, H, W, s = prm
+        return {"x": synth.uniform_pm1(seed, (B, C, H, W)).astype(np.float32)}
+    if kind == "spp":
+        B, C, H, W = prm
+        return {"x": synth.uniform_pm1(seed, (B, C, H, W)).astype(np.float32)}
+    if kind == "conv":
+        mod, B, Cin, Cout, H, W, k, s, leaky = prm
+        fan = Cin * k * k
+        d = {"x": synth.uniform_pm1(seed, (B, Cin, H, W)).astype(np.float32),
+             "w": (synth.uniform_pm1(seed + 1, (Cout, Cin, k, k)) * (2.0 / np.sqrt(fan))).astype(np.float32),
+             "b": (synth.uniform_pm1(seed + 2, (Cout,)) * 0.2).astype(np.float32)}
+        g, be, mu, var = synth.make_bn(seed + 3, Cout)
+        d.update(bn_w=g, bn_b=be, bn_mean=mu, bn_var=var)
+        return d
+    B, ch, H, W, nb = prm
+    d = {"x": synth.uniform_pm1(seed, (B, ch, H, W)).astype(np.float32)}
+    for i in range(nb):
+        for j, (ci, co, k) in enumerate([(ch, ch // 2, 1), (ch // 2, ch, 3)]):
+            s2 = seed + 10 * (2 * i + j + 1)
+            d["w%d_%d" % (i, j)] = (synth.uniform_pm1(s2, (co, ci, k, k)) * (2.0 / np.sqrt(ci * k * k))).astype(np.float32)
+            d["b%d_%d" % (i, j)] = (synth.uniform_pm1(s2 + 1, (co,)) * 0.2).astype(np.float32)
+            g, be, mu, var = synth.make_bn(s2 + 2, co)
+            d["bn%d_%d" % (i, j)] = np.stack([g, be, mu, var]).astype(np.float32)
+    return d

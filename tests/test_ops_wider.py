@@ -1,0 +1,132 @@
+"""Operator API of the wider model families: reorg_layer, SPP, 1x1 / stride-2 convolutions and
+the residual add.  CPU: the numpy restatement against the reference's golden outputs.  GPU: the HIP operators
+(through the C ABI and through the drop-in modules) against both."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import OPS_CASES, ops_inputs
+from oracle import ops_oracle as O
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops.npz"))
+# bf16 operands (rel. 2^-9 each) and a bf16 result (2^-9), K up to 64*9 products of O(1/sqrt(K)) terms:
+# |err| <= 2^-8 |y| + 0.02 covers it with margin; the fixtures' outputs are O(1..4)
+BF16_RTOL, BF16_ATOL = 2.0 ** -7, 0.03
+
+
+def oracle_out(tag, kind, prm, d):
+    if kind == "reorg":
+        return O.reorg(d["x"], prm[4])
+    if kind == "spp":
+        return O.spp(d["x"])
+    if kind == "conv":
+        mod, B, Cin, Cout, H, W, k, s, leaky = prm
+        slope = 0.1 if mod == "Conv_BN_LeakyReLU" else (0.125 if leaky else 0.0)
+        return O.conv_bn_act(d["x"], d["w"], d["b"], d["bn_w"], d["bn_b"], d["bn_mean"], d["bn_var"], stride=s, neg_slope=slope)
+    B, ch, H, W, nb = prm
+    blocks = [tuple((d["w%d_%d" % (i, j)], d["b%d_%d" % (i, j)], tuple(d["bn%d_%d" % (i, j)])) for j in range(2)) for i in range(nb)]
+    return O.resblock(d["x"], blocks)
+
+
+@pytest.mark.parametrize("case", OPS_CASES, ids=[c[0] for c in OPS_CASES])
+def test_oracle_matches_reference_golden(case):
+    tag, kind, prm = case
+    got = oracle_out(tag, kind, prm, ops_inputs(tag, kind, prm))
+    ref = GOLD[tag]
+    assert got.shape == ref.shape
+    if kind in ("reorg", "spp"):
+        assert np.array_equal(got.astype(np.float32), ref)          # data movement / max: bit-exact
+    else:
+        assert np.abs(got - ref).max() < 2e-5                       # fp32 reference vs float64 restatement
+
+
+def _module_for(kind, prm, d):
+    import torch
+    from yolo355.utils import modules as M
+    from yolo355.backbone import darknet as D
+
+    def load(m, w, b, bn):
+        m.convs[0].weight.data = torch.from_numpy(w.copy())
+        m.convs[0].bias.data = torch.from_numpy(b.copy())
+        m.convs[1].weight.data = torch.from_numpy(np.asarray(bn[0]).copy())
+        m.convs[1].bias.data = torch.from_numpy(np.asarray(bn[1]).copy())
+        m.convs[1].running_mean.data = torch.from_numpy(np.asarray(bn[2]).copy())
+        m.convs[1].running_var.data = torch.from_numpy(np.asarray(bn[3]).copy())
+    if kind == "reorg":
+        return M.reorg_layer(prm[4])
+    if kind == "spp":
+        return M.SPP()
+    if kind == "conv":
+        mod, B, Cin, Cout, H, W, k, s, leaky = prm
+        m = M.Conv2d(Cin, Cout, k, padding=k // 2, stride=s, leakyReLU=leaky) if mod == "Conv2d" \
+            else D.Conv_BN_LeakyReLU(Cin, Cout, k, padding=k // 2, stride=s)
+        load(m, d["w"], d["b"], [d["bn_w"], d["bn_b"], d["bn_mean"], d["bn_var"]])
+        return m.eval()
+    B, ch, H, W, nb = prm
+    m = D.resblock(ch, nblocks=nb)
+    for i in range(nb):
+        for j in range(2):
+            load(m.module_list[i][j], d["w%d_%d" % (i, j)], d["b%d_%d" % (i, j)], d["bn%d_%d" % (i, j)])
+    return m.eval()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", OPS_CASES, ids=[c[0] for c in OPS_CASES])
+def test_dropin_modules_match_reference(case):
+    """the drop-in modules (same constructor arguments and state_dict layout as the reference's) on cuda:0"""
+    import torch
+    tag, kind, prm = case
+    d = ops_inputs(tag, kind, prm)
+    m = _module_for(kind, prm, d)
+    with torch.no_grad():
+        y = m(torch.from_numpy(d["x"]).cuda())
+    assert y.is_cuda and y.dtype == torch.float32
+    got = y.cpu().numpy()
+    ref = GOLD[tag]
+    assert got.shape == ref.shape
+    if kind in ("reorg", "spp"):
+        assert np.array_equal(got, ref)
+        return
+    orc = oracle_out(tag, kind, prm, d)
+    for want in (ref, orc):
+        err = np.abs(got - want)
+        tol = BF16_ATOL * (3 if kind == "resblock" else 1) + BF16_RTOL * np.abs(want)
+        assert (err <= tol).all(), (tag, float(err.max()), float(np.abs(want).max()))
+    # and the error is bf16-sized, not a layout bug hiding under the tolerance
+    assert np.abs(got - ref).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_conv2d_bf16_is_exact_on_bf16_operands():
+    """small integers are exact in bf16 and their sums exact in fp32: the MFMA path must reproduce them exactly
+    (stride 2 on an odd map, 1x1, residual)"""
+    from yolo355 import engine as E, synth
+    rng = synth.uniform_pm1
+    x = np.round(rng(1, (2, 48, 9, 11)) * 4).astype(np.float32)
+    w = np.round(rng(2, (40, 48, 3, 3)) * 2).astype(np.float32)
+    b = np.round(rng(3, (40,)) * 8).astype(np.float32)
+    got = E.conv2d_bf16(x, w, b, stride=2, neg_slope=0.5)
+    want = O.conv2d(x, w, b, stride=2)
+    want = np.where(want >= 0, want, want * 0.5)
+    assert np.abs(want).max() < 256                                   # representable in bf16 after the epilogue
+    assert np.array_equal(got, want.astype(np.float32))
+    w1 = np.round(rng(4, (64, 48, 1, 1)) * 2).astype(np.float32)
+    res = np.round(rng(5, (2, 64, 9, 11)) * 16).astype(np.float32)
+    got = E.conv2d_bf16(x, w1, None, residual=res, stride=1, neg_slope=1.0)
+    want = O.conv2d(x, w1, np.zeros(64, np.float32)) + res
+    assert np.abs(want).max() < 256
+    assert np.array_equal(got, want.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_wider_ops_fail_loudly():
+    from yolo355 import engine as E
+    from yolo355._ffi import Y355Error
+    x = np.zeros((1, 4, 7, 8), np.float32)
+    with pytest.raises(Y355Error):
+        E.reorg_f32(x, 2)                                             # 7 is not divisible by 2
+    with pytest.raises(Y355Error):
+        E.conv2d_bf16(x, np.zeros((8, 4, 1, 1), np.float32), stride=2)   # stride 2 needs a 3x3 kernel
+    with pytest.raises(Y355Error):
+        E.conv2d_bf16(x, np.zeros((8, 4, 5, 5), np.float32))

@@ -1,4 +1,4 @@
-// yolo355 -- generic chunked-K implicit-GEMM convolution (3x3/pad 1 or 1x1, stride 1) for gfx950,
+// yolo355 -- generic chunked-K implicit-GEMM convolution (3x3/pad 1 or 1x1; stride 1, or 2 for 3x3) for gfx950,
 // in two arithmetic types:
 //   bf16 : BN-folded fp32 models run as bf16 x bf16 -> fp32 on v_mfma_f32_16x16x32_bf16
 //          (SlimYOLOv2.forward, models/slim_yolo_v2.py:549-622; utils.modules.Conv2d :6-18)
@@ -65,10 +65,12 @@ __device__ __forceinline__ long long requant_g(int acc, long long bias, const Re
     return y355_rne_shift<long long>(t, rq.sh);
 }
 
-template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN>
+template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S>
 __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
     constexpr bool THIN = (CHB == 32);           // 32 B per pixel: a k-step covers two taps
-    constexpr int PW = TW + 2, PH = TH + 2, NPIX = PH * PW;
+    // input patch of a TH x TW output tile: S*(T-1)+3 pixels a side (stride S, 3x3, pad 1)
+    constexpr int PW = S * (TW - 1) + 3, PH = S * (TH - 1) + 3, NPIX = PH * PW;
+    static_assert(S == 1 || (S == 2 && !POOL && !THIN), "stride 2: plain 64-byte-chunk tiles only");
     constexpr int STRIDE = CHB + 16;             // 16-byte pad: conflict-free ds_read_b128 across pixels
     constexpr int CPP = CHB / 16;
     constexpr int SUB = THIN ? 1 : CHB / 64;     // k-steps per tap and chunk
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
             oy = row / TW;
             ox = row % TW;
         }
-        abase[m] = (oy * PW + ox) * STRIDE + (THIN ? 0 : g * 16);
+        abase[m] = (S * oy * PW + S * ox) * STRIDE + (THIN ? 0 : g * 16);
     }
     int kofs[THIN ? 5 : 1];
     if constexpr (THIN) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
                     const int it = min(it0 + u * 256, ITEMS - 1);
                     const int pix = it / CPP, c = it % CPP;
                     const int py = pix / PW, px = pix % PW;
-                    const int gy = min(y0 + py, H + 1), gx = min(x0 + px, W + 1);
+                    const int gy = min(S * y0 + py, H + 1), gx = min(S * x0 + px, W + 1);
                     v[u] = *(const v4i *)(src0 + ((size_t)gy * (W + 2) + gx) * p.in_pb + c * 16);
                 }
 #pragma unroll
@@ -210,8 +212,9 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
     // ---- epilogue
     const int nlane = nb * BN + wn * (NT * 16) + li * NT;       // first of this lane's NT channels
     const int halo = p.out_halo;
-    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const int Ho = POOL ? (H >> 1) : (S == 2 ? (H + 1) >> 1 : H), Wo = POOL ? (W >> 1) : (S == 2 ? (W + 1) >> 1 : W);
     char *outb = p.out + (size_t)b * (Ho + 2 * halo) * (Wo + 2 * halo) * p.out_pb + p.out_off;
+    const char *resb = p.res ? p.res + (size_t)b * (Ho + 2) * (Wo + 2) * p.res_pb + p.res_off : nullptr;
     unsigned int nsat = 0;
 
     float biasf[NT];
@@ -232,6 +235,11 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
             for (int t = 0; t < NT; ++t) {
                 const float x = vf[t] + biasf[t];
                 y[t] = x >= 0.f ? x : x * slope;
+            }
+            if (resb && valid) {                        // the residual is a bf16 activation: exact in fp32
+                const unsigned short *r = (const unsigned short *)(resb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * p.res_pb) + nlane;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) y[t] += __uint_as_float((unsigned int)r[t] << 16);
             }
             if (valid) {
                 if (p.out_f32) {
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int row = (wm * MT + m) * 16 + 4 * g + r;
                 const int oy = y0 + row / TW, ox = x0 + row % TW;
-                const bool valid = row < BM && oy < H && ox < W;
+                const bool valid = row < BM && oy < Ho && ox < Wo;
                 float vf[NT];
                 int vi[NT];
 #pragma unroll
@@ -295,18 +303,18 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN>
+template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S = 1>
 struct ConvGInst {
-    static constexpr size_t LDS = (size_t)(TH + 2) * (TW + 2) * (CHB + 16);
+    static constexpr size_t LDS = (size_t)(S * (TH - 1) + 3) * (S * (TW - 1) + 3) * (CHB + 16);
     static void launch(const ConvGParams &p, int nblocks, hipStream_t s) {
-        hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN>), dim3(nblocks), dim3(256), LDS, s, p);
+        hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(256), LDS, s, p);
     }
     static int prepare() {
-        return (int)hipFuncSetAttribute((const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN>,
+        return (int)hipFuncSetAttribute((const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     static constexpr ConvGInfo info() {
-        return ConvGInfo{BF ? 1 : 0, CHB, BN, TH, TW, POOL ? 1 : 0, WM, WN, BN / 16 / WN, LDS, &launch, &prepare};
+        return ConvGInfo{BF ? 1 : 0, CHB, BN, TH, TW, POOL ? 1 : 0, WM, WN, BN / 16 / WN, S, LDS, &launch, &prepare};
     }
 };
 
@@ -319,7 +327,8 @@ struct ConvGInst {
     ConvGInst<BF, 256, 256, 13, 13, false, 1, 4>::info(),  /* 5 256 B chunks     (conv5..7)         */ \
     ConvGInst<BF, 256, 64, 13, 13, false, 4, 1>::info(),   /* 6 256 B, few couts (pred)             */ \
     ConvGInst<BF, 64, 64, 8, 16, false, 4, 1>::info(),     /* 7 small tiles, any shape              */ \
-    ConvGInst<BF, 64, 64, 8, 16, true, 4, 1>::info()       /* 8 small tiles, pooled                 */
+    ConvGInst<BF, 64, 64, 8, 16, true, 4, 1>::info(),      /* 8 small tiles, pooled                 */ \
+    ConvGInst<BF, 64, 64, 8, 16, false, 4, 1, 2>::info()   /* 9 stride 2 (darknet53 down-sampling)  */
 
 static const ConvGInfo g_convg[2][Y355_G_COUNT] = {{CONVG_SET(false)}, {CONVG_SET(true)}};
 
@@ -336,7 +345,8 @@ int y355_prepare_convg(void) {
 
 // Pick the instantiation for a layer: `in_pb` bytes per input pixel (multiple of 32), real output
 // channels `cout`, pooled or not, on an H x W map.
-int y355_convg_select(int in_pb, int cout, int pool, int H, int W) {
+int y355_convg_select(int in_pb, int cout, int pool, int H, int W, int stride) {
+    if (stride == 2) return (in_pb % 64 == 0 && !pool) ? 9 : -1;
     const bool small = (H < 13 || W < 13);
     if (in_pb == 32) return pool ? 0 : 1;
     if (pool) return small ? 8 : 3;

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <vector>
 
 int y355_fail(int code, const std::string &msg);
 #define OPSCHK(expr)                                                                        \
@@ -92,5 +93,211 @@ extern "C" int y355_maxpool2x2_i8(int device_id, const int8_t *in, int batch, in
     OPSCHK(hipMemcpy(out, d_out, nout, hipMemcpyDeviceToHost));
     (void)hipFree(d_in);
     (void)hipFree(d_out);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Operator API of the wider model families, stand-alone forms.  Host pointers, fp32
+// NCHW like the reference's tensors, synchronous.
+//   y355_reorg_f32    utils.modules.reorg_layer (utils/modules.py:43-57): out[b][(sy*s+sx)*C + c][y][x] =
+//                     in[b][c][s*y+sy][s*x+sx]  (data movement: bit-exact)
+//   y355_spp_f32      utils.modules.SPP (:59-72): cat[x, maxpool5(x), maxpool9(x), maxpool13(x)], stride 1,
+//                     padding k/2 with -inf  (max of fp32: bit-exact)
+//   y355_conv2d_bf16  utils.modules.Conv2d / backbone.darknet.Conv_BN_LeakyReLU / resblock with BN folded
+//                     by the caller: conv (1x1, or 3x3 pad 1; stride 1, or 2 for 3x3) + bias +
+//                     LeakyReLU(neg_slope) [+ residual], operands rounded to bf16, fp32 accumulation on
+//                     v_mfma_f32_16x16x32_bf16 (convg.hip), result rounded to bf16
+namespace {
+#define OPS2CHK(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            for (void *q_ : bufs) (void)hipFree(q_);                                        \
+            return y355_fail(Y355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                   \
+    } while (0)
+
+__global__ void reorg_f32_kernel(const float *in, float *out, int B, int C, int H, int W, int s) {
+    const int Ho = H / s, Wo = W / s;
+    const size_t n = (size_t)B * C * s * s * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+        const int oc = (int)((i / ((size_t)Wo * Ho)) % ((size_t)C * s * s));
+        const int b = (int)(i / ((size_t)Wo * Ho * C * s * s));
+        const int k = oc / C, c = oc % C, sy = k / s, sx = k % s;
+        out[i] = in[(((size_t)b * C + c) * H + (size_t)s * y + sy) * W + (size_t)s * x + sx];
+    }
+}
+
+__global__ void spp_f32_kernel(const float *in, float *out, size_t planes_b, int C, int H, int W) {
+    // one thread per input element: writes x and the three window maxima (windows clipped to the map:
+    // the -inf padding of max_pool2d never wins)
+    const size_t n = planes_b * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((size_t)W * H)) % C);
+        const size_t b = i / ((size_t)W * H * C);
+        const float *pl = in + (b * C + c) * (size_t)H * W;
+        float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const float v = pl[(size_t)yy * W + xx];
+                const int r = max(abs(dy), abs(dx));
+                m13 = fmaxf(m13, v);
+                if (r <= 4) m9 = fmaxf(m9, v);
+                if (r <= 2) m5 = fmaxf(m5, v);
+            }
+        }
+        float *ob = out + b * 4 * C * (size_t)H * W + (size_t)y * W + x;
+        const size_t cs = (size_t)H * W;
+        ob[(size_t)c * cs] = pl[(size_t)y * W + x];
+        ob[((size_t)C + c) * cs] = m5;
+        ob[((size_t)2 * C + c) * cs] = m9;
+        ob[((size_t)3 * C + c) * cs] = m13;
+    }
+}
+
+// fp32 NCHW -> bf16 NHWC with a one-pixel halo and cpad channels (buffer zeroed beforehand)
+__global__ void nchw_to_nhwc_bf16_kernel(const float *in, unsigned short *out, int B, int C, int H, int W, int cpad) {
+    const size_t n = (size_t)B * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((size_t)W * H)) % C);
+        const size_t b = i / ((size_t)W * H * C);
+        out[((b * (H + 2) + y + 1) * (size_t)(W + 2) + x + 1) * cpad + c] = __builtin_bit_cast(unsigned short, (__bf16)in[i]);
+    }
+}
+__global__ void nhwc_bf16_to_nchw_kernel(const unsigned short *in, float *out, int B, int C, int H, int W, int cpad) {
+    const size_t n = (size_t)B * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((size_t)W * H)) % C);
+        const size_t b = i / ((size_t)W * H * C);
+        out[i] = __uint_as_float((unsigned int)in[((b * (H + 2) + y + 1) * (size_t)(W + 2) + x + 1) * cpad + c] << 16);
+    }
+}
+inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 16384); }
+}  // namespace
+
+extern "C" int y355_reorg_f32(int device_id, const float *x, int batch, int channels, int height, int width, int stride, float *out) {
+    if (!x || !out) return y355_fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || channels < 1 || stride < 1 || height < stride || width < stride) return y355_fail(Y355_EINVAL, "bad shape");
+    if (height % stride || width % stride) return y355_fail(Y355_EINVAL, "reorg needs H, W divisible by the stride");
+    const size_t n = (size_t)batch * channels * height * width;
+    std::vector<void *> bufs;
+    float *d_in = nullptr, *d_out = nullptr;
+    OPS2CHK(hipSetDevice(device_id));
+    OPS2CHK(hipMalloc((void **)&d_in, n * 4)); bufs.push_back(d_in);
+    OPS2CHK(hipMalloc((void **)&d_out, n * 4)); bufs.push_back(d_out);
+    OPS2CHK(hipMemcpy(d_in, x, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(reorg_f32_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_in, d_out, batch, channels, height, width, stride);
+    OPS2CHK(hipGetLastError());
+    OPS2CHK(hipDeviceSynchronize());
+    OPS2CHK(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+extern "C" int y355_spp_f32(int device_id, const float *x, int batch, int channels, int height, int width, float *out) {
+    if (!x || !out) return y355_fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || channels < 1 || height < 1 || width < 1) return y355_fail(Y355_EINVAL, "bad shape");
+    const size_t n = (size_t)batch * channels * height * width;
+    std::vector<void *> bufs;
+    float *d_in = nullptr, *d_out = nullptr;
+    OPS2CHK(hipSetDevice(device_id));
+    OPS2CHK(hipMalloc((void **)&d_in, n * 4)); bufs.push_back(d_in);
+    OPS2CHK(hipMalloc((void **)&d_out, n * 16)); bufs.push_back(d_out);
+    OPS2CHK(hipMemcpy(d_in, x, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(spp_f32_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_in, d_out, (size_t)batch, channels, height, width);
+    OPS2CHK(hipGetLastError());
+    OPS2CHK(hipDeviceSynchronize());
+    OPS2CHK(hipMemcpy(out, d_out, n * 16, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+extern "C" int y355_conv2d_bf16(int device_id, const float *x, const float *w, const float *bias, const float *residual,
+                                int batch, int cin, int cout, int height, int width, int ksize, int stride, float neg_slope,
+                                float *out) {
+    if (!x || !w || !out) return y355_fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || cin < 1 || cout < 1 || height < 1 || width < 1) return y355_fail(Y355_EINVAL, "bad shape");
+    if (ksize != 1 && ksize != 3) return y355_fail(Y355_EINVAL, "kernel size 1 or 3 (padding k/2)");
+    if (stride != 1 && !(stride == 2 && ksize == 3)) return y355_fail(Y355_EINVAL, "stride 1, or 2 with a 3x3 kernel");
+    const bool thin = (cin <= 16 && ksize == 3 && stride == 1);
+    const int cin_pad = thin ? 16 : (cin + 31) / 32 * 32;
+    const int in_pb = cin_pad * 2;
+    const int kid = y355_convg_select(in_pb, cout, 0, height, width, stride);
+    const ConvGInfo *ki = y355_convg_kernel(1, kid);
+    if (!ki) return y355_fail(Y355_EINVAL, "no kernel for this shape");
+    const int Ho = stride == 2 ? (height + 1) / 2 : height, Wo = stride == 2 ? (width + 1) / 2 : width;
+    const int cout_pad = (cout + ki->bn - 1) / ki->bn * ki->bn;
+    const int taps = ksize * ksize;
+    const size_t wbytes = y355_convg_packed_bytes(*ki, in_pb, taps, cout_pad);
+    std::vector<char> wpk(wbytes);
+    y355_convg_pack(*ki, w, nullptr, cout, cin, ksize, in_pb, cout_pad, wpk.data());
+    std::vector<float> bpad(cout_pad, 0.f);
+    if (bias) std::copy(bias, bias + cout, bpad.begin());
+    const size_t n_in = (size_t)batch * cin * height * width, n_out = (size_t)batch * cout * Ho * Wo;
+    const size_t in_bytes = (size_t)batch * (height + 2) * (width + 2) * in_pb;
+    const size_t out_pb = (size_t)cout_pad * 2, out_bytes = (size_t)batch * (Ho + 2) * (Wo + 2) * out_pb;
+    std::vector<void *> bufs;
+    float *d_x = nullptr, *d_y = nullptr, *d_b = nullptr;
+    char *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_res = nullptr;
+    OPS2CHK(hipSetDevice(device_id));
+    if (int e = y355_prepare_convg()) return y355_fail(Y355_EHIP, std::string("kernel attributes: ") + hipGetErrorString((hipError_t)e));
+    OPS2CHK(hipMalloc((void **)&d_x, std::max(n_in, n_out) * 4)); bufs.push_back(d_x);
+    OPS2CHK(hipMalloc((void **)&d_y, n_out * 4)); bufs.push_back(d_y);
+    OPS2CHK(hipMalloc((void **)&d_b, cout_pad * 4)); bufs.push_back(d_b);
+    OPS2CHK(hipMalloc((void **)&d_in, in_bytes)); bufs.push_back(d_in);
+    OPS2CHK(hipMalloc((void **)&d_out, out_bytes)); bufs.push_back(d_out);
+    OPS2CHK(hipMalloc((void **)&d_w, wbytes)); bufs.push_back(d_w);
+    OPS2CHK(hipMemset(d_in, 0, in_bytes));
+    OPS2CHK(hipMemset(d_out, 0, out_bytes));
+    OPS2CHK(hipMemcpy(d_w, wpk.data(), wbytes, hipMemcpyHostToDevice));
+    OPS2CHK(hipMemcpy(d_b, bpad.data(), cout_pad * 4, hipMemcpyHostToDevice));
+    if (residual) {
+        OPS2CHK(hipMalloc((void **)&d_res, out_bytes)); bufs.push_back(d_res);
+        OPS2CHK(hipMemset(d_res, 0, out_bytes));
+        OPS2CHK(hipMemcpy(d_x, residual, n_out * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(grid_for(n_out)), dim3(256), 0, 0, d_x, (unsigned short *)d_res, batch, cout, Ho,
+                           Wo, cout_pad);
+        OPS2CHK(hipDeviceSynchronize());
+    }
+    OPS2CHK(hipMemcpy(d_x, x, n_in * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(grid_for(n_in)), dim3(256), 0, 0, d_x, (unsigned short *)d_in, batch, cin, height,
+                       width, cin_pad);
+    ConvGParams p{};
+    p.in = d_in;
+    p.out = d_out;
+    p.w = d_w;
+    p.bias_f = d_b;
+    p.B = batch;
+    p.H = height;
+    p.W = width;
+    p.in_pb = in_pb;
+    p.nchunks = in_pb / ki->chb;
+    p.out_pb = (int)out_pb;
+    p.out_off = 0;
+    p.out_halo = 1;
+    p.tiles_x = (Wo + ki->tw - 1) / ki->tw;
+    p.tiles_y = (Ho + ki->th - 1) / ki->th;
+    p.nblk = cout_pad / ki->bn;
+    p.taps = taps;
+    p.slope = neg_slope;
+    p.res = d_res;
+    p.res_pb = (int)out_pb;
+    p.res_off = 0;
+    ki->launch(p, p.tiles_x * p.tiles_y * p.nblk * batch, 0);
+    OPS2CHK(hipGetLastError());
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_kernel, dim3(grid_for(n_out)), dim3(256), 0, 0, (const unsigned short *)d_out, d_y, batch, cout,
+                       Ho, Wo, cout_pad);
+    OPS2CHK(hipGetLastError());
+    OPS2CHK(hipDeviceSynchronize());
+    OPS2CHK(hipMemcpy(out, d_y, n_out * 4, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
     return 0;
 }

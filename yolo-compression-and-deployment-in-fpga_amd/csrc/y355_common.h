@@ -228,6 +228,10 @@ struct ConvGParams {
     float slope;              // bf16: y = x >= 0 ? x : slope * x
     int out_f32;              // bf16: store fp32 (prediction layers)
     RequantG rq;
+    // bf16: residual added after the activation (backbone/darknet.py:36 `module(x) + x`), same layout as
+    // `out` (halo, pixel pitch res_pb, byte offset res_off of channel 0); null = none
+    const char *res;
+    int res_pb, res_off;
 };
 
 struct Conv1FParams {
@@ -241,14 +245,15 @@ struct Conv1FParams {
 
 struct ConvGInfo {
     int bf, chb, bn, th, tw, pool, wm, wn, nt;
+    int stride;               // 1, or 2 (3x3 / pad 1 / stride 2: backbone/darknet.py:124-141)
     size_t lds_bytes;
     void (*launch)(const ConvGParams &p, int nblocks, hipStream_t s);
     int (*prepare)(void);
 };
-#define Y355_G_COUNT 9
+#define Y355_G_COUNT 10
 const ConvGInfo *y355_convg_kernel(int bf, int id);
 int y355_prepare_convg(void);
-int y355_convg_select(int in_pb, int cout, int pool, int H, int W);
+int y355_convg_select(int in_pb, int cout, int pool, int H, int W, int stride = 1);
 int y355_convg_ksteps(const ConvGInfo &ki, int in_pb, int taps);
 size_t y355_convg_packed_bytes(const ConvGInfo &ki, int in_pb, int taps, int cout_pad);
 void y355_convg_pack(const ConvGInfo &ki, const float *w_f, const int8_t *w_q, int cout, int cin, int ksize,

@@ -323,3 +323,55 @@ def maxpool2x2_i8(q, device_id=0):
     out = np.empty((B, Cc, H // 2, W // 2), np.int8)
     _ffi.check(lib.y355_maxpool2x2_i8(int(device_id), qi.ctypes.data, B, Cc, H, W, out.ctypes.data))
     return out
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("yolo355 needs a GPU; there is no CPU fallback")
+
+
+def reorg_f32(x, stride, device_id=0):
+    """utils.modules.reorg_layer.forward on fp32 NCHW (y355_reorg_f32); bit-exact data movement."""
+    lib = _ffi.lib()
+    _need_gpu()
+    xi = np.ascontiguousarray(x, dtype=np.float32)
+    B, Cc, H, W = xi.shape
+    s = int(stride)
+    out = np.empty((B, Cc * s * s, H // max(s, 1), W // max(s, 1)), np.float32)
+    _ffi.check(lib.y355_reorg_f32(int(device_id), xi.ctypes.data, B, Cc, H, W, s, out.ctypes.data))
+    return out
+
+
+def spp_f32(x, device_id=0):
+    """utils.modules.SPP.forward on fp32 NCHW (y355_spp_f32); bit-exact."""
+    lib = _ffi.lib()
+    _need_gpu()
+    xi = np.ascontiguousarray(x, dtype=np.float32)
+    B, Cc, H, W = xi.shape
+    out = np.empty((B, 4 * Cc, H, W), np.float32)
+    _ffi.check(lib.y355_spp_f32(int(device_id), xi.ctypes.data, B, Cc, H, W, out.ctypes.data))
+    return out
+
+
+def conv2d_bf16(x, w, bias=None, residual=None, stride=1, neg_slope=1.0, device_id=0):
+    """conv (1x1, or 3x3 pad 1; stride 1, or 2 for 3x3) + bias + LeakyReLU(neg_slope) [+ residual] on the bf16 MFMA
+    (y355_conv2d_bf16).  fp32 NCHW in and out; operands and result are rounded to bf16."""
+    lib = _ffi.lib()
+    _need_gpu()
+    xi = np.ascontiguousarray(x, dtype=np.float32)
+    wi = np.ascontiguousarray(w, dtype=np.float32)
+    B, Cin, H, W = xi.shape
+    Cout, Cin2, k, k2 = wi.shape
+    if Cin2 != Cin or k != k2:
+        raise ValueError("weight shape %s does not match the input's %d channels" % (wi.shape, Cin))
+    s = int(stride)
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if s == 2 else (H, W)
+    bi = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    ri = None if residual is None else np.ascontiguousarray(residual, dtype=np.float32)
+    if ri is not None and ri.shape != (B, Cout, Ho, Wo):
+        raise ValueError("residual shape %s, expected %s" % (ri.shape, (B, Cout, Ho, Wo)))
+    out = np.empty((B, Cout, Ho, Wo), np.float32)
+    _ffi.check(lib.y355_conv2d_bf16(int(device_id), xi.ctypes.data, wi.ctypes.data, None if bi is None else bi.ctypes.data,
+                                    None if ri is None else ri.ctypes.data, B, Cin, Cout, H, W, int(k), s, float(neg_slope),
+                                    out.ctypes.data))
+    return out

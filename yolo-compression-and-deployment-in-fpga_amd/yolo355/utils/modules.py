@@ -60,10 +60,35 @@ def folded_f32(convs):
     return w.float().numpy(), b.float().numpy()
 
 
+def _conv_bn_act_forward(convs, x, residual=None):
+    """Eval-mode forward of nn.Sequential(conv, [BatchNorm2d], [LeakyReLU | ReLU]) through y355_conv2d_bf16."""
+    from ..engine import conv2d_bf16
+    conv = convs[0]
+    k = conv.kernel_size[0]
+    if conv.kernel_size[0] != conv.kernel_size[1] or k not in (1, 3) or conv.padding != (k // 2, k // 2) \
+            or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride[0] != conv.stride[1]:
+        raise NotImplementedError("yolo355 conv: 1x1, or 3x3 with padding 1; stride 1 (or 2 for 3x3); no dilation / groups")
+    if any(isinstance(m, nn.BatchNorm2d) and m.training for m in convs):
+        raise NotImplementedError("yolo355 is an inference engine: call .eval() first (BatchNorm uses running statistics)")
+    slope = 1.0
+    for m in convs:
+        if isinstance(m, nn.LeakyReLU):
+            slope = float(m.negative_slope)
+        elif isinstance(m, nn.ReLU):
+            slope = 0.0
+    w, b = folded_f32(convs)
+    dev = x.device
+    y = conv2d_bf16(x.detach().float().cpu().numpy(), w, b,
+                    None if residual is None else residual.detach().float().cpu().numpy(),
+                    stride=conv.stride[0], neg_slope=slope, device_id=dev.index if x.is_cuda and dev.index is not None else 0)
+    return torch.from_numpy(y).to(dev)
+
+
 class Conv2d(nn.Module):
     """conv + BatchNorm + LeakyReLU(0.125)/ReLU (utils/modules.py:6-18): the building block of the
-    fp32 models (SlimYOLOv2, the YOLOv3tiny head).  The models fold BN at load time and run whole
-    graphs through the engine; a stand-alone call of this module is not built."""
+    fp32 models (SlimYOLOv2, YOLOv2/v3 heads).  The whole-model classes fold BN at load time and run
+    their graphs through y355_net; a stand-alone call folds BN (eval mode) and runs this one layer on
+    the bf16 MFMA through y355_conv2d_bf16 -- operands and result rounded to bf16."""
 
     def __init__(self, in_channels, out_channels, ksize, padding=0, stride=1, dilation=1, leakyReLU=False):
         super().__init__()
@@ -73,8 +98,7 @@ class Conv2d(nn.Module):
             nn.LeakyReLU(0.125, inplace=True) if leakyReLU else nn.ReLU(inplace=True))
 
     def forward(self, x):
-        raise NotImplementedError("yolo355: stand-alone Conv2d.forward is not built; the fp32 models "
-                                  "(SlimYOLOv2, YOLOv3tiny) run whole graphs through y355_net")
+        return _conv_bn_act_forward(self.convs, x)
 
 
 class Conv2d_fuse(_FusedBase):
@@ -110,18 +134,24 @@ class Conv2d_fuse_nobias(_FusedBase):
 
 
 class reorg_layer(nn.Module):
-    """utils/modules.py:43-57 -- only used by yolo_v2 (out of this round's scope)."""
+    """utils/modules.py:43-57: [B, C, H, W] -> [B, C*s*s, H/s, W/s], out channel (sy*s + sx)*C + c (used by yolo_v2).
+    Runs y355_reorg_f32: bit-exact."""
 
     def __init__(self, stride):
         super().__init__()
         self.stride = stride
 
     def forward(self, x):
-        raise NotImplementedError("yolo355: reorg_layer is not on the slim-YOLOv2 path (SURVEY.md 8f)")
+        from ..engine import reorg_f32
+        y = reorg_f32(x.detach().float().cpu().numpy(), self.stride, device_id=x.device.index if x.is_cuda and x.device.index is not None else 0)
+        return torch.from_numpy(y).to(x.device)
 
 
 class SPP(nn.Module):
-    """utils/modules.py:59-72 -- only used by yolo_v3_spp (out of scope)."""
+    """utils/modules.py:59-72: cat(x, max_pool 5, 9, 13 (stride 1, same size)) (used by yolo_v3_spp).
+    Runs y355_spp_f32: bit-exact."""
 
     def forward(self, x):
-        raise NotImplementedError("yolo355: SPP is not on the slim-YOLOv2 path (SURVEY.md 8f)")
+        from ..engine import spp_f32
+        y = spp_f32(x.detach().float().cpu().numpy(), device_id=x.device.index if x.is_cuda and x.device.index is not None else 0)
+        return torch.from_numpy(y).to(x.device)
