@@ -164,12 +164,24 @@ int y355_maxpool2x2_i8(int device_id, const int8_t *in, int batch, int channels,
  *     one resblock branch (:24-38) with BatchNorm folded into (w, bias) by the caller: conv (ksize 1, or 3 with
  *     padding 1; stride 1, or 2 with ksize 3) + bias + LeakyReLU(neg_slope) [+ residual]; w [cout][cin][k][k];
  *     residual (or NULL) and out are [B][cout][Ho][Wo].  Operands are rounded to bf16 (RNE), accumulation is
- *     fp32 on the bf16 MFMA, the result is rounded to bf16: parity with the fp32 reference is a tolerance. */
+ *     fp32 on the bf16 MFMA, the result is rounded to bf16 (out_fp32 != 0: kept in fp32, as the engines keep
+ *     prediction maps; no residual then): parity with the fp32 reference is a tolerance.
+ *   y355_maxpool2x2_f32: nn.MaxPool2d((2,2), 2) (backbone/darknet.py:49,55,63,74,83) on fp32; bit-exact */
 int y355_reorg_f32(int device_id, const float *x, int batch, int channels, int height, int width, int stride, float *out);
 int y355_spp_f32(int device_id, const float *x, int batch, int channels, int height, int width, float *out);
 int y355_conv2d_bf16(int device_id, const float *x, const float *w, const float *bias, const float *residual,
                      int batch, int cin, int cout, int height, int width, int ksize, int stride, float neg_slope,
-                     float *out);
+                     int out_fp32, float *out);
+int y355_maxpool2x2_f32(int device_id, const float *in, int batch, int channels, int height, int width, float *out);
+/* detection head on fp32 prediction maps, stand-alone (models/yolo_v2.py:183-210; models/tiny_yolo_v3.py:202-262):
+ * pred[l] = NCHW [B][A*(5+C)][hs[l]][ws[l]] (host), 1 or 2 levels, channel layout [obj x A | cls x A*C | txtytwth x A*4];
+ * anchors [nlev][A][2]; wh_mul = the stride for anchors in grid units (yolo_v2), 1 for anchors in pixels (v3 family).
+ * Outputs as y355_forward: boxes f32 [B][max_det][4] normalised x1y1x2y2, scores, classes, counts; anchor-index order.
+ * At most 4096 anchors per image. */
+int y355_head_f32(int device_id, int nlev, const float *const *pred, const int *hs, const int *ws, const float *strides,
+                  const float *anchors, int num_anchors, int num_classes, int in_h, int in_w, float wh_mul,
+                  float conf_thresh, float nms_thresh, int batch, int max_det, float *boxes, float *scores,
+                  int32_t *cls, int32_t *count);
 /* head only: pred int8 [B][A*(5+C)][Hs][Ws] NCHW host -> detections (host), synchronous.
  * Replaces slim_yolo_v2.py:330-358 (decode, score, threshold, per-class NMS). */
 int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred,

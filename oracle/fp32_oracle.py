@@ -123,3 +123,38 @@ def detect(arch, layers, x, input_size, anchors, num_classes, conf_thresh=0.01, 
     dets = [O.postprocess(box[i], sc[i], conf_thresh, nms_thresh, num_classes) for i in range(box.shape[0])]
     return dict(preds=[p.numpy() for p in preds], taps=[t.numpy() for t in taps], box=np.asarray(box),
                 cls_scores=np.asarray(sc), dets=dets)
+
+
+def head_decode_v2(pred_f32, input_size, anchors, num_classes, stride):
+    """models/yolo_v2.py:40-93, 183-204 (create_grid with ws = w // stride, decode_xywh * stride, / scale, clamp,
+    sigmoid(conf) * softmax(cls)) for every image.  pred: [B, A*(5+C), H, W].  Returns (bbox [B,N,4], scores [B,N,C])."""
+    pred = torch.as_tensor(pred_f32, dtype=torch.float32)
+    A, C = len(anchors), num_classes
+    B, abC, H, W = pred.shape
+    w, h = input_size[1], input_size[0]
+    ws, hs = w // stride, h // stride
+    assert (hs, ws) == (H, W)
+    p = pred.permute(0, 2, 3, 1).contiguous().view(B, H * W, abC)
+    conf = p[:, :, :A].contiguous().view(B, H * W * A, 1)
+    cls = p[:, :, A:(1 + C) * A].contiguous().view(B, H * W * A, C)
+    txty = p[:, :, (1 + C) * A:].contiguous().view(B, H * W, A, 4)
+    gy, gx = torch.meshgrid([torch.arange(hs), torch.arange(ws)], indexing="ij")
+    grid_xy = torch.stack([gx, gy], dim=-1).float().view(1, hs * ws, 1, 2)
+    anchor_wh = torch.tensor(anchors, dtype=torch.float32).repeat(hs * ws, 1, 1).unsqueeze(0)
+    xy = torch.sigmoid(txty[..., :2]) + grid_xy
+    wh = torch.exp(txty[..., 2:]) * anchor_wh
+    xywh = torch.cat([xy, wh], -1).view(B, H * W * A, 4) * stride
+    box = torch.zeros_like(xywh)
+    box[:, :, 0] = xywh[:, :, 0] - xywh[:, :, 2] / 2
+    box[:, :, 1] = xywh[:, :, 1] - xywh[:, :, 3] / 2
+    box[:, :, 2] = xywh[:, :, 0] + xywh[:, :, 2] / 2
+    box[:, :, 3] = xywh[:, :, 1] + xywh[:, :, 3] / 2
+    scale = torch.tensor([[[w, h, w, h]]]).float()
+    box = torch.clamp(box / scale, 0., 1.)
+    return box.numpy(), (torch.softmax(cls, 2) * torch.sigmoid(conf)).numpy()
+
+
+def detect_v2(pred_f32, anchors, num_classes, input_size, stride, conf_thresh, nms_thresh):
+    """decode + postprocess (models/yolo_v2.py:137-163 = slim_yolo_v2.py:176-210) of a prediction map, per image."""
+    box, sc = head_decode_v2(pred_f32, input_size, anchors, num_classes, stride)
+    return [O.postprocess(box[i], sc[i], conf_thresh, nms_thresh, num_classes) for i in range(box.shape[0])]

@@ -88,3 +88,35 @@ def ops_inputs(tag, kind, prm):
             g, be, mu, var = synth.make_bn(s2 + 2, co)
             d["bn%d_%d" % (i, j)] = np.stack([g, be, mu, var]).astype(np.float32)
     return d
+
+
+def synth_state_dict(sd, seed, weight_gain=2.0):
+    """Fill a state_dict (reference model or drop-in: same keys) from the build-owned generator, by key and shape:
+    conv weights U(+-gain/sqrt(fan_in)), biases U(+-0.1), BatchNorm eval statistics from synth.make_bn."""
+    import numpy as np
+    import torch
+    from yolo355 import synth
+    out = {}
+    bn_cache = {}
+    for i, (k, v) in enumerate(sd.items()):
+        shape = tuple(v.shape)
+        s = seed + 13 * i
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith(".weight") and len(shape) == 4:
+            fan = shape[1] * shape[2] * shape[3]
+            gain = weight_gain * (8.0 if k.startswith("pred") else 1.0)      # lively logits: boxes and scores that differ
+            out[k] = torch.from_numpy((synth.uniform_pm1(s, shape) * (gain / np.sqrt(fan))).astype(np.float32))
+        elif len(shape) == 1 and (k.endswith("running_var") or k.endswith("running_mean") or ".1." in k):
+            base = k.rsplit(".", 1)[0]
+            if base not in bn_cache:
+                bn_cache[base] = synth.make_bn(seed + 7 * len(bn_cache) + 1, shape[0])
+            g, be, mu, var = bn_cache[base]
+            out[k] = torch.from_numpy({"weight": g, "bias": be, "running_mean": mu, "running_var": var}[k.rsplit(".", 1)[1]].copy())
+        else:
+            out[k] = torch.from_numpy((synth.uniform_pm1(s, shape) * 0.1).astype(np.float32))
+    return out
+
+
+# whole-model cases of the wider families, composed from the operator API: (tag, class, input size, classes, seed)
+WIDE_MODEL_CASES = [("yolo_v2_224", "myYOLOv2", [224, 224], 20, 4100)]

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Golden vectors of the wider model families, produced by running the REFERENCE's own
+myYOLOv2 (models/yolo_v2.py) in the build container, eval mode, CPU fp32.  Weights and inputs come from the
+build-owned generator (tests/cases.py:synth_state_dict, yolo355.synth.make_images); stored: the prediction map
+and the detections at conf 0.05.
+
+    python tests/golden/gen_golden_models_wide.py        # rewrites tests/golden/models_wide.npz
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_golden as G  # noqa: E402
+
+import torch  # noqa: E402
+from yolo355 import synth  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(HERE))
+from cases import WIDE_MODEL_CASES, synth_state_dict  # noqa: E402
+
+
+def main():
+    G.import_reference()
+    out = {}
+    for tag, cls, size, classes, seed in WIDE_MODEL_CASES:
+        mod = importlib.import_module("models.yolo_v2")
+        m = getattr(mod, cls)("cpu", input_size=size, num_classes=classes, trainable=False, conf_thresh=0.05, nms_thresh=0.5,
+                              anchor_size=synth.ANCHOR_SIZE)
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed))
+        m.eval()
+        grabbed = {}
+        m.pred.register_forward_hook(lambda mm, i, o: grabbed.__setitem__("pred", o.detach().numpy().copy()))
+        x = torch.from_numpy(synth.make_images(seed + 1, 1, size[0], size[1]))
+        with torch.no_grad():
+            b, s, c = m(x)
+        out[tag + "_pred"] = grabbed["pred"].astype(np.float32)
+        out[tag + "_boxes"] = np.asarray(b, np.float32)
+        out[tag + "_scores"] = np.asarray(s, np.float32)
+        out[tag + "_cls"] = np.asarray(c, np.int64)
+        print(tag, grabbed["pred"].shape, float(np.abs(grabbed["pred"]).max()), len(s))
+    np.savez_compressed(os.path.join(HERE, "models_wide.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

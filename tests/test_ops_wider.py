@@ -130,3 +130,55 @@ def test_wider_ops_fail_loudly():
         E.conv2d_bf16(x, np.zeros((8, 4, 1, 1), np.float32), stride=2)   # stride 2 needs a 3x3 kernel
     with pytest.raises(Y355Error):
         E.conv2d_bf16(x, np.zeros((8, 4, 5, 5), np.float32))
+
+
+# ---- whole models of the wider families, composed from the operator API ---------------------------------
+from cases import WIDE_MODEL_CASES, synth_state_dict  # noqa: E402
+from helpers import dets_close  # noqa: E402
+
+WGOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "models_wide.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WIDE_MODEL_CASES, ids=[c[0] for c in WIDE_MODEL_CASES])
+def test_yolo_v2_dropin_matches_reference(case):
+    """myYOLOv2 (DarkNet-19, reorg route, stride-32 head) with the reference's constructor and state_dict layout:
+    prediction map within the bf16 tolerance of the reference's fp32 map, detections close, and the head EXACT on
+    the engine's own map (decode + NMS restated in numpy)."""
+    import torch
+    from yolo355 import synth, engine as E
+    from yolo355.models.yolo_v2 import myYOLOv2
+    from oracle import fp32_oracle as F
+    tag, cls, size, classes, seed = case
+    m = myYOLOv2("cuda", input_size=size, num_classes=classes, trainable=False, conf_thresh=0.05, nms_thresh=0.5,
+                 anchor_size=synth.ANCHOR_SIZE)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed))
+    m.eval()
+    x = torch.from_numpy(synth.make_images(seed + 1, 1, size[0], size[1])).cuda()
+    with torch.no_grad():
+        pred = m.prediction_map(x)
+    ref = WGOLD[tag + "_pred"]
+    assert pred.shape == ref.shape
+    err = np.abs(pred - ref)
+    # 23 bf16 layers: the error of a map with |values| up to ~7 stays below 2 % of the range, mean below 0.5 %
+    assert err.max() < 0.02 * np.abs(ref).max() + 0.05, float(err.max())
+    assert err.mean() < 0.005 * np.abs(ref).max(), float(err.mean())
+    b, s, c = m(x)
+    assert b.dtype == np.float32 and s.dtype == np.float32 and c.dtype == np.int64 and b.flags.writeable
+    ok, why = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b, s, c), iou_min=0.7, score_tol=0.08)
+    assert ok, why
+    # the head itself: exact decode + NMS of the engine's own prediction map
+    want = F.detect_v2(pred, synth.ANCHOR_SIZE, classes, size, 32, 0.05, 0.5)[0]
+    assert len(want[1]) == len(s) and np.array_equal(want[2], c)
+    assert np.abs(want[0] - b).max() < 2e-5 and np.abs(want[1] - s).max() < 2e-6
+
+
+@pytest.mark.parametrize("case", WIDE_MODEL_CASES, ids=[c[0] for c in WIDE_MODEL_CASES])
+def test_v2_head_oracle_matches_reference_golden(case):
+    """CPU: decode + per-class NMS of the reference's own prediction map reproduce the reference's detections"""
+    from yolo355 import synth
+    from oracle import fp32_oracle as F
+    tag, cls, size, classes, seed = case
+    d = F.detect_v2(WGOLD[tag + "_pred"], synth.ANCHOR_SIZE, classes, size, 32, 0.05, 0.5)[0]
+    assert np.array_equal(d[0], WGOLD[tag + "_boxes"]) and np.array_equal(d[1], WGOLD[tag + "_scores"])
+    assert np.array_equal(d[2], WGOLD[tag + "_cls"])

@@ -827,3 +827,116 @@ extern "C" int y355_net_profile_get(y355_net *h, float *ms) {
     for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Stand-alone detection head on fp32 prediction maps (operator API of the wider model families):
+// models/yolo_v2.py:183-210 (one level, anchors in grid units: wh_mul = stride), models/tiny_yolo_v3.py /
+// models/yolo_v3.py:207-262 (anchors in pixels: wh_mul = 1): decode, sigmoid(obj) * softmax(cls), threshold,
+// per-class NMS, survivors in anchor-index order.  Host pointers, synchronous; pred[l] is NCHW
+// [B][A*(5+C)][hs[l]][ws[l]] like the reference's tensors.
+extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, const int *hs, const int *ws, const float *strides,
+                             const float *anchors, int num_anchors, int num_classes, int in_h, int in_w, float wh_mul,
+                             float conf_thresh, float nms_thresh, int batch, int max_det, float *boxes, float *scores,
+                             int32_t *cls, int32_t *count) {
+    if (!pred || !hs || !ws || !strides || !anchors || !boxes || !scores || !cls || !count) return y355_fail(Y355_EINVAL, "null argument");
+    if (nlev < 1 || nlev > 2) return y355_fail(Y355_EINVAL, "1 or 2 prediction levels (the 3-level yolo_v3 head exceeds the 4096-anchor head)");
+    if (num_anchors < 1 || num_anchors * nlev > Y355_HEAD_MAXA || num_classes < 1 || batch < 1 || max_det < 1)
+        return y355_fail(Y355_EINVAL, "bad anchors / classes / batch / max_det");
+    const int predc = num_anchors * (5 + num_classes);
+    if (predc > 256) return y355_fail(Y355_EINVAL, "A*(5+C) > 256 not supported");
+    int N = 0;
+    for (int l = 0; l < nlev; ++l) {
+        if (!pred[l] || hs[l] < 1 || ws[l] < 1) return y355_fail(Y355_EINVAL, "bad prediction level");
+        N += hs[l] * ws[l] * num_anchors;
+    }
+    if (N > Y355_NMS_CAP) return y355_fail(Y355_EINVAL, "more than 4096 anchors per image not supported");
+    if (max_det > N) max_det = N;
+    HIPCHK(hipSetDevice(device_id));
+    if (int e = y355_prepare_kernels()) return e;
+    std::vector<void *> bufs;
+    auto alloc = [&](void **p, size_t bytes, bool zero) -> int {
+        if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) return 1;
+        bufs.push_back(*p);
+        if (zero && hipMemset(*p, 0, bytes ? bytes : 16) != hipSuccess) return 1;
+        return 0;
+    };
+    auto release = [&]() { for (void *q : bufs) (void)hipFree(q); };
+    const int B = batch;
+    const size_t cap = Y355_NMS_CAP;
+    const int cpad = predc <= 64 ? 64 : predc <= 128 ? 128 : 256;
+    y355_head_ws w{};
+    int rc = 0;
+    float *d_pred[2] = {nullptr, nullptr};
+    for (int l = 0; l < nlev && !rc; ++l) {
+        // NCHW -> NHWC with cpad channels
+        const size_t px = (size_t)hs[l] * ws[l];
+        std::vector<float> t((size_t)B * px * cpad, 0.f);
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < predc; ++c) {
+                const float *src = pred[l] + ((size_t)b * predc + c) * px;
+                for (size_t i = 0; i < px; ++i) t[((size_t)b * px + i) * cpad + c] = src[i];
+            }
+        rc = alloc((void **)&d_pred[l], t.size() * 4 + 1024, false);
+        if (!rc && hipMemcpy(d_pred[l], t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+    }
+    float *d_box = nullptr, *d_score = nullptr;
+    int *d_cls = nullptr, *d_count = nullptr;
+    if (!rc) rc = alloc(&w.cbox, sizeof(float) * 4 * cap * B, false);
+    if (!rc) rc = alloc(&w.cscore, sizeof(float) * cap * B, false);
+    if (!rc) rc = alloc(&w.ccls, sizeof(int) * cap * B, false);
+    if (!rc) rc = alloc(&w.corig, sizeof(int) * cap * B, false);
+    if (!rc) rc = alloc(&w.count, sizeof(int) * B, true);
+    if (!rc) rc = alloc(&w.edges, sizeof(unsigned int) * 64 * cap * B, false);
+    if (!rc) rc = alloc(&w.nedges, sizeof(int) * 2 * (size_t)B, true);
+    if (!rc) rc = alloc(&w.binstart, sizeof(int) * (cap + 8) * B, true);
+    if (!rc) rc = alloc(&w.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
+    if (!rc) rc = alloc(&w.tiny, sizeof(int) * cap * B, true);
+    if (!rc) rc = alloc(&w.ntiny, sizeof(int) * B, true);
+    if (!rc) rc = alloc(&w.dbox, sizeof(float) * 4 * cap * B, true);
+    if (!rc) rc = alloc(&w.dscore, sizeof(float) * cap * B, true);
+    if (!rc) rc = alloc(&w.dcls, sizeof(int) * cap * B, true);
+    if (!rc) rc = alloc(&w.ctype, sizeof(int) * cap * B, true);
+    if (!rc) rc = alloc((void **)&d_box, sizeof(float) * 4 * (size_t)max_det * B, true);
+    if (!rc) rc = alloc((void **)&d_score, sizeof(float) * (size_t)max_det * B, true);
+    if (!rc) rc = alloc((void **)&d_cls, sizeof(int) * (size_t)max_det * B, true);
+    if (!rc) rc = alloc((void **)&d_count, sizeof(int) * B, true);
+    if (rc) { release(); return y355_fail(Y355_EHIP, "device allocation failed"); }
+    HeadParams p{};
+    p.nlev = nlev;
+    for (int l = 0; l < nlev; ++l) {
+        HeadLevel &lv = p.lev[l];
+        lv.pred = nullptr;
+        lv.pred_f = d_pred[l];
+        lv.cstride = cpad;
+        lv.Hs = hs[l];
+        lv.Ws = ws[l];
+        lv.stride = strides[l];
+        lv.dq = 1.0f;
+        for (int i = 0; i < 2 * num_anchors; ++i) lv.anchors[i] = anchors[l * 2 * num_anchors + i];
+    }
+    p.A = num_anchors;
+    p.C = num_classes;
+    p.wh_mul = wh_mul;
+    p.group_by_area = 1;
+    p.Hb = std::min(16, hs[0]);
+    p.Wb = std::min(16, ws[0]);
+    p.in_w = (float)in_w;
+    p.in_h = (float)in_h;
+    p.conf_thresh = conf_thresh;
+    p.nms_thresh = nms_thresh;
+    p.max_det = max_det;
+    p.out_box = d_box;
+    p.out_score = d_score;
+    p.out_cls = d_cls;
+    p.out_count = d_count;
+    y355_launch_head_nms(p, B, w, 0, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(boxes, d_box, sizeof(float) * 4 * (size_t)max_det * B, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(scores, d_score, sizeof(float) * (size_t)max_det * B, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cls, d_cls, sizeof(int) * (size_t)max_det * B, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(count, d_count, sizeof(int) * B, hipMemcpyDeviceToHost);
+    release();
+    if (e != hipSuccess) return y355_fail(Y355_EHIP, std::string("head: ") + hipGetErrorString(e));
+    return 0;
+}

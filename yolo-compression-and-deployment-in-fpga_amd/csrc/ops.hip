@@ -180,6 +180,25 @@ __global__ void nhwc_bf16_to_nchw_kernel(const unsigned short *in, float *out, i
         out[i] = __uint_as_float((unsigned int)in[((b * (H + 2) + y + 1) * (size_t)(W + 2) + x + 1) * cpad + c] << 16);
     }
 }
+__global__ void nhwc_f32_to_nchw_kernel(const float *in, float *out, int B, int C, int H, int W, int cpad) {
+    const size_t n = (size_t)B * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((size_t)W * H)) % C);
+        const size_t b = i / ((size_t)W * H * C);
+        out[i] = in[((b * (H + 2) + y + 1) * (size_t)(W + 2) + x + 1) * cpad + c];
+    }
+}
+__global__ void maxpool2x2_f32_kernel(const float *in, float *out, size_t planes, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t n = planes * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+        const size_t pl = i / ((size_t)Ho * Wo);
+        const float *s = in + (pl * H + 2 * y) * W + 2 * x;
+        out[i] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[W], s[W + 1]));
+    }
+}
 inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 16384); }
 }  // namespace
 
@@ -222,7 +241,7 @@ extern "C" int y355_spp_f32(int device_id, const float *x, int batch, int channe
 
 extern "C" int y355_conv2d_bf16(int device_id, const float *x, const float *w, const float *bias, const float *residual,
                                 int batch, int cin, int cout, int height, int width, int ksize, int stride, float neg_slope,
-                                float *out) {
+                                int out_fp32, float *out) {
     if (!x || !w || !out) return y355_fail(Y355_EINVAL, "null argument");
     if (batch < 1 || cin < 1 || cout < 1 || height < 1 || width < 1) return y355_fail(Y355_EINVAL, "bad shape");
     if (ksize != 1 && ksize != 3) return y355_fail(Y355_EINVAL, "kernel size 1 or 3 (padding k/2)");
@@ -243,7 +262,8 @@ extern "C" int y355_conv2d_bf16(int device_id, const float *x, const float *w, c
     if (bias) std::copy(bias, bias + cout, bpad.begin());
     const size_t n_in = (size_t)batch * cin * height * width, n_out = (size_t)batch * cout * Ho * Wo;
     const size_t in_bytes = (size_t)batch * (height + 2) * (width + 2) * in_pb;
-    const size_t out_pb = (size_t)cout_pad * 2, out_bytes = (size_t)batch * (Ho + 2) * (Wo + 2) * out_pb;
+    if (out_fp32 && residual) return y355_fail(Y355_EINVAL, "fp32 output (prediction layers) takes no residual");
+    const size_t out_pb = (size_t)cout_pad * (out_fp32 ? 4 : 2), out_bytes = (size_t)batch * (Ho + 2) * (Wo + 2) * out_pb;
     std::vector<void *> bufs;
     float *d_x = nullptr, *d_y = nullptr, *d_b = nullptr;
     char *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_res = nullptr;
@@ -288,16 +308,40 @@ extern "C" int y355_conv2d_bf16(int device_id, const float *x, const float *w, c
     p.nblk = cout_pad / ki->bn;
     p.taps = taps;
     p.slope = neg_slope;
+    p.out_f32 = out_fp32 ? 1 : 0;
     p.res = d_res;
     p.res_pb = (int)out_pb;
     p.res_off = 0;
     ki->launch(p, p.tiles_x * p.tiles_y * p.nblk * batch, 0);
     OPS2CHK(hipGetLastError());
-    hipLaunchKernelGGL(nhwc_bf16_to_nchw_kernel, dim3(grid_for(n_out)), dim3(256), 0, 0, (const unsigned short *)d_out, d_y, batch, cout,
-                       Ho, Wo, cout_pad);
+    if (out_fp32)
+        hipLaunchKernelGGL(nhwc_f32_to_nchw_kernel, dim3(grid_for(n_out)), dim3(256), 0, 0, (const float *)d_out, d_y, batch, cout, Ho, Wo,
+                           cout_pad);
+    else
+        hipLaunchKernelGGL(nhwc_bf16_to_nchw_kernel, dim3(grid_for(n_out)), dim3(256), 0, 0, (const unsigned short *)d_out, d_y, batch,
+                           cout, Ho, Wo, cout_pad);
     OPS2CHK(hipGetLastError());
     OPS2CHK(hipDeviceSynchronize());
     OPS2CHK(hipMemcpy(out, d_y, n_out * 4, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+extern "C" int y355_maxpool2x2_f32(int device_id, const float *in, int batch, int channels, int height, int width, float *out) {
+    if (!in || !out) return y355_fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || channels < 1 || height < 2 || width < 2) return y355_fail(Y355_EINVAL, "bad shape");
+    if ((height | width) & 1) return y355_fail(Y355_EINVAL, "pooling needs even H, W");
+    const size_t planes = (size_t)batch * channels, nin = planes * height * width, nout = nin / 4;
+    std::vector<void *> bufs;
+    float *d_in = nullptr, *d_out = nullptr;
+    OPS2CHK(hipSetDevice(device_id));
+    OPS2CHK(hipMalloc((void **)&d_in, nin * 4)); bufs.push_back(d_in);
+    OPS2CHK(hipMalloc((void **)&d_out, nout * 4)); bufs.push_back(d_out);
+    OPS2CHK(hipMemcpy(d_in, in, nin * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(maxpool2x2_f32_kernel, dim3(grid_for(nout)), dim3(256), 0, 0, d_in, d_out, planes, height, width);
+    OPS2CHK(hipGetLastError());
+    OPS2CHK(hipDeviceSynchronize());
+    OPS2CHK(hipMemcpy(out, d_out, nout * 4, hipMemcpyDeviceToHost));
     for (void *q : bufs) (void)hipFree(q);
     return 0;
 }

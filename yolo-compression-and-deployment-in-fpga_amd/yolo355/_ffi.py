@@ -86,7 +86,11 @@ _SIGS = {
     "y355_reorg_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y355_spp_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y355_conv2d_bf16": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "y355_maxpool2x2_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "y355_head_f32": (C.c_int, [C.c_int, C.c_int, P(C.c_void_p), P(C.c_int), P(C.c_int), P(C.c_float), P(C.c_float), C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
     "y355_debug_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "y355_debug_nms_stamps": (C.c_int, [C.c_void_p]),
     "y355_head_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

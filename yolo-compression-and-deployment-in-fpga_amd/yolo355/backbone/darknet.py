@@ -94,3 +94,46 @@ def darknet_light(pretrained=False, hr=False, **kwargs):
     if pretrained:
         raise NotImplementedError("yolo355: load pretrained backbone weights with load_state_dict")
     return DarkNet_Light()
+
+
+class _Pool2(nn.Module):
+    """nn.MaxPool2d((2, 2), 2) through y355_maxpool2x2_f32 (bit-exact)."""
+
+    def forward(self, x):
+        import torch
+        from ..engine import maxpool2x2_f32
+        y = maxpool2x2_f32(x.detach().float().cpu().numpy(), device_id=x.device.index if x.is_cuda and x.device.index is not None else 0)
+        return torch.from_numpy(y).to(x.device)
+
+
+class DarkNet_19(nn.Module):
+    """backbone/darknet.py:40-110: returns (C_4, C_5, C_6) at strides 8, 16, 32.  The pools are parameter-free, so the
+    state_dict layout equals the reference's (conv_k.N.convs.*)."""
+
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        C = Conv_BN_LeakyReLU
+        self.conv_1 = nn.Sequential(C(3, 32, 3, 1), _Pool2())
+        self.conv_2 = nn.Sequential(C(32, 64, 3, 1), _Pool2())
+        self.conv_3 = nn.Sequential(C(64, 128, 3, 1), C(128, 64, 1), C(64, 128, 3, 1), _Pool2())
+        self.conv_4 = nn.Sequential(C(128, 256, 3, 1), C(256, 128, 1), C(128, 256, 3, 1))
+        self.maxpool_4 = _Pool2()
+        self.conv_5 = nn.Sequential(C(256, 512, 3, 1), C(512, 256, 1), C(256, 512, 3, 1), C(512, 256, 1), C(256, 512, 3, 1))
+        self.maxpool_5 = _Pool2()
+        self.conv_6 = nn.Sequential(C(512, 1024, 3, 1), C(1024, 512, 1), C(512, 1024, 3, 1), C(1024, 512, 1), C(512, 1024, 3, 1))
+
+    def forward(self, x):
+        x = self.conv_1(x)
+        x = self.conv_2(x)
+        x = self.conv_3(x)
+        c4 = self.conv_4(x)
+        c5 = self.conv_5(self.maxpool_4(c4))
+        c6 = self.conv_6(self.maxpool_5(c5))
+        return c4, c5, c6
+
+
+def darknet19(pretrained=False, hr=False, **kwargs):
+    """backbone/darknet.py:257-271; pretrained ImageNet weights are a file the caller loads."""
+    if pretrained:
+        raise NotImplementedError("yolo355: load pretrained backbone weights with load_state_dict")
+    return DarkNet_19()

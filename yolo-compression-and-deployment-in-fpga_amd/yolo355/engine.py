@@ -353,7 +353,7 @@ def spp_f32(x, device_id=0):
     return out
 
 
-def conv2d_bf16(x, w, bias=None, residual=None, stride=1, neg_slope=1.0, device_id=0):
+def conv2d_bf16(x, w, bias=None, residual=None, stride=1, neg_slope=1.0, out_fp32=False, device_id=0):
     """conv (1x1, or 3x3 pad 1; stride 1, or 2 for 3x3) + bias + LeakyReLU(neg_slope) [+ residual] on the bf16 MFMA
     (y355_conv2d_bf16).  fp32 NCHW in and out; operands and result are rounded to bf16."""
     lib = _ffi.lib()
@@ -373,5 +373,43 @@ def conv2d_bf16(x, w, bias=None, residual=None, stride=1, neg_slope=1.0, device_
     out = np.empty((B, Cout, Ho, Wo), np.float32)
     _ffi.check(lib.y355_conv2d_bf16(int(device_id), xi.ctypes.data, wi.ctypes.data, None if bi is None else bi.ctypes.data,
                                     None if ri is None else ri.ctypes.data, B, Cin, Cout, H, W, int(k), s, float(neg_slope),
-                                    out.ctypes.data))
+                                    1 if out_fp32 else 0, out.ctypes.data))
     return out
+
+
+def maxpool2x2_f32(x, device_id=0):
+    """nn.MaxPool2d((2, 2), 2) on fp32 NCHW (y355_maxpool2x2_f32); bit-exact."""
+    lib = _ffi.lib()
+    _need_gpu()
+    xi = np.ascontiguousarray(x, dtype=np.float32)
+    B, Cc, H, W = xi.shape
+    out = np.empty((B, Cc, H // 2, W // 2), np.float32)
+    _ffi.check(lib.y355_maxpool2x2_f32(int(device_id), xi.ctypes.data, B, Cc, H, W, out.ctypes.data))
+    return out
+
+
+def head_f32(preds, strides, anchors, num_classes, input_size, wh_mul, conf_thresh, nms_thresh, max_det=None, device_id=0):
+    """Detection head on fp32 prediction maps (y355_head_f32).  preds: list (1 or 2 levels) of [B, A*(5+C), Hs, Ws];
+    anchors: [nlev][A][2].  Returns a list over the batch of (boxes [n,4] normalised, scores [n], classes int64 [n])."""
+    import ctypes as C
+    lib = _ffi.lib()
+    _need_gpu()
+    ps = [np.ascontiguousarray(p, dtype=np.float32) for p in preds]
+    nlev = len(ps)
+    B = ps[0].shape[0]
+    an = np.ascontiguousarray(anchors, dtype=np.float32).reshape(nlev, -1, 2)
+    A = an.shape[1]
+    hs = (C.c_int * nlev)(*[p.shape[2] for p in ps])
+    ws = (C.c_int * nlev)(*[p.shape[3] for p in ps])
+    st = (C.c_float * nlev)(*[float(s) for s in strides])
+    ptrs = (C.c_void_p * nlev)(*[p.ctypes.data for p in ps])
+    N = sum(p.shape[2] * p.shape[3] * A for p in ps)
+    md = N if max_det is None else min(int(max_det), N)
+    boxes = np.zeros((B, md, 4), np.float32)
+    scores = np.zeros((B, md), np.float32)
+    cls = np.zeros((B, md), np.int32)
+    count = np.zeros((B,), np.int32)
+    _ffi.check(lib.y355_head_f32(int(device_id), nlev, ptrs, hs, ws, st, an.ctypes.data_as(C.POINTER(C.c_float)), A, int(num_classes),
+                                 int(input_size[0]), int(input_size[1]), float(wh_mul), float(conf_thresh), float(nms_thresh), B, md,
+                                 boxes.ctypes.data, scores.ctypes.data, cls.ctypes.data, count.ctypes.data))
+    return [(boxes[b, :count[b]].copy(), scores[b, :count[b]].copy(), cls[b, :count[b]].astype(np.int64)) for b in range(B)]
