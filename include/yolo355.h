@@ -173,6 +173,9 @@ int y355_conv2d_bf16(int device_id, const float *x, const float *w, const float 
                      int batch, int cin, int cout, int height, int width, int ksize, int stride, float neg_slope,
                      int out_fp32, float *out);
 int y355_maxpool2x2_f32(int device_id, const float *in, int batch, int channels, int height, int width, float *out);
+/* F.interpolate(x, scale_factor=2.0, mode='bilinear', align_corners=True) (models/yolo_v3.py:211,215) on fp32:
+ * [B][C][H][W] -> [B][C][2H][2W]; fp32 arithmetic (within 1e-6 of torch's) */
+int y355_upsample2x_f32(int device_id, const float *in, int batch, int channels, int height, int width, float *out);
 /* detection head on fp32 prediction maps, stand-alone (models/yolo_v2.py:183-210; models/tiny_yolo_v3.py:202-262):
  * pred[l] = NCHW [B][A*(5+C)][hs[l]][ws[l]] (host), 1 or 2 levels, channel layout [obj x A | cls x A*C | txtytwth x A*4];
  * anchors [nlev][A][2]; wh_mul = the stride for anchors in grid units (yolo_v2), 1 for anchors in pixels (v3 family).

@@ -70,15 +70,17 @@ def tiny_preds(layers, x):
     return [pred_1, pred_2], taps
 
 
-def tiny_head_decode(preds, input_size, anchors, num_classes):
-    """models/tiny_yolo_v3.py:41-112, 202-232 for every image: (bbox [B,N,4], cls_scores [B,N,C]).
-    anchors: 2*A pairs in pixels, stride-16 level first."""
-    A = len(anchors) // 2
+def tiny_head_decode(preds, input_size, anchors, num_classes, level_strides=(16, 32)):
+    """models/tiny_yolo_v3.py:41-112, 202-232 (level_strides (16, 32)) and models/yolo_v3.py:65-110, 217-270
+    (level_strides (8, 16, 32)) for every image: (bbox [B,N,4], cls_scores [B,N,C]).
+    anchors: nlev*A pairs in pixels, finest level first."""
+    nlev = len(level_strides)
+    A = len(anchors) // nlev
     C = num_classes
-    anc = torch.tensor(anchors, dtype=torch.float32).view(2, A, 2)
+    anc = torch.tensor(anchors, dtype=torch.float32).view(nlev, A, 2)
     w, h = input_size[1], input_size[0]
     confs, clss, txs, grids, strides, awh = [], [], [], [], [], []
-    for ind, (pred, s) in enumerate(zip(preds, (16, 32))):
+    for ind, (pred, s) in enumerate(zip(preds, level_strides)):
         pred = torch.as_tensor(pred, dtype=torch.float32)
         B, abC, H, W = pred.shape
         p = pred.permute(0, 2, 3, 1).contiguous().view(B, H * W, abC)
@@ -157,4 +159,10 @@ def head_decode_v2(pred_f32, input_size, anchors, num_classes, stride):
 def detect_v2(pred_f32, anchors, num_classes, input_size, stride, conf_thresh, nms_thresh):
     """decode + postprocess (models/yolo_v2.py:137-163 = slim_yolo_v2.py:176-210) of a prediction map, per image."""
     box, sc = head_decode_v2(pred_f32, input_size, anchors, num_classes, stride)
+    return [O.postprocess(box[i], sc[i], conf_thresh, nms_thresh, num_classes) for i in range(box.shape[0])]
+
+
+def detect_v3(preds, anchors, num_classes, input_size, conf_thresh, nms_thresh):
+    """decode + postprocess of the three prediction maps of yolo_v3 / yolo_v3_spp (models/yolo_v3.py:217-270), per image."""
+    box, sc = tiny_head_decode(preds, input_size, anchors, num_classes, level_strides=(8, 16, 32))
     return [O.postprocess(box[i], sc[i], conf_thresh, nms_thresh, num_classes) for i in range(box.shape[0])]

@@ -120,3 +120,7 @@ def synth_state_dict(sd, seed, weight_gain=2.0):
 
 # whole-model cases of the wider families, composed from the operator API: (tag, class, input size, classes, seed)
 WIDE_MODEL_CASES = [("yolo_v2_224", "myYOLOv2", [224, 224], 20, 4100)]
+# three-level models: (tag, reference module, class, input size, classes, seed, weight gain); anchors = synth.MULTI_ANCHOR_SIZE
+# (gain 1.3 keeps the activations of the 75 residual-connected layers O(1): logits within +-2)
+WIDE3_MODEL_CASES = [("yolo_v3_224", "models.yolo_v3", "myYOLOv3", [224, 224], 20, 4200, 1.3),
+                     ("yolo_v3_spp_224", "models.yolo_v3_spp", "myYOLOv3Spp", [224, 224], 20, 4300, 1.3)]

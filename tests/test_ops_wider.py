@@ -165,8 +165,8 @@ def test_yolo_v2_dropin_matches_reference(case):
     assert err.mean() < 0.005 * np.abs(ref).max(), float(err.mean())
     b, s, c = m(x)
     assert b.dtype == np.float32 and s.dtype == np.float32 and c.dtype == np.int64 and b.flags.writeable
-    ok, why = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b, s, c), iou_min=0.7, score_tol=0.08)
-    assert ok, why
+    fr, fg = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b, s, c), iou_min=0.7, score_tol=0.08)
+    assert fr > 0.9 and fg > 0.9, (fr, fg)
     # the head itself: exact decode + NMS of the engine's own prediction map
     want = F.detect_v2(pred, synth.ANCHOR_SIZE, classes, size, 32, 0.05, 0.5)[0]
     assert len(want[1]) == len(s) and np.array_equal(want[2], c)
@@ -182,3 +182,55 @@ def test_v2_head_oracle_matches_reference_golden(case):
     d = F.detect_v2(WGOLD[tag + "_pred"], synth.ANCHOR_SIZE, classes, size, 32, 0.05, 0.5)[0]
     assert np.array_equal(d[0], WGOLD[tag + "_boxes"]) and np.array_equal(d[1], WGOLD[tag + "_scores"])
     assert np.array_equal(d[2], WGOLD[tag + "_cls"])
+
+
+from cases import WIDE3_MODEL_CASES  # noqa: E402
+
+
+def _gold3(tag):
+    return [WGOLD[tag + "_pred_%d" % k].astype(np.float32) for k in (1, 2, 3)]
+
+
+@pytest.mark.parametrize("case", WIDE3_MODEL_CASES, ids=[c[0] for c in WIDE3_MODEL_CASES])
+def test_v3_head_oracle_matches_reference_golden(case):
+    """CPU: the three-level decode + NMS restatement on the reference's own maps reproduces its detections
+    (the stride-8 map is stored as float16, so: same count and classes, boxes / scores within the rounding)"""
+    from yolo355 import synth
+    from oracle import fp32_oracle as F
+    tag = case[0]
+    d = F.detect_v3(_gold3(tag), synth.MULTI_ANCHOR_SIZE, case[4], case[3], 0.05, 0.5)[0]
+    ok = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), d, iou_min=0.95, score_tol=0.005)
+    assert min(ok) > 0.97, ok
+    assert abs(len(d[1]) - len(WGOLD[tag + "_scores"])) <= max(2, len(d[1]) // 50)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WIDE3_MODEL_CASES, ids=[c[0] for c in WIDE3_MODEL_CASES])
+def test_yolo_v3_dropins_match_reference(case):
+    """myYOLOv3 / myYOLOv3Spp (DarkNet-53: stride-2 convolutions, 23 residual blocks; 1x1 + bilinear x2 routes; SPP)
+    composed from the operator API: the three prediction maps within the bf16 tolerance of the reference's fp32
+    maps, detections close, head exact on the engine's own maps."""
+    import torch
+    from yolo355 import synth
+    from yolo355.models import yolo_v3 as Y
+    from oracle import fp32_oracle as F
+    tag, _, cls, size, classes, seed, gain = case
+    m = getattr(Y, cls)("cuda", input_size=size, num_classes=classes, trainable=False, conf_thresh=0.05, nms_thresh=0.5,
+                        anchor_size=synth.MULTI_ANCHOR_SIZE)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed, weight_gain=gain))
+    m.eval()
+    x = torch.from_numpy(synth.make_images(seed + 1, 1, size[0], size[1])).cuda()
+    with torch.no_grad():
+        preds = m.prediction_maps(x)
+    for got, ref in zip(preds, _gold3(tag)):
+        assert got.shape == ref.shape
+        err = np.abs(got - ref)
+        # 75+ bf16 layers with residual accumulation: below 3 % of the range, mean below 0.6 %
+        assert err.max() < 0.03 * np.abs(ref).max() + 0.03, float(err.max())
+        assert err.mean() < 0.006 * np.abs(ref).max(), float(err.mean())
+    b, s, c = m(x)
+    fr, fg = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b, s, c), iou_min=0.7, score_tol=0.05)
+    assert fr > 0.9 and fg > 0.9, (fr, fg, len(s), len(WGOLD[tag + "_scores"]))
+    want = F.detect_v3(preds, synth.MULTI_ANCHOR_SIZE, classes, size, 0.05, 0.5)[0]
+    assert len(want[1]) == len(s) and np.array_equal(want[2], c)
+    assert np.abs(want[0] - b).max() < 2e-5 and np.abs(want[1] - s).max() < 2e-6

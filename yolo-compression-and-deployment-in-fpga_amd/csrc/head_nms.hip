@@ -74,14 +74,16 @@ __global__ __launch_bounds__(256) void decode_kernel(const HeadParams p, const H
     const int np = blockIdx.x * 256 + threadIdx.x;
     const int A = p.A, C = p.C;
     const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
-    const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0;
-    const int N = N0 + HW1 * A;
+    const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0, N1 = N0 + HW1 * A;
+    const int HW2 = p.nlev > 2 ? p.lev[2].Hs * p.lev[2].Ws : 0;
+    const int N = N1 + HW2 * A;
     if (np >= N) return;
-    const int lv = np >= N0 ? 1 : 0;
+    const int lv = (np >= N0 ? 1 : 0) + (np >= N1 ? 1 : 0);
     const HeadLevel &L = p.lev[lv];
-    const int npl = np - lv * N0, HWl = lv ? HW1 : HW0;
+    const int lbase = lv == 0 ? 0 : (lv == 1 ? N0 : N1);
+    const int npl = np - lbase, HWl = lv == 0 ? HW0 : (lv == 1 ? HW1 : HW2);
     const int a = npl / HWl, cell = npl % HWl;
-    const int n = lv * N0 + cell * A + a;      // the reference's anchor index (:337-341)
+    const int n = lbase + cell * A + a;        // the reference's anchor index (:337-341)
     const int gy = cell / L.Ws, gx = cell % L.Ws;
     const size_t po = ((size_t)(b * L.Hs + gy) * L.Ws + gx) * L.cstride;
     const int8_t *pq = L.pred ? L.pred + po : nullptr;
@@ -132,8 +134,9 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     NSTAMP(0, blockIdx.x, 0);
     const int A = p.A;
     const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
-    const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0;
-    const int N = N0 + HW1 * A;
+    const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0, N1 = N0 + HW1 * A;
+    const int HW2 = p.nlev > 2 ? p.lev[2].Hs * p.lev[2].Ws : 0;
+    const int N = N1 + HW2 * A;
     const int HWb = p.Hb * p.Wb;
     for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
     if (tid < MAXA) {
@@ -176,10 +179,11 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
         rk[u] = 0;
         ktu[u] = 0;
         if (np < N) {
-            const int lv = np >= N0 ? 1 : 0;
-            const int npl = np - lv * N0, HWl = lv ? HW1 : HW0;
+            const int lv = (np >= N0 ? 1 : 0) + (np >= N1 ? 1 : 0);
+            const int lbase = lv == 0 ? 0 : (lv == 1 ? N0 : N1);
+            const int npl = np - lbase, HWl = lv == 0 ? HW0 : (lv == 1 ? HW1 : HW2);
             const int a = npl / HWl, cell = npl % HWl;
-            orig[u] = lv * N0 + cell * A + a;
+            orig[u] = lbase + cell * A + a;
             valid[u] = score[u] >= p.conf_thresh;
             if (valid[u]) {
                 // candidate group: the anchor type, or (group_by_area) the octave of the clamped box's

@@ -839,7 +839,7 @@ extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, 
                              float conf_thresh, float nms_thresh, int batch, int max_det, float *boxes, float *scores,
                              int32_t *cls, int32_t *count) {
     if (!pred || !hs || !ws || !strides || !anchors || !boxes || !scores || !cls || !count) return y355_fail(Y355_EINVAL, "null argument");
-    if (nlev < 1 || nlev > 2) return y355_fail(Y355_EINVAL, "1 or 2 prediction levels (the 3-level yolo_v3 head exceeds the 4096-anchor head)");
+    if (nlev < 1 || nlev > 3) return y355_fail(Y355_EINVAL, "1 to 3 prediction levels");
     if (num_anchors < 1 || num_anchors * nlev > Y355_HEAD_MAXA || num_classes < 1 || batch < 1 || max_det < 1)
         return y355_fail(Y355_EINVAL, "bad anchors / classes / batch / max_det");
     const int predc = num_anchors * (5 + num_classes);
@@ -866,7 +866,7 @@ extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, 
     const int cpad = predc <= 64 ? 64 : predc <= 128 ? 128 : 256;
     y355_head_ws w{};
     int rc = 0;
-    float *d_pred[2] = {nullptr, nullptr};
+    float *d_pred[3] = {nullptr, nullptr, nullptr};
     for (int l = 0; l < nlev && !rc; ++l) {
         // NCHW -> NHWC with cpad channels
         const size_t px = (size_t)hs[l] * ws[l];

@@ -199,6 +199,24 @@ __global__ void maxpool2x2_f32_kernel(const float *in, float *out, size_t planes
         out[i] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[W], s[W + 1]));
     }
 }
+// F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) (models/yolo_v3.py:211,215)
+__global__ void upsample2x_f32_kernel(const float *in, float *out, size_t planes, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const size_t n = planes * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+        const size_t pl = i / ((size_t)Ho * Wo);
+        const float sy = ry * (float)y, sx = rx * (float)x;
+        const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float *s = in + pl * (size_t)H * W;
+        const float top = (1.f - lx) * s[(size_t)y0 * W + x0] + lx * s[(size_t)y0 * W + x1];
+        const float bot = (1.f - lx) * s[(size_t)y1 * W + x0] + lx * s[(size_t)y1 * W + x1];
+        out[i] = (1.f - ly) * top + ly * bot;
+    }
+}
 inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 16384); }
 }  // namespace
 
@@ -339,6 +357,24 @@ extern "C" int y355_maxpool2x2_f32(int device_id, const float *in, int batch, in
     OPS2CHK(hipMalloc((void **)&d_out, nout * 4)); bufs.push_back(d_out);
     OPS2CHK(hipMemcpy(d_in, in, nin * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(maxpool2x2_f32_kernel, dim3(grid_for(nout)), dim3(256), 0, 0, d_in, d_out, planes, height, width);
+    OPS2CHK(hipGetLastError());
+    OPS2CHK(hipDeviceSynchronize());
+    OPS2CHK(hipMemcpy(out, d_out, nout * 4, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+extern "C" int y355_upsample2x_f32(int device_id, const float *in, int batch, int channels, int height, int width, float *out) {
+    if (!in || !out) return y355_fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || channels < 1 || height < 1 || width < 1) return y355_fail(Y355_EINVAL, "bad shape");
+    const size_t planes = (size_t)batch * channels, nin = planes * height * width, nout = nin * 4;
+    std::vector<void *> bufs;
+    float *d_in = nullptr, *d_out = nullptr;
+    OPS2CHK(hipSetDevice(device_id));
+    OPS2CHK(hipMalloc((void **)&d_in, nin * 4)); bufs.push_back(d_in);
+    OPS2CHK(hipMalloc((void **)&d_out, nout * 4)); bufs.push_back(d_out);
+    OPS2CHK(hipMemcpy(d_in, in, nin * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(upsample2x_f32_kernel, dim3(grid_for(nout)), dim3(256), 0, 0, d_in, d_out, planes, height, width);
     OPS2CHK(hipGetLastError());
     OPS2CHK(hipDeviceSynchronize());
     OPS2CHK(hipMemcpy(out, d_out, nout * 4, hipMemcpyDeviceToHost));

@@ -172,7 +172,7 @@ struct HeadLevel {
     float anchors[32];    // (w, h) of this level's A anchors
 };
 struct HeadParams {
-    HeadLevel lev[2];     // anchor index n: level 0 first, n = cell * A + a inside a level
+    HeadLevel lev[3];     // anchor index n: level 0 first, n = cell * A + a inside a level
     int nlev;
     int A, C;             // anchors per level, classes
     float wh_mul;         // w = exp(tw) * aw * wh_mul   (16: anchors in grid units; 1: pixels)

@@ -88,6 +88,7 @@ _SIGS = {
     "y355_conv2d_bf16": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "y355_maxpool2x2_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "y355_upsample2x_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y355_head_f32": (C.c_int, [C.c_int, C.c_int, P(C.c_void_p), P(C.c_int), P(C.c_int), P(C.c_float), P(C.c_float), C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),

@@ -413,3 +413,14 @@ def head_f32(preds, strides, anchors, num_classes, input_size, wh_mul, conf_thre
                                  int(input_size[0]), int(input_size[1]), float(wh_mul), float(conf_thresh), float(nms_thresh), B, md,
                                  boxes.ctypes.data, scores.ctypes.data, cls.ctypes.data, count.ctypes.data))
     return [(boxes[b, :count[b]].copy(), scores[b, :count[b]].copy(), cls[b, :count[b]].astype(np.int64)) for b in range(B)]
+
+
+def upsample2x_f32(x, device_id=0):
+    """F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=True) on fp32 NCHW (y355_upsample2x_f32)."""
+    lib = _ffi.lib()
+    _need_gpu()
+    xi = np.ascontiguousarray(x, dtype=np.float32)
+    B, Cc, H, W = xi.shape
+    out = np.empty((B, Cc, 2 * H, 2 * W), np.float32)
+    _ffi.check(lib.y355_upsample2x_f32(int(device_id), xi.ctypes.data, B, Cc, H, W, out.ctypes.data))
+    return out

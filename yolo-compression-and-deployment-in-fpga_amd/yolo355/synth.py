@@ -127,6 +127,8 @@ def make_bn(seed, cout):
 
 
 # ---- fp32 model families (SlimYOLOv2 with BatchNorm, YOLOv3tiny) ---------------------------
+MULTI_ANCHOR_SIZE = [[32.64, 47.68], [50.24, 108.16], [126.72, 96.32], [78.4, 201.92], [178.24, 178.56],
+                     [129.6, 294.72], [331.84, 194.56], [227.84, 325.76], [365.44, 358.72]]      # data/config.py:18-20 (yolo_v3, VOC)
 TINY_MULTI_ANCHOR_SIZE = [[34.01, 61.79], [86.94, 109.68], [93.49, 227.46],
                           [246.38, 163.33], [178.68, 306.55], [344.89, 337.14]]      # data/config.py:27-28
 # (state_dict prefix, cin, cout, ksize, has_bn) in the weight-slot order of csrc/net.hip
