@@ -129,6 +129,10 @@ int y355_forward_counters(y355_engine *h, int64_t *saturated, int64_t *guard);
  * boxes f32 [B][N][4], best-class scores f32 [B][N], classes i32 [B][N]; N = anchors per image.
  * Valid after y355_head_nms or a forward with Y355_F_TAP; host pointers; synchronous. */
 int y355_get_candidates(y355_engine *h, int batch, float *boxes, float *scores, int32_t *cls);
+/* evaluator-side rescale of a batch, in place, on the engine's stream: boxes[b][i] *= (w_b, h_b, w_b, h_b)
+ * for i < count[b]; wh_dev = f32 [B][2] (width, height) of the original images.  Replaces `bboxes *= scale`
+ * (test.py:88-90, utils/vocapi_evaluator_mask.py:71-72, utils/cocoapi_evaluator.py:77-85); same float32 results. */
+int y355_scale_boxes(y355_engine *h, float *boxes_dev, const int32_t *count_dev, const float *wh_dev, int batch);
 int y355_max_det(y355_engine *h);              /* effective per-image cap */
 int y355_num_anchors_total(y355_engine *h);    /* N = Hs*Ws*A */
 

@@ -727,6 +727,31 @@ extern "C" int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, in
 extern "C" int y355_max_det(y355_engine *h) { return h ? h->max_det : Y355_EINVAL; }
 extern "C" int y355_num_anchors_total(y355_engine *h) { return h ? h->N : Y355_EINVAL; }
 
+// Evaluator-side step right after the path: `bboxes *= [[w, h, w, h]]` of every image
+// (test.py:88-90, utils/vocapi_evaluator_mask.py:71-72, utils/cocoapi_evaluator.py:77-85) for a whole batch on
+// the GPU, on the engine's stream, in place.  The reference's float32 *= int64 computes the product in float64
+// and rounds once to float32; box (24-bit) x size (< 2^24) is exact in float64, so one fp32 multiply is identical.
+__global__ void scale_boxes_kernel(float *boxes, const int32_t *count, const float *wh, int max_det) {
+    const int b = blockIdx.y;
+    const int n = count[b];
+    const float w = wh[2 * b], h = wh[2 * b + 1];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 *p = (float4 *)(boxes + ((size_t)b * max_det + i) * 4);
+        float4 v = *p;
+        v.x *= w; v.y *= h; v.z *= w; v.w *= h;
+        *p = v;
+    }
+}
+extern "C" int y355_scale_boxes(y355_engine *h, float *boxes_dev, const int32_t *count_dev, const float *wh_dev, int batch) {
+    if (!h || !boxes_dev || !count_dev || !wh_dev) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const int md = y355_max_det(h);
+    hipLaunchKernelGGL(scale_boxes_kernel, dim3((md + 255) / 256, batch), dim3(256), 0, h->stream, boxes_dev, count_dev, wh_dev, md);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // diagnostic: record s_memtime stamps of the production conv kernel of `layer` (-1 = off)
 extern "C" int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *out_host, int nwg) {
     if (!h) return fail(Y355_EINVAL, "null engine");

@@ -74,6 +74,7 @@ _SIGS = {
     "y355_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y355_forward_counters": (C.c_int, [C.c_void_p, P(C.c_int64), P(C.c_int64)]),
     "y355_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_scale_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "y355_max_det": (C.c_int, [C.c_void_p]),
     "y355_num_anchors_total": (C.c_int, [C.c_void_p]),
     "y355_conv3x3_i8_fused": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

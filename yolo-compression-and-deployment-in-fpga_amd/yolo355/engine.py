@@ -203,6 +203,32 @@ class Engine:
         return [(boxes[i, :n[i]].copy(), scores[i, :n[i]].copy(), cls[i, :n[i]].astype(np.int64))
                 for i in range(B)]
 
+    def forward_scaled(self, x, sizes_wh, find=False, frames=False):
+        """Batched forward + the evaluators' `bboxes *= [[w, h, w, h]]` on the GPU (y355_scale_boxes).
+        x: float32 [B,3,H,W] (or uint8 frames [B,H,W,3] with frames=True); sizes_wh: [B,2] original (width, height).
+        Returns a list over the batch of (bboxes in pixels of the original image, scores, cls_inds)."""
+        wh = torch.as_tensor(np.asarray(sizes_wh, np.float32).reshape(-1, 2)).to(self.device)
+        flags = _ffi.F_GUARD if find else 0
+        if frames:
+            fd = (torch.from_numpy(x) if isinstance(x, np.ndarray) else x).to(self.device)
+            B = fd.shape[0]
+            ob, os_, oc, on = self.forward_frames_device(fd, flags)
+        else:
+            xd = self._dev_input(x)
+            B = xd.shape[0]
+            ob, os_, oc, on = self.forward_device(xd, flags)
+        if wh.shape[0] != B:
+            raise ValueError("sizes_wh has %d rows for a batch of %d" % (wh.shape[0], B))
+        _ffi.check(self._lib.y355_scale_boxes(self._h, ob.data_ptr(), on.data_ptr(), wh.data_ptr(), B))
+        n = on[:B].cpu().numpy()
+        if find:
+            sat, guard = self.counters()
+            if guard:
+                print("too high!!!")
+                raise AssertionError("conv output exceeds the 16-bit head-room (find=True): %d positions" % guard)
+        boxes, scores, cls = ob[:B].cpu().numpy(), os_[:B].cpu().numpy(), oc[:B].cpu().numpy()
+        return [(boxes[i, :n[i]].copy(), scores[i, :n[i]].copy(), cls[i, :n[i]].astype(np.int64)) for i in range(B)]
+
     def set_normalization(self, mean_bgr, std_bgr):
         m = (C.c_float * 3)(*[float(v) for v in mean_bgr])
         sd = (C.c_float * 3)(*[float(v) for v in std_bgr])

@@ -98,8 +98,10 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
         (bboxes float32 [n,4] in [0,1], scores float32 [n], cls_inds int64 [n]), anchor order."""
         return self.forward_batch(x, quantization=quantization, find=find)[0]
 
-    def forward_batch(self, x, quantization=True, find=False):
-        """Every image of the batch: element i equals forward(x[i:i+1]) of a frozen model."""
+    def forward_batch(self, x, quantization=True, find=False, sizes_wh=None):
+        """Every image of the batch: element i equals forward(x[i:i+1]) of a frozen model.  sizes_wh ([B,2] original
+        (width, height)): boxes come back in pixels of the original images -- the evaluators'
+        `bboxes *= scale` (utils/vocapi_evaluator_mask.py:71-72) done on the GPU for the whole batch."""
         if self.trainable:
             raise NotImplementedError("yolo355 is an inference engine: the training branch "
                                       "(models/slim_yolo_v2.py:360-382) is out of scope")
@@ -117,6 +119,8 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
             sa = [t.exponent() for t in trackers]
         eng.set_act_exponents(sa)
         eng.set_thresholds(self.conf_thresh, self.nms_thresh)
+        if sizes_wh is not None:
+            return eng.forward_scaled(x, sizes_wh, find=find)
         return eng.forward(x, find=find)
 
     def forward_frames(self, frames, find=False):

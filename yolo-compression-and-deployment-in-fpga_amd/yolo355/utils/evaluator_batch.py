@@ -1,0 +1,81 @@
+"""Evaluator-side batching.  The reference's evaluators call the network one image at a time
+(utils/vocapi_evaluator_mask.py:57-82, utils/vocapi_evaluator.py, utils/cocoapi_evaluator.py:70-98) and rescale the
+boxes on the host.  These helpers produce the same data structures with batched forwards and the rescale on the GPU
+(`forward_batch(..., sizes_wh=...)` -> y355_scale_boxes); the mAP computation that follows them is untouched.
+
+    # utils/vocapi_evaluator_mask.py:49-95  (evaluate)
+    - for i in range(num_images): ... bboxes, scores, cls_inds = net(x, quantization=..., find=...) ...
+    + self.all_boxes = voc_all_boxes(net, self.dataset, len(self.labelmap), batch_size=64, quantization=quantization, find=find)
+
+    # utils/cocoapi_evaluator.py:66-98
+    + ids, data_dict = coco_data_dict(model, self.dataset, self.transform, batch_size=64)
+"""
+import numpy as np
+import torch
+
+
+def _batches(n, bs):
+    for i0 in range(0, n, bs):
+        yield i0, min(n, i0 + bs)
+
+
+def _run(net, x, sizes_wh, **kw):
+    if not hasattr(net, "forward_batch"):
+        raise TypeError("evaluator batching needs a yolo355 model (forward_batch)")
+    try:
+        return net.forward_batch(x, sizes_wh=sizes_wh, **kw)
+    except TypeError:
+        # models without the fused rescale (the composed wider families): rescale like the reference, per image
+        out = net.forward_batch(x, **{k: v for k, v in kw.items() if k not in ("quantization", "find")})
+        res = []
+        for (b, s, c), (w, h) in zip(out, sizes_wh):
+            b = b.copy()
+            b *= np.array([[w, h, w, h]])
+            res.append((b, s, c))
+        return res
+
+
+def voc_all_boxes(net, dataset, num_classes, batch_size=64, quantization=False, find=False, num_images=None):
+    """all_boxes[cls][image] = N x 5 float32 (x1, y1, x2, y2, score) exactly as the loop of
+    utils/vocapi_evaluator_mask.py:57-82 builds it; dataset.pull_item(i) -> (im [3,H,W] tensor, gt, h, w)."""
+    n = len(dataset) if num_images is None else int(num_images)
+    all_boxes = [[[] for _ in range(n)] for _ in range(num_classes)]
+    for i0, i1 in _batches(n, batch_size):
+        ims, sizes = [], []
+        for i in range(i0, i1):
+            im, gt, h, w = dataset.pull_item(i)
+            ims.append(torch.as_tensor(im))
+            sizes.append((w, h))
+        x = torch.stack(ims).float()
+        dets = _run(net, x, np.asarray(sizes, np.float32), quantization=quantization, find=find)
+        for k, (bboxes, scores, cls_inds) in enumerate(dets):
+            i = i0 + k
+            for j in range(num_classes):
+                inds = np.where(cls_inds == j)[0]
+                if len(inds) == 0:
+                    all_boxes[j][i] = np.empty([0, 5], dtype=np.float32)
+                    continue
+                all_boxes[j][i] = np.hstack((bboxes[inds], scores[inds][:, np.newaxis])).astype(np.float32, copy=False)
+    return all_boxes
+
+
+def coco_data_dict(net, dataset, transform, batch_size=64, num_images=None, **kw):
+    """(ids, data_dict) exactly as utils/cocoapi_evaluator.py:66-98 builds them: dataset.pull_image(i) -> (img HWC BGR,
+    id); transform(img)[0] -> HWC float image at the network size; dataset.class_ids maps class index -> COCO id."""
+    n = len(dataset) if num_images is None else int(num_images)
+    ids, data_dict = [], []
+    for i0, i1 in _batches(n, batch_size):
+        xs, sizes, bids = [], [], []
+        for i in range(i0, i1):
+            img, id_ = dataset.pull_image(i)
+            xs.append(torch.from_numpy(np.ascontiguousarray(transform(img)[0][:, :, (2, 1, 0)])).permute(2, 0, 1))
+            sizes.append((img.shape[1], img.shape[0]))
+            bids.append(int(id_))
+        dets = _run(net, torch.stack(xs).float(), np.asarray(sizes, np.float32), **kw)
+        for id_, (bboxes, scores, cls_inds) in zip(bids, dets):
+            ids.append(id_)
+            for k, box in enumerate(bboxes):
+                x1, y1, x2, y2 = float(box[0]), float(box[1]), float(box[2]), float(box[3])
+                data_dict.append({"image_id": id_, "category_id": dataset.class_ids[int(cls_inds[k])],
+                                  "bbox": [x1, y1, x2 - x1, y2 - y1], "score": float(scores[k])})
+    return ids, data_dict
