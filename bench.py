@@ -55,14 +55,43 @@ def pmc_traffic(kernel):
     return None
 
 
-def quantized_layers(seed=2):
+def quantized_layers(seed=2, **kw):
     """synthetic fp32 weights -> per-tensor pow2 int8 (product-side prep, not the oracle)."""
     out = []
-    for name, w, b in synth.make_weights(seed, num_classes=NUM_CLASSES):
+    for name, w, b in synth.make_weights(seed, num_classes=NUM_CLASSES, **kw):
         qw, ew = prep.to_int8_pow2(torch.from_numpy(w))
         qb, eb = prep.to_int8_pow2(torch.from_numpy(b))
         out.append(dict(name=name, q_w=qw, q_b=qb, e_w=ew, e_b=eb))
     return out
+
+
+def sparse_fixture(args, dev, streams, x):
+    """The same path on the 'sparse' fixture of SURVEY.md 8d / G4 (objectness bias -4, conf 0.1: a few detections per
+    image instead of every anchor) -- the NMS load of a trained model rather than the random-weight worst case the
+    headline `value` is quoted on.  Same batch, streams, kernels; reported beside `value`, never instead of it."""
+    B = args.batch
+    engines = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            e = Engine([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.1, nms_thresh=0.5, max_batch=B, device=dev)
+            e.load_quantized(quantized_layers(2, pred_gain=400.0, obj_bias=-4.0))
+        engines.append(e)
+    sa = engines[0].calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
+    for e in engines:
+        e.set_act_exponents(sa)
+    bufs = [tuple(torch.empty_like(t) for t in engines[0]._buffers(B)) for _ in range(2 * len(engines))]
+    torch.cuda.synchronize()
+    out = None
+    for i in range(args.warmup):
+        out = engines[i % len(engines)].forward_device(x, 0, bufs[i % len(bufs)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = engines[i % len(engines)].forward_device(x, 0, bufs[i % len(bufs)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * args.steps / dt, 1), "unit": "images/sec", "conf_thresh": 0.1,
+            "weights": "make_weights(2, pred_gain=400, obj_bias=-4)", "detections_per_step": int(out[3][:B].sum().item())}
 
 
 def cpu_baseline(n_images=256):
@@ -178,6 +207,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sparse", action="store_true", help="skip the extra 'sparse fixture' measurement (SURVEY.md 8d)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32 = the headline configuration (fp32 NCHW tensor resident in HBM); u8 = uint8 HWC BGR "
@@ -315,6 +345,8 @@ def main():
                          "layers": layers,
                          "head_ms": round(float(layer_ms[10]), 4), "nms_ms": round(float(layer_ms[11]), 4)},
         }
+        if world == 1 and not args.no_sparse:
+            res["sparse_fixture"] = sparse_fixture(args, dev, streams, x)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["cpu_baseline_pytorch"] = cpu_baseline_torch()

@@ -271,9 +271,20 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
     const Requant rq = p.rq;
     const int Ho = H >> 1, Wo = W >> 1;
     unsigned int nsat = 0;
+    // sh_l (a left requant shift; sh_r = 0 then) folded into the accumulator shift and the bias; saturation is
+    // DETECTED with one v_xad per output and COUNTED exactly by a second, cold pass over the tile only when it happened
+    const int shl2 = rq.shl + rq.sh_l;
+    const int bias2 = bias << rq.sh_l;
+    auto requant = [&](int v) {
+        int x = (v << shl2) + bias2;
+        x = max(x, x << rq.lk);
+        const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
+        return (x + rq.hm1 + rb) >> rq.sh_r;
+    };
     // lane geometry inside an m-tile: window li>>2, position li&3 -> pixel (r>>1, 2*(li>>2) + (r&1))
     const int r4 = li & 3;
     const int lbase = ((r4 >> 1) + min(g, 2)) * PW + 2 * (li >> 2) + (r4 & 1);
+    unsigned int satx = 0;
 #pragma unroll 1
     for (int wy = wave; wy < NWR; wy += 4) {
         const unsigned int *src = patch + lbase + wy * 2 * PW;
@@ -288,11 +299,29 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
             v4i acc = {0, 0, 0, 0};
             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw, acc, 0, 0, 0);
             const int vmax = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
-            const int qq = y355_requant_fast(vmax, bias, rq);
+            const int qq = requant(vmax);
             const int q = y355_clamp8<int>(qq);
-            const int wx = mt * 4 + g;
-            nsat += (q != qq && (y0 >> 1) + wy < Ho && (x0 >> 1) + wx < Wo) ? 1u : 0u;
+            satx += (unsigned int)(q ^ qq);
             dst[mt * 64] = (unsigned char)(q & 0xff);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(satx != 0) != 0ull) {        // wave-uniform: the recount re-runs MFMAs (all lanes feed them)
+#pragma unroll 1
+        for (int wy = wave; wy < NWR; wy += 4) {
+            const unsigned int *src = patch + lbase + wy * 2 * PW;
+#pragma unroll 1
+            for (int mt = 0; mt < MPR; ++mt) {
+                v4i a;
+                a[0] = (int)src[mt * 8 + 0];
+                a[1] = (int)src[mt * 8 + 1];
+                a[2] = (int)src[mt * 8 + 2];
+                a[3] = (int)src[mt * 8 + 3];
+                v4i acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw, acc, 0, 0, 0);
+                const int qq = requant(max(max(acc[0], acc[1]), max(acc[2], acc[3])));
+                const int wx = mt * 4 + g;
+                nsat += (y355_clamp8<int>(qq) != qq && (y0 >> 1) + wy < Ho && (x0 >> 1) + wx < Wo) ? 1u : 0u;
+            }
         }
     }
     __syncthreads();
