@@ -117,12 +117,21 @@ def cpu_baseline(n_images=256):
 TINY_MMAC = [74.760192, 199.360512, 199.360512, 199.360512, 199.360512, 199.360512, 797.442048, 398.721024,
              5.537792, 598.081536, 199.360512, 6.4896, 12.9792]
 PEAK_BF16_DENSE = 2.5e15
+# myYOLOv2 on DarkNet-19 (models/yolo_v2.py, backbone/darknet.py:40-110), weight slots of csrc/net.hip kV2Ops:
+# (cin, cout, ksize, map side at 416x416 the convolution runs on); cout 0 = A * (5 + C)
+V2_LAYERS = [(3, 32, 3, 416), (32, 64, 3, 208), (64, 128, 3, 104), (128, 64, 1, 104), (64, 128, 3, 104),
+             (128, 256, 3, 52), (256, 128, 1, 52), (128, 256, 3, 52),
+             (256, 512, 3, 26), (512, 256, 1, 26), (256, 512, 3, 26), (512, 256, 1, 26), (256, 512, 3, 26),
+             (512, 1024, 3, 13), (1024, 512, 1, 13), (512, 1024, 3, 13), (1024, 512, 1, 13), (512, 1024, 3, 13),
+             (1024, 1024, 3, 13), (1024, 1024, 3, 13), (512, 64, 1, 26), (1280, 1024, 3, 13), (1024, 0, 1, 13)]
 
 
 def bench_net(args):
     """configs[2] (SlimYOLOv2 fp32 weights on bf16 MFMA, batch 64) and configs[3] (YOLOv3tiny int8 /
     bf16, batch 128) through the table-driven executor; one GPU."""
     from yolo355.netengine import Net
+    if args.workload == "yolo_v2_bf16":
+        return bench_yolo_v2(args)
     arch = "slim_yolo_v2" if args.workload == "slim_fp32" else "tiny_yolo_v3"
     dtype = "int8" if args.workload == "tiny_int8" else "bf16"
     classes = 2 if arch == "slim_yolo_v2" else 20
@@ -183,6 +192,54 @@ def bench_net(args):
                      "nms_ms": round(float(ms[-1]), 4)}}))
 
 
+def bench_yolo_v2(args):
+    """myYOLOv2 through y355_net (Y355_ARCH_YOLO_V2): 23 BN-folded convolutions on the bf16 MFMA,
+    batch 64, 416x416, 20 classes, synthetic weights; one GPU."""
+    from yolo355.netengine import Net
+    classes, B = 20, args.batch
+    dev = torch.device("cuda", 0)
+    net = Net("yolo_v2", [H, W], classes, synth.ANCHOR_SIZE, 0.01, 0.5, max_batch=B, device=dev, dtype="bf16")
+    predc = len(synth.ANCHOR_SIZE) * (5 + classes)
+    mmac = 0.0
+    for i, (ci, co, k, side) in enumerate(V2_LAYERS):
+        co = co or predc
+        w = (synth.uniform_pm1(300 + i, (co, ci, k, k)) * (1.7 / np.sqrt(ci * k * k))).astype(np.float32)
+        b = (synth.uniform_pm1(400 + i, (co,)) * (0.1 if i + 1 < len(V2_LAYERS) else 0.0)).astype(np.float32)
+        if i + 1 == len(V2_LAYERS):
+            b[:len(synth.ANCHOR_SIZE)] = -1.0          # objectness bias: detections on a fraction of the anchors
+        net.load_layer(i, w, b)
+        mmac += co * ci * k * k * side * side / 1e6
+    x = torch.from_numpy(synth.make_images(1000, B, H, W)).to(dev)
+    for _ in range(args.warmup):
+        net.forward_device(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net.forward_device(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    net.profile(True)
+    acc = None
+    for _ in range(5):
+        net.forward_device(x)
+        ms = np.array(net.profile_ms())
+        acc = ms if acc is None else acc + ms
+    ms = acc / 5
+    op_ms = float(ms[:-2].sum())
+    achieved = B * 2e6 * mmac / (op_ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "images/sec yolo_v2 (DarkNet-19) fp32 weights on bf16 MFMA 416x416", "value": round(B * args.steps / dt, 1),
+        "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "yolo_v2 bf16, batch %d, 416x416, %d classes, conf 0.01" % (B, classes),
+                   "detections_per_step": int(out[3][:B].sum().item())},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+                     "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+                     "kernel": "convg_kernel, all launches of the graph (%.1f MMAC/image)" % mmac,
+                     "op_ms": [round(float(v), 4) for v in ms[:-2]], "head_ms": round(float(ms[-2]), 4),
+                     "nms_ms": round(float(ms[-1]), 4)}}))
+
+
 def cpu_baseline_torch(n_images=16):
     """the reference's PyTorch CPU route -- the same forward restated with stock torch CPU
     ops (oracle/yolo_oracle.py: conv2d on the fake-quantised operands, numpy NMS), pinned bit-equal to the
@@ -212,7 +269,7 @@ def main():
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32 = the headline configuration (fp32 NCHW tensor resident in HBM); u8 = uint8 HWC BGR "
                          "frames with BaseTransform fused into the first layer (SURVEY 8f-1), same detections")
-    ap.add_argument("--workload", default="slim_int8", choices=["slim_int8", "slim_fp32", "tiny_int8", "tiny_bf16"],
+    ap.add_argument("--workload", default="slim_int8", choices=["slim_int8", "slim_fp32", "tiny_int8", "tiny_bf16", "yolo_v2_bf16"],
                     help="slim_int8 = the headline metric (BASELINE.json configs[1]); the others time "
                          "configs[2] / configs[3] through y355_net (single GPU, no cpu_baseline)")
     args = ap.parse_args()

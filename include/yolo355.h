@@ -219,6 +219,7 @@ int y355_debug_nms_stamps(unsigned long long *out_host);
  * fp32; prediction maps stay fp32.  Same handle rules as y355_engine. */
 #define Y355_ARCH_SLIM_V2 0
 #define Y355_ARCH_TINY_V3 1
+#define Y355_ARCH_YOLO_V2 2   /* myYOLOv2 (models/yolo_v2.py:9-232) on DarkNet-19 (backbone/darknet.py:40-110); bf16 only */
 #define Y355_DT_INT8 0
 #define Y355_DT_BF16 1
 typedef struct y355_net y355_net;

@@ -163,7 +163,7 @@ def test_yolo_v2_dropin_matches_reference(case):
     # 23 bf16 layers: the error of a map with |values| up to ~7 stays below 2 % of the range, mean below 0.5 %
     assert err.max() < 0.02 * np.abs(ref).max() + 0.05, float(err.max())
     assert err.mean() < 0.005 * np.abs(ref).max(), float(err.mean())
-    b, s, c = m(x)
+    b, s, c = m.forward_batch_composed(x)[0]
     assert b.dtype == np.float32 and s.dtype == np.float32 and c.dtype == np.int64 and b.flags.writeable
     fr, fg = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b, s, c), iou_min=0.7, score_tol=0.08)
     assert fr > 0.9 and fg > 0.9, (fr, fg)
@@ -171,6 +171,25 @@ def test_yolo_v2_dropin_matches_reference(case):
     want = F.detect_v2(pred, synth.ANCHOR_SIZE, classes, size, 32, 0.05, 0.5)[0]
     assert len(want[1]) == len(s) and np.array_equal(want[2], c)
     assert np.abs(want[0] - b).max() < 2e-5 and np.abs(want[1] - s).max() < 2e-6
+    # ---- the GPU-resident graph (y355_net, Y355_ARCH_YOLO_V2): same tolerances against the reference, and the
+    # same numbers as the layer-by-layer form up to the bf16 rounding of intermediate maps (here: identical maps,
+    # both forms round every activation to bf16 and accumulate in fp32 in the same order)
+    b2, s2, c2 = m(x)
+    assert b2.dtype == np.float32 and s2.dtype == np.float32 and c2.dtype == np.int64 and b2.flags.writeable
+    fr, fg = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b2, s2, c2), iou_min=0.7, score_tol=0.08)
+    assert fr > 0.9 and fg > 0.9, (fr, fg)
+    net = m._get_net(1)
+    pred2 = net.get_tensor(net.num_tensors - 1, 1)
+    err = np.abs(pred2 - ref)
+    assert err.max() < 0.02 * np.abs(ref).max() + 0.05 and err.mean() < 0.005 * np.abs(ref).max(), (float(err.max()), float(err.mean()))
+    assert np.abs(pred2 - pred).max() < 0.02 * np.abs(ref).max()
+    want = F.detect_v2(pred2, synth.ANCHOR_SIZE, classes, size, 32, 0.05, 0.5)[0]
+    assert len(want[1]) == len(s2) and np.array_equal(want[2], c2)
+    assert np.abs(want[0] - b2).max() < 2e-5 and np.abs(want[1] - s2).max() < 2e-6
+    # batch semantics: element i of a batch equals the single-image run
+    xb = torch.from_numpy(np.concatenate([synth.make_images(seed + 1 + i, 1, size[0], size[1]) for i in range(3)])).cuda()
+    outs = m.forward_batch(xb)
+    assert all(np.array_equal(p, q) for p, q in zip(outs[0], (b2, s2, c2)))
 
 
 @pytest.mark.parametrize("case", WIDE_MODEL_CASES, ids=[c[0] for c in WIDE_MODEL_CASES])

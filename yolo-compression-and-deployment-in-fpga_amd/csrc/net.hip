@@ -25,7 +25,7 @@ int y355_prepare_kernels();
     } while (0)
 
 namespace {
-enum { OP_CONV1 = 0, OP_CONV, OP_POOL, OP_UPSAMPLE };
+enum { OP_CONV1 = 0, OP_CONV, OP_POOL, OP_UPSAMPLE, OP_INPUT, OP_REORG };
 enum { ACT_NONE = 0, ACT_L125, ACT_L100 };     // LeakyReLU(0.125) utils/modules.py:15; (0.1) backbone/darknet.py:18
 
 struct TensorDef { int C, div, pred; };        // channels; H = height / div; pred: prediction map (no halo)
@@ -76,9 +76,54 @@ const OpDef kTinyOps[] = {
     {OP_CONV, 12, 14, 0, 11, 512, 0, 1, 0, ACT_NONE},      // pred_2 (stride 32)
     {OP_CONV, 11, 13, 0, 12, 256, 0, 1, 0, ACT_NONE},      // pred_1 (stride 16)
 };
-const ArchDef kArch[2] = {
+// ---- myYOLOv2 (models/yolo_v2.py:26-39, 165-179) on DarkNet-19 (backbone/darknet.py:40-110); bf16 only
+const TensorDef kV2T[] = {
+    {3, 1, 0},                                                   //  0 input as bf16 NHWC16
+    {32, 2, 0}, {64, 4, 0},                                      //  1 conv_1+pool, 2 conv_2+pool
+    {128, 4, 0}, {64, 4, 0}, {128, 8, 0},                        //  3..5 conv_3 (last pooled)
+    {256, 8, 0}, {128, 8, 0}, {256, 8, 0}, {256, 16, 0},         //  6..8 conv_4 (8 = C_4), 9 maxpool_4
+    {512, 16, 0}, {256, 16, 0}, {512, 16, 0}, {256, 16, 0}, {512, 16, 0},   // 10..14 conv_5 (14 = C_5)
+    {512, 32, 0},                                                // 15 maxpool_5
+    {1024, 32, 0}, {512, 32, 0}, {1024, 32, 0}, {512, 32, 0}, {1024, 32, 0},   // 16..20 conv_6 (20 = C_6)
+    {1024, 32, 0},                                               // 21 convsets_1[0]
+    {64, 16, 0},                                                 // 22 route_layer
+    {1280, 32, 0},                                               // 23 cat(reorg(route) [0:256), convsets_1 [256:1280))
+    {1024, 32, 0},                                               // 24 convsets_2
+    {0, 32, 1},                                                  // 25 pred
+};
+const OpDef kV2Ops[] = {
+    {OP_INPUT, -1, 0, 0, -1, 3, 3, 0, 0, 0},
+    {OP_CONV, 0, 1, 0, 0, 3, 32, 3, 1, ACT_L100},
+    {OP_CONV, 1, 2, 0, 1, 32, 64, 3, 1, ACT_L100},
+    {OP_CONV, 2, 3, 0, 2, 64, 128, 3, 0, ACT_L100},
+    {OP_CONV, 3, 4, 0, 3, 128, 64, 1, 0, ACT_L100},
+    {OP_CONV, 4, 5, 0, 4, 64, 128, 3, 1, ACT_L100},
+    {OP_CONV, 5, 6, 0, 5, 128, 256, 3, 0, ACT_L100},
+    {OP_CONV, 6, 7, 0, 6, 256, 128, 1, 0, ACT_L100},
+    {OP_CONV, 7, 8, 0, 7, 128, 256, 3, 0, ACT_L100},
+    {OP_POOL, 8, 9, 0, -1, 256, 256, 2, 0, 0},
+    {OP_CONV, 9, 10, 0, 8, 256, 512, 3, 0, ACT_L100},
+    {OP_CONV, 10, 11, 0, 9, 512, 256, 1, 0, ACT_L100},
+    {OP_CONV, 11, 12, 0, 10, 256, 512, 3, 0, ACT_L100},
+    {OP_CONV, 12, 13, 0, 11, 512, 256, 1, 0, ACT_L100},
+    {OP_CONV, 13, 14, 0, 12, 256, 512, 3, 0, ACT_L100},
+    {OP_POOL, 14, 15, 0, -1, 512, 512, 2, 0, 0},
+    {OP_CONV, 15, 16, 0, 13, 512, 1024, 3, 0, ACT_L100},
+    {OP_CONV, 16, 17, 0, 14, 1024, 512, 1, 0, ACT_L100},
+    {OP_CONV, 17, 18, 0, 15, 512, 1024, 3, 0, ACT_L100},
+    {OP_CONV, 18, 19, 0, 16, 1024, 512, 1, 0, ACT_L100},
+    {OP_CONV, 19, 20, 0, 17, 512, 1024, 3, 0, ACT_L100},
+    {OP_CONV, 20, 21, 0, 18, 1024, 1024, 3, 0, ACT_L125},        // convsets_1[0]
+    {OP_CONV, 21, 23, 256, 19, 1024, 1024, 3, 0, ACT_L125},      // convsets_1[1] -> cat[256:1280)
+    {OP_CONV, 14, 22, 0, 20, 512, 64, 1, 0, ACT_L125},           // route_layer on C_5
+    {OP_REORG, 22, 23, 0, -1, 64, 256, 2, 0, 0},                 // reorg(stride 2) -> cat[0:256)
+    {OP_CONV, 23, 24, 0, 21, 1280, 1024, 3, 0, ACT_L125},        // convsets_2
+    {OP_CONV, 24, 25, 0, 22, 1024, 0, 1, 0, ACT_NONE},           // pred (1x1)
+};
+const ArchDef kArch[3] = {
     {10, kSlimT, 10, kSlimOps, 10, 1, {9, -1}, {16.f, 0.f}},
     {15, kTinyT, 16, kTinyOps, 13, 2, {13, 14}, {16.f, 32.f}},
+    {26, kV2T, 27, kV2Ops, 23, 1, {25, -1}, {32.f, 0.f}},
 };
 
 struct Tensor {
@@ -284,7 +329,10 @@ extern "C" void y355_net_destroy(y355_net *h) {
 
 extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (!cfg || !out) return y355_fail(Y355_EINVAL, "null argument");
-    if (cfg->arch != Y355_ARCH_SLIM_V2 && cfg->arch != Y355_ARCH_TINY_V3) return y355_fail(Y355_EINVAL, "unknown arch");
+    if (cfg->arch != Y355_ARCH_SLIM_V2 && cfg->arch != Y355_ARCH_TINY_V3 && cfg->arch != Y355_ARCH_YOLO_V2)
+        return y355_fail(Y355_EINVAL, "unknown arch");
+    if (cfg->arch == Y355_ARCH_YOLO_V2 && cfg->dtype != Y355_DT_BF16)
+        return y355_fail(Y355_EINVAL, "yolo_v2 is built in bf16 only (the reference has no quantized form of it)");
     if (cfg->dtype != Y355_DT_BF16 && cfg->dtype != Y355_DT_INT8) return y355_fail(Y355_EINVAL, "unknown dtype");
     if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % 32 || cfg->width % 32)
         return y355_fail(Y355_EINVAL, "input size must be a positive multiple of 32");
@@ -572,6 +620,38 @@ static int refresh_i8(y355_net *h) {
     return 0;
 }
 
+// fp32 NCHW [B][3][H][W] -> bf16 NHWC16 with halo (channels 3..15 stay zero)
+__global__ void input_bf16_kernel(const float *x, char *out, int B, int H, int W, int out_pb) {
+    const size_t total = (size_t)B * H * W;
+    const size_t plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W), y = (int)((i / W) % H);
+        const size_t b = i / plane;
+        const float *src = x + b * 3 * plane + (size_t)y * W + xx;
+        unsigned short h3[4] = {__builtin_bit_cast(unsigned short, (__bf16)src[0]), __builtin_bit_cast(unsigned short, (__bf16)src[plane]),
+                                __builtin_bit_cast(unsigned short, (__bf16)src[2 * plane]), 0};
+        uint2 u;
+        u.x = (unsigned int)h3[0] | ((unsigned int)h3[1] << 16);
+        u.y = (unsigned int)h3[2];
+        *(uint2 *)(out + ((b * (H + 2) + y + 1) * (size_t)(W + 2) + xx + 1) * out_pb) = u;
+    }
+}
+// utils.modules.reorg_layer (utils/modules.py:48-57) on bf16 NHWC: out[.., (sy*s+sx)*C + c] = in[s*y+sy][s*x+sx][c];
+// 16 bytes (8 channels) per thread
+__global__ void reorg_bf16_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int C, int out_pb, int out_off, int s) {
+    const int Ho = Hin / s, Wo = Win / s, cg = C / 8;
+    const size_t total = (size_t)B * Ho * Wo * s * s * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int k = (int)((i / cg) % (s * s));
+        const int x = (int)((i / ((size_t)cg * s * s)) % Wo), y = (int)((i / ((size_t)cg * s * s * Wo)) % Ho);
+        const size_t b = i / ((size_t)cg * s * s * Wo * Ho);
+        const int sy = k / s, sx = k % s;
+        const uint4 v = *(const uint4 *)(in + ((b * (Hin + 2) + (size_t)s * y + sy + 1) * (Win + 2) + (size_t)s * x + sx + 1) * in_pb + g * 16);
+        *(uint4 *)(out + ((b * (Ho + 2) + y + 1) * (size_t)(Wo + 2) + x + 1) * out_pb + out_off + ((size_t)k * C + g * 8) * 2) = v;
+    }
+}
+
 static float act_slope(int act) { return act == ACT_L125 ? 0.125f : act == ACT_L100 ? 0.1f : 1.0f; }
 
 static int run_op(y355_net *h, int i, int B, const float *x_dev) {
@@ -650,6 +730,16 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
         else
             hipLaunchKernelGGL(pool_i8_kernel, dim3(blocks), dim3(256), 0, s, ti.dev, to.dev, B, ti.H, ti.W, (int)ti.pb,
                                o.cin * h->es, to.H, to.W, (int)to.pb, stride);
+    } else if (o.type == OP_INPUT) {
+        const Tensor &to = h->T[o.out];
+        const size_t total = (size_t)B * to.H * to.W;
+        hipLaunchKernelGGL(input_bf16_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, x_dev, to.dev, B,
+                           to.H, to.W, (int)to.pb);
+    } else if (o.type == OP_REORG) {
+        const Tensor &ti = h->T[o.in], &to = h->T[o.out];
+        const size_t total = (size_t)B * to.H * to.W * o.ksize * o.ksize * (o.cin / 8);
+        hipLaunchKernelGGL(reorg_bf16_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, ti.dev, to.dev, B,
+                           ti.H, ti.W, (int)ti.pb, o.cin, (int)to.pb, o.choff * h->es, o.ksize);
     } else {
         const Tensor &ti = h->T[o.in], &to = h->T[o.out];
         const size_t total = (size_t)B * to.H * to.W * o.cin;
@@ -685,7 +775,7 @@ static HeadParams net_head_params(y355_net *h, float *ob, float *os, int *oc, in
     p.A = h->cfg.num_anchors;
     p.C = h->cfg.num_classes;
     // slim-YOLOv2 anchors are in grid units (models/slim_yolo_v2.py:126), tiny-v3's in pixels (tiny_yolo_v3.py:85)
-    p.wh_mul = h->cfg.arch == Y355_ARCH_SLIM_V2 ? 16.0f : 1.0f;
+    p.wh_mul = h->cfg.arch == Y355_ARCH_SLIM_V2 ? 16.0f : (h->cfg.arch == Y355_ARCH_YOLO_V2 ? 32.0f : 1.0f);
     // fp32 / multi-level heads: box sizes spread over many octaves per anchor -> group by area
     // (YOLOv3tiny int8, B = 128: NMS 1.08 -> 0.50 ms; SlimYOLOv2 bf16: 0.45 -> 0.32 ms)
     p.group_by_area = 1;

@@ -36,7 +36,7 @@ class NetConfig(C.Structure):
                 ("own_stream", C.c_int32)]
 
 
-ARCH_SLIM_V2, ARCH_TINY_V3 = 0, 1
+ARCH_SLIM_V2, ARCH_TINY_V3, ARCH_YOLO_V2 = 0, 1, 2
 DT_INT8, DT_BF16 = 0, 1
 
 

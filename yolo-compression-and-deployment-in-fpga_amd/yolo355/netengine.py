@@ -9,7 +9,7 @@ import torch
 from . import _ffi
 from .engine import _require_gpu
 
-ARCH = {"slim_yolo_v2": _ffi.ARCH_SLIM_V2, "tiny_yolo_v3": _ffi.ARCH_TINY_V3}
+ARCH = {"slim_yolo_v2": _ffi.ARCH_SLIM_V2, "tiny_yolo_v3": _ffi.ARCH_TINY_V3, "yolo_v2": _ffi.ARCH_YOLO_V2}
 DTYPE = {"int8": _ffi.DT_INT8, "bf16": _ffi.DT_BF16}
 
 
