@@ -184,7 +184,8 @@ int y355_upsample2x_f32(int device_id, const float *in, int batch, int channels,
  * pred[l] = NCHW [B][A*(5+C)][hs[l]][ws[l]] (host), 1 or 2 levels, channel layout [obj x A | cls x A*C | txtytwth x A*4];
  * anchors [nlev][A][2]; wh_mul = the stride for anchors in grid units (yolo_v2), 1 for anchors in pixels (v3 family).
  * Outputs as y355_forward: boxes f32 [B][max_det][4] normalised x1y1x2y2, scores, classes, counts; anchor-index order.
- * At most 4096 anchors per image. */
+ * Images with more than 4096 anchors (yolo_v3 at 416 x 416: 10 647) are thresholded and compacted on the GPU before the
+ * sort; at most 4096 anchors per image may pass conf_thresh (else Y355_EINVAL). */
 int y355_head_f32(int device_id, int nlev, const float *const *pred, const int *hs, const int *ws, const float *strides,
                   const float *anchors, int num_anchors, int num_classes, int in_h, int in_w, float wh_mul,
                   float conf_thresh, float nms_thresh, int batch, int max_det, float *boxes, float *scores,

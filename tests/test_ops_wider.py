@@ -253,3 +253,27 @@ def test_yolo_v3_dropins_match_reference(case):
     want = F.detect_v3(preds, synth.MULTI_ANCHOR_SIZE, classes, size, 0.05, 0.5)[0]
     assert len(want[1]) == len(s) and np.array_equal(want[2], c)
     assert np.abs(want[0] - b).max() < 2e-5 and np.abs(want[1] - s).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_head_with_more_than_4096_anchors():
+    """yolo_v3 at 416 x 416 has 10 647 anchors per image: threshold-then-compact in front of the sort.  Exact against
+    the numpy restatement on the same maps; loud when more than 4096 anchors pass the threshold."""
+    from yolo355 import engine as E, synth
+    from yolo355._ffi import Y355Error
+    from oracle import fp32_oracle as F
+    C, A, size = 20, 3, [416, 416]
+    preds = []
+    for li, s in enumerate((8, 16, 32)):
+        hs = 416 // s
+        p = synth.uniform_pm1(9100 + li, (2, A * (5 + C), hs, hs)).astype(np.float32) * 3.0
+        p[:, :A] -= 3.5                                              # objectness: a minority of the anchors pass 0.05
+        preds.append(p)
+    got = E.head_f32(preds, (8, 16, 32), np.asarray(synth.MULTI_ANCHOR_SIZE, np.float32).reshape(3, A, 2), C, size, 1.0, 0.05, 0.5)
+    want = F.detect_v3(preds, synth.MULTI_ANCHOR_SIZE, C, size, 0.05, 0.5)
+    for g, w in zip(got, want):
+        assert 100 < len(w[1]) and len(g[1]) == len(w[1]), (len(g[1]), len(w[1]))
+        assert np.array_equal(g[2], w[2])
+        assert np.abs(g[0] - w[0]).max() < 2e-5 and np.abs(g[1] - w[1]).max() < 2e-6
+    with pytest.raises(Y355Error, match="4096"):
+        E.head_f32(preds, (8, 16, 32), np.asarray(synth.MULTI_ANCHOR_SIZE, np.float32).reshape(3, A, 2), C, size, 1.0, 1e-6, 0.5)

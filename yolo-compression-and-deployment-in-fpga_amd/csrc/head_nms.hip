@@ -51,6 +51,15 @@ struct HeadWork {
     float *dbox;          // [B][CAP][4]  decode of every anchor, (level, anchor, cell) order
     float *dscore;        // [B][CAP]
     int *dcls;            // [B][CAP]
+    // heads with more than CAP anchors per image (three-level models at 416 x 416): decode_kernel writes the raw arrays
+    // (pitch rstride), compact_kernel keeps the anchors at or above conf_thresh in anchor-index order in dbox / dscore /
+    // dcls (at most CAP of them; more sets ovf[b]); the sort then sees an ordinary <= CAP-anchor image
+    float *rbox;          // [B][rstride][4] or null (= small head: decode writes dbox directly)
+    float *rscore;        // [B][rstride]
+    int *rcls;            // [B][rstride]
+    int *rcount;          // [B] anchors kept by the compaction
+    int *ovf;             // [B] 1: more than CAP anchors passed the threshold (the rest were dropped)
+    int rstride;
     unsigned long long *stamps;   // diagnostics or null
 };
 
@@ -114,16 +123,74 @@ __global__ __launch_bounds__(256) void decode_kernel(const HeadParams p, const H
     bx4.y = fminf(fmaxf((cy - bh / 2) / p.in_h, 0.f), 1.f);
     bx4.z = fminf(fmaxf((cx + bw / 2) / p.in_w, 0.f), 1.f);
     bx4.w = fminf(fmaxf((cy + bh / 2) / p.in_h, 0.f), 1.f);
-    const size_t o = (size_t)b * NMS_CAP + np;
-    ((float4 *)wk.dbox)[o] = bx4;
-    wk.dscore[o] = best;
-    wk.dcls[o] = bc;
+    if (wk.rbox) {
+        const size_t o = (size_t)b * wk.rstride + np;
+        ((float4 *)wk.rbox)[o] = bx4;
+        wk.rscore[o] = best;
+        wk.rcls[o] = bc;
+    } else {
+        const size_t o = (size_t)b * NMS_CAP + np;
+        ((float4 *)wk.dbox)[o] = bx4;
+        wk.dscore[o] = best;
+        wk.dcls[o] = bc;
+    }
     if (p.cand_score) {      // full per-anchor tap (parity tests)
         p.cand_score[(size_t)b * N + n] = best;
         p.cand_cls[(size_t)b * N + n] = bc;
         *(float4 *)(p.cand_box + ((size_t)b * N + n) * 4) = bx4;
     }
 }
+
+// ---- compact_kernel (heads with more than CAP anchors): one workgroup per image walks the anchors in the reference's
+// anchor-index order n (level, cell, anchor), keeps those with score >= conf_thresh, in order, up to CAP.
+__global__ __launch_bounds__(1024) void compact_kernel(const HeadParams p, const HeadWork wk) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A = p.A;
+    const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
+    const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0, N1 = N0 + HW1 * A;
+    const int HW2 = p.nlev > 2 ? p.lev[2].Hs * p.lev[2].Ws : 0;
+    const int N = N1 + HW2 * A;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    const float4 *rb = (const float4 *)wk.rbox + (size_t)b * wk.rstride;
+    const float *rs = wk.rscore + (size_t)b * wk.rstride;
+    const int *rc = wk.rcls + (size_t)b * wk.rstride;
+    float4 *db = (float4 *)wk.dbox + (size_t)b * NMS_CAP;
+    float *ds = wk.dscore + (size_t)b * NMS_CAP;
+    int *dc = wk.dcls + (size_t)b * NMS_CAP;
+    int overflow = 0;
+    for (int n0 = 0; n0 < N; n0 += 1024) {
+        const int n = n0 + tid;
+        bool keep = false;
+        int np = 0;
+        if (n < N) {
+            const int lv = (n >= N0 ? 1 : 0) + (n >= N1 ? 1 : 0);
+            const int lbase = lv == 0 ? 0 : (lv == 1 ? N0 : N1), HWl = lv == 0 ? HW0 : (lv == 1 ? HW1 : HW2);
+            const int cell = (n - lbase) / A, a = (n - lbase) % A;
+            np = lbase + a * HWl + cell;                     // where decode_kernel put anchor n
+            keep = rs[np] >= p.conf_thresh;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const int pos = off + before;
+        if (keep) {
+            if (pos < NMS_CAP) { db[pos] = rb[np]; ds[pos] = rs[np]; dc[pos] = rc[np]; }
+            else overflow = 1;
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base_s += t; }
+        __syncthreads();
+    }
+    if (__syncthreads_or(overflow) && tid == 0) wk.ovf[b] = 1;
+    if (tid == 0) wk.rcount[b] = min(base_s, NMS_CAP);
+}
+
 
 __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const HeadWork wk) {
     __shared__ int hist[NMS_CAP];          // bin counts -> bin starts
@@ -136,7 +203,8 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
     const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0, N1 = N0 + HW1 * A;
     const int HW2 = p.nlev > 2 ? p.lev[2].Hs * p.lev[2].Ws : 0;
-    const int N = N1 + HW2 * A;
+    const bool compacted = wk.rbox != nullptr;             // anchors already thresholded and in anchor-index order
+    const int N = compacted ? wk.rcount[b] : N1 + HW2 * A;
     const int HWb = p.Hb * p.Wb;
     for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
     if (tid < MAXA) {
@@ -183,7 +251,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             const int lbase = lv == 0 ? 0 : (lv == 1 ? N0 : N1);
             const int npl = np - lbase, HWl = lv == 0 ? HW0 : (lv == 1 ? HW1 : HW2);
             const int a = npl / HWl, cell = npl % HWl;
-            orig[u] = lbase + cell * A + a;
+            orig[u] = compacted ? np : lbase + cell * A + a;     // compacted: position = rank in anchor-index order
             valid[u] = score[u] >= p.conf_thresh;
             if (valid[u]) {
                 // candidate group: the anchor type, or (group_by_area) the octave of the clamped box's
@@ -685,7 +753,15 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     {
         int n = 0;
         for (int l = 0; l < p.nlev; ++l) n += p.lev[l].Hs * p.lev[l].Ws * p.A;
+        const bool large = n > NMS_CAP;                     // callers allocate the raw arrays for such heads
+        wk.rbox = large ? (float *)ws.rbox : nullptr;
+        wk.rscore = (float *)ws.rscore;
+        wk.rcls = (int *)ws.rcls;
+        wk.rcount = (int *)ws.rcount;
+        wk.ovf = (int *)ws.ovf;
+        wk.rstride = ws.rstride;
         hipLaunchKernelGGL(decode_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, s, p, wk);
+        if (large) hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     }
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);

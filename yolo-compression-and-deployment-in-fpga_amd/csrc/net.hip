@@ -939,8 +939,9 @@ extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, 
         if (!pred[l] || hs[l] < 1 || ws[l] < 1) return y355_fail(Y355_EINVAL, "bad prediction level");
         N += hs[l] * ws[l] * num_anchors;
     }
-    if (N > Y355_NMS_CAP) return y355_fail(Y355_EINVAL, "more than 4096 anchors per image not supported");
-    if (max_det > N) max_det = N;
+    if (N > 16 * Y355_NMS_CAP) return y355_fail(Y355_EINVAL, "more than 65536 anchors per image not supported");
+    const bool large = N > Y355_NMS_CAP;          // threshold-then-compact in front of the sort (head_nms.hip)
+    if (max_det > (large ? Y355_NMS_CAP : N)) max_det = large ? Y355_NMS_CAP : N;
     HIPCHK(hipSetDevice(device_id));
     if (int e = y355_prepare_kernels()) return e;
     std::vector<void *> bufs;
@@ -986,6 +987,14 @@ extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, 
     if (!rc) rc = alloc(&w.dscore, sizeof(float) * cap * B, true);
     if (!rc) rc = alloc(&w.dcls, sizeof(int) * cap * B, true);
     if (!rc) rc = alloc(&w.ctype, sizeof(int) * cap * B, true);
+    if (large) {
+        w.rstride = (N + 3) / 4 * 4;
+        if (!rc) rc = alloc(&w.rbox, sizeof(float) * 4 * (size_t)w.rstride * B, true);
+        if (!rc) rc = alloc(&w.rscore, sizeof(float) * (size_t)w.rstride * B, true);
+        if (!rc) rc = alloc(&w.rcls, sizeof(int) * (size_t)w.rstride * B, true);
+        if (!rc) rc = alloc(&w.rcount, sizeof(int) * B, true);
+        if (!rc) rc = alloc(&w.ovf, sizeof(int) * B, true);
+    }
     if (!rc) rc = alloc((void **)&d_box, sizeof(float) * 4 * (size_t)max_det * B, true);
     if (!rc) rc = alloc((void **)&d_score, sizeof(float) * (size_t)max_det * B, true);
     if (!rc) rc = alloc((void **)&d_cls, sizeof(int) * (size_t)max_det * B, true);
@@ -1026,7 +1035,14 @@ extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, 
     if (e == hipSuccess) e = hipMemcpy(scores, d_score, sizeof(float) * (size_t)max_det * B, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(cls, d_cls, sizeof(int) * (size_t)max_det * B, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(count, d_count, sizeof(int) * B, hipMemcpyDeviceToHost);
+    bool overflow = false;
+    if (e == hipSuccess && large) {
+        std::vector<int> ovf(B, 0);
+        e = hipMemcpy(ovf.data(), w.ovf, sizeof(int) * B, hipMemcpyDeviceToHost);
+        for (int v : ovf) overflow |= v != 0;
+    }
     release();
+    if (overflow) return y355_fail(Y355_EINVAL, "more than 4096 anchors of an image pass conf_thresh: raise the threshold");
     if (e != hipSuccess) return y355_fail(Y355_EHIP, std::string("head: ") + hipGetErrorString(e));
     return 0;
 }

@@ -195,7 +195,11 @@ struct HeadParams {
 // count i32, edges u32[64*CAP] (suppressing pairs), nedges i32[2] (count, overflow flag),
 // binstart i32[CAP+8], astat f32[16][4], tiny i32[CAP], ntiny i32, ctype i32[CAP] (candidate group),
 // dbox f32[CAP][4] / dscore f32[CAP] / dcls i32[CAP] (decode of every anchor).
-struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *edges, *nedges, *binstart, *astat, *tiny, *ntiny, *ctype, *dbox, *dscore, *dcls; };
+// Heads with more than Y355_NMS_CAP anchors per image also need rbox f32[rstride][4], rscore f32[rstride], rcls i32[rstride]
+// (raw decode, rstride >= anchors per image), rcount i32, ovf i32 (more than CAP anchors passed conf_thresh: zero it before
+// a forward, check it after).
+struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *edges, *nedges, *binstart, *astat, *tiny, *ntiny, *ctype, *dbox, *dscore, *dcls;
+                      void *rbox = nullptr, *rscore = nullptr, *rcls = nullptr, *rcount = nullptr, *ovf = nullptr; int rstride = 0; };
 int y355_prepare_head(void);
 // decode, candidate sort, pruned pair walk (edge list), rounds + output.  `mid` (optional) is recorded
 // between the candidate sort and the pair walk.

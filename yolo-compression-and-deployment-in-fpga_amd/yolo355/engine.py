@@ -429,7 +429,7 @@ def head_f32(preds, strides, anchors, num_classes, input_size, wh_mul, conf_thre
     ws = (C.c_int * nlev)(*[p.shape[3] for p in ps])
     st = (C.c_float * nlev)(*[float(s) for s in strides])
     ptrs = (C.c_void_p * nlev)(*[p.ctypes.data for p in ps])
-    N = sum(p.shape[2] * p.shape[3] * A for p in ps)
+    N = min(sum(p.shape[2] * p.shape[3] * A for p in ps), 4096)      # the head keeps at most 4096 candidates per image
     md = N if max_det is None else min(int(max_det), N)
     boxes = np.zeros((B, md, 4), np.float32)
     scores = np.zeros((B, md), np.float32)

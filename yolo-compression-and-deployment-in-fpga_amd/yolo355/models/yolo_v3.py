@@ -3,8 +3,9 @@ DarkNet-53 backbone (stride-2 convolutions, residual blocks), three prediction l
 1x1 convolutions and bilinear x2 up-sampling, optional SPP in front of the stride-32 branch.  Same constructor,
 attribute names (checkpoints load unchanged) and eval-mode return value.  The graph runs layer by layer through the
 operator API of the wider model families (y355_conv2d_bf16 with the residual add in its epilogue, y355_spp_f32,
-y355_upsample2x_f32, y355_head_f32 -- SURVEY.md 8f-3): functional (parity, bring-up), not the fast path; the head
-holds at most 4096 anchors per image (input sizes up to 256 x 256 with three anchors per level).  Training is not built."""
+y355_upsample2x_f32, y355_head_f32 -- SURVEY.md 8f-3): functional (parity, bring-up), not the fast path.  At 416 x 416 an
+image has 10 647 anchors: the head thresholds and compacts them on the GPU, and at most 4096 may pass conf_thresh.
+Training is not built."""
 import numpy as np
 import torch
 import torch.nn as nn
