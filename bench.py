@@ -132,6 +132,8 @@ def bench_net(args):
     from yolo355.netengine import Net
     if args.workload == "yolo_v2_bf16":
         return bench_yolo_v2(args)
+    if args.workload in ("yolo_v3_bf16", "yolo_v3_spp_bf16"):
+        return bench_yolo_v3(args)
     arch = "slim_yolo_v2" if args.workload == "slim_fp32" else "tiny_yolo_v3"
     dtype = "int8" if args.workload == "tiny_int8" else "bf16"
     classes = 2 if arch == "slim_yolo_v2" else 20
@@ -240,6 +242,81 @@ def bench_yolo_v2(args):
                      "nms_ms": round(float(ms[-1]), 4)}}))
 
 
+def v3_mmac(S, predc, spp):
+    """conv MMAC per image of myYOLOv3 / myYOLOv3Spp at S x S (models/yolo_v3.py:26-61, backbone/darknet.py:112-161)"""
+    t = 0.0
+
+    def c(ci, co, k, side):
+        nonlocal t
+        t += ci * co * k * k * side * side / 1e6
+
+    def res(ch, side, n):
+        for _ in range(n):
+            c(ch, ch // 2, 1, side)
+            c(ch // 2, ch, 3, side)
+    c(3, 32, 3, S); c(32, 64, 3, S // 2); res(64, S // 2, 1)
+    c(64, 128, 3, S // 4); res(128, S // 4, 2)
+    c(128, 256, 3, S // 8); res(256, S // 8, 8)
+    c(256, 512, 3, S // 16); res(512, S // 16, 8)
+    c(512, 1024, 3, S // 32); res(1024, S // 32, 4)
+    for side, cin0, a, b in ((S // 32, 4096 if spp else 1024, 512, 1024), (S // 16, 768, 256, 512), (S // 8, 384, 128, 256)):
+        c(cin0, a, 1, side); c(a, b, 3, side); c(b, a, 1, side); c(a, b, 3, side); c(b, a, 1, side)
+        if side != S // 8:
+            c(a, a // 2, 1, side)
+        c(a, b, 3, side); c(b, predc, 1, side)
+    return t
+
+
+def bench_yolo_v3(args):
+    """myYOLOv3 / myYOLOv3Spp through y355_net: 75 BN-folded convolutions on the bf16 MFMA, batch 32,
+    416x416, 20 classes; weights = the drop-in class's default initialisation under torch.manual_seed(0), BatchNorm
+    folded by the class; one GPU.  10 647 anchors per image: threshold-then-compact head, conf 0.1."""
+    from yolo355.models.yolo_v3 import myYOLOv3, myYOLOv3Spp
+    spp = args.workload == "yolo_v3_spp_bf16"
+    classes = 20
+    B = args.batch if args.batch != PER_GPU_BATCH else 32
+    torch.manual_seed(0)
+    m = (myYOLOv3Spp if spp else myYOLOv3)("cuda:0", input_size=[H, W], num_classes=classes, trainable=False, conf_thresh=0.1,
+                                           nms_thresh=0.5, anchor_size=synth.MULTI_ANCHOR_SIZE).eval()
+    with torch.no_grad():
+        for pr in (m.pred_1, m.pred_2, m.pred_3):
+            pr.bias[:3] = -2.0                         # objectness: a fraction of the anchors above the threshold
+    net = m._get_net(B)
+    net.set_thresholds(0.1, 0.5)
+    x = torch.from_numpy(synth.make_images(1000, B, H, W)).cuda()
+    for _ in range(args.warmup):
+        net.forward_device(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net.forward_device(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if net.overflow():
+        raise RuntimeError("more than 4096 anchors of an image passed the threshold")
+    net.profile(True)
+    acc = None
+    for _ in range(5):
+        net.forward_device(x)
+        ms = np.array(net.profile_ms())
+        acc = ms if acc is None else acc + ms
+    ms = acc / 5
+    mmac = v3_mmac(H, 3 * (5 + classes), spp)
+    op_ms = float(ms[:-2].sum())
+    achieved = B * 2e6 * mmac / (op_ms * 1e-3) / 1e12
+    name = "yolo_v3_spp" if spp else "yolo_v3"
+    print(json.dumps({
+        "metric": "images/sec %s (DarkNet-53) fp32 weights on bf16 MFMA 416x416" % name, "value": round(B * args.steps / dt, 1),
+        "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "%s bf16, batch %d, 416x416, %d classes, conf 0.1" % (name, B, classes),
+                   "detections_per_step": int(out[3][:B].sum().item())},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+                     "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+                     "kernel": "convg_kernel and the graph's other launches (%.1f MMAC/image)" % mmac,
+                     "head_ms": round(float(ms[-2]), 4), "nms_ms": round(float(ms[-1]), 4)}}))
+
+
 def cpu_baseline_torch(n_images=16):
     """the reference's PyTorch CPU route -- the same forward restated with stock torch CPU
     ops (oracle/yolo_oracle.py: conv2d on the fake-quantised operands, numpy NMS), pinned bit-equal to the
@@ -269,7 +346,7 @@ def main():
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32 = the headline configuration (fp32 NCHW tensor resident in HBM); u8 = uint8 HWC BGR "
                          "frames with BaseTransform fused into the first layer (SURVEY 8f-1), same detections")
-    ap.add_argument("--workload", default="slim_int8", choices=["slim_int8", "slim_fp32", "tiny_int8", "tiny_bf16", "yolo_v2_bf16"],
+    ap.add_argument("--workload", default="slim_int8", choices=["slim_int8", "slim_fp32", "tiny_int8", "tiny_bf16", "yolo_v2_bf16", "yolo_v3_bf16", "yolo_v3_spp_bf16"],
                     help="slim_int8 = the headline metric (BASELINE.json configs[1]); the others time "
                          "configs[2] / configs[3] through y355_net (single GPU, no cpu_baseline)")
     args = ap.parse_args()

@@ -221,6 +221,8 @@ int y355_debug_nms_stamps(unsigned long long *out_host);
 #define Y355_ARCH_SLIM_V2 0
 #define Y355_ARCH_TINY_V3 1
 #define Y355_ARCH_YOLO_V2 2   /* myYOLOv2 (models/yolo_v2.py:9-232) on DarkNet-19 (backbone/darknet.py:40-110); bf16 only */
+#define Y355_ARCH_YOLO_V3 3   /* myYOLOv3 (models/yolo_v3.py:9-304) on DarkNet-53 (backbone/darknet.py:112-161); bf16 only */
+#define Y355_ARCH_YOLO_V3_SPP 4   /* myYOLOv3Spp (models/yolo_v3_spp.py): SPP in front of the stride-32 branch; bf16 only */
 #define Y355_DT_INT8 0
 #define Y355_DT_BF16 1
 typedef struct y355_net y355_net;
@@ -272,6 +274,9 @@ int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *out_max);
 int y355_net_max_det(y355_net *h);
 int y355_net_num_anchors_total(y355_net *h);
 int y355_net_sync(y355_net *h);
+/* heads with more than 4096 anchors per image (yolo_v3 at 416 x 416): *overflow = 1 if, in a forward since the last call, more
+ * than 4096 anchors of an image passed conf_thresh (the excess was dropped: raise the threshold); synchronous; clears the flag */
+int y355_net_overflow(y355_net *h, int *overflow);
 int y355_net_profile(y355_net *h, int enable);
 int y355_net_num_timers(y355_net *h);          /* ops + head decode + NMS */
 int y355_net_profile_get(y355_net *h, float *ms);

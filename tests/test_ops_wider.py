@@ -247,12 +247,53 @@ def test_yolo_v3_dropins_match_reference(case):
         # 75+ bf16 layers with residual accumulation: below 3 % of the range, mean below 0.6 %
         assert err.max() < 0.03 * np.abs(ref).max() + 0.03, float(err.max())
         assert err.mean() < 0.006 * np.abs(ref).max(), float(err.mean())
-    b, s, c = m(x)
+    b, s, c = m.forward_batch_composed(x)[0]
     fr, fg = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b, s, c), iou_min=0.7, score_tol=0.05)
     assert fr > 0.9 and fg > 0.9, (fr, fg, len(s), len(WGOLD[tag + "_scores"]))
     want = F.detect_v3(preds, synth.MULTI_ANCHOR_SIZE, classes, size, 0.05, 0.5)[0]
     assert len(want[1]) == len(s) and np.array_equal(want[2], c)
     assert np.abs(want[0] - b).max() < 2e-5 and np.abs(want[1] - s).max() < 2e-6
+    # ---- the GPU-resident graph (y355_net, Y355_ARCH_YOLO_V3 / _SPP)
+    b2, s2, c2 = m(x)
+    net = m._get_net(1)
+    nt = net.num_tensors
+    preds2 = [net.get_tensor(nt - 1, 1), net.get_tensor(nt - 3, 1), net.get_tensor(nt - 5, 1)]     # strides 8, 16, 32
+    for got, ref in zip(preds2, _gold3(tag)):
+        assert got.shape == ref.shape
+        err = np.abs(got - ref)
+        assert err.max() < 0.03 * np.abs(ref).max() + 0.03 and err.mean() < 0.006 * np.abs(ref).max(), (float(err.max()), float(err.mean()))
+    fr, fg = dets_close((WGOLD[tag + "_boxes"], WGOLD[tag + "_scores"], WGOLD[tag + "_cls"]), (b2, s2, c2), iou_min=0.7, score_tol=0.05)
+    assert fr > 0.9 and fg > 0.9, (fr, fg, len(s2))
+    want = F.detect_v3(preds2, synth.MULTI_ANCHOR_SIZE, classes, size, 0.05, 0.5)[0]
+    assert len(want[1]) == len(s2) and np.array_equal(want[2], c2)
+    assert np.abs(want[0] - b2).max() < 2e-5 and np.abs(want[1] - s2).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_yolo_v3_at_416_runs_on_the_gpu_resident_graph():
+    """the reference's default input size: 10 647 anchors per image -> threshold-then-compact head; batch of two; the head
+    is exact on the engine's own maps, and element i of the batch equals the single-image run"""
+    import torch
+    from yolo355 import synth
+    from yolo355.models.yolo_v3 import myYOLOv3
+    from oracle import fp32_oracle as F
+    size, classes, seed = [416, 416], 20, 4200
+    m = myYOLOv3("cuda", input_size=size, num_classes=classes, trainable=False, conf_thresh=0.05, nms_thresh=0.5,
+                 anchor_size=synth.MULTI_ANCHOR_SIZE)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed, weight_gain=1.3))
+    m.eval()
+    x = torch.from_numpy(np.concatenate([synth.make_images(seed + 1 + i, 1, 416, 416) for i in range(2)])).cuda()
+    outs = m.forward_batch(x)
+    net = m._get_net(2)
+    assert net.num_anchors_total == 10647
+    nt = net.num_tensors
+    preds = [net.get_tensor(nt - 1, 2), net.get_tensor(nt - 3, 2), net.get_tensor(nt - 5, 2)]
+    want = F.detect_v3(preds, synth.MULTI_ANCHOR_SIZE, classes, size, 0.05, 0.5)
+    for (b, s, c), w in zip(outs, want):
+        assert len(s) > 20 and len(w[1]) == len(s) and np.array_equal(w[2], c)
+        assert np.abs(w[0] - b).max() < 2e-5 and np.abs(w[1] - s).max() < 2e-6
+    one = m.forward_batch(x[1:2])[0]
+    assert all(np.array_equal(p, q) for p, q in zip(one, outs[1]))
 
 
 @pytest.mark.gpu

@@ -25,7 +25,7 @@ int y355_prepare_kernels();
     } while (0)
 
 namespace {
-enum { OP_CONV1 = 0, OP_CONV, OP_POOL, OP_UPSAMPLE, OP_INPUT, OP_REORG };
+enum { OP_CONV1 = 0, OP_CONV, OP_POOL, OP_UPSAMPLE, OP_INPUT, OP_REORG, OP_SPP };
 enum { ACT_NONE = 0, ACT_L125, ACT_L100 };     // LeakyReLU(0.125) utils/modules.py:15; (0.1) backbone/darknet.py:18
 
 struct TensorDef { int C, div, pred; };        // channels; H = height / div; pred: prediction map (no halo)
@@ -33,10 +33,12 @@ struct OpDef {
     int type, in, out;
     int choff;        // first channel written in `out` (concat by construction)
     int layer;        // weight slot
-    int cin, cout;    // cout 0 = A * (5 + C)
+    int cin, cout;    // cout 0 = A * (5 + C); cin may be a leading channel range of a wider (concat) buffer
     int ksize, pool, act;
+    int stride2;      // 1: 3x3 / pad 1 / stride 2 (backbone/darknet.py:124-141)
+    int res1;         // residual tensor + 1 added after the activation (darknet.py:36), 0 = none
 };
-struct ArchDef { int ntensors; const TensorDef *t; int nops; const OpDef *ops; int nlayers; int nlev; int pred_t[2]; float stride[2]; };
+struct ArchDef { int ntensors; const TensorDef *t; int nops; const OpDef *ops; int nlayers; int nlev; int pred_t[3]; float stride[3]; };
 
 // ---- SlimYOLOv2 (models/slim_yolo_v2.py:403-419, 551-567)
 const TensorDef kSlimT[] = {{16, 2, 0}, {32, 4, 0}, {64, 4, 0}, {64, 8, 0}, {128, 8, 0}, {128, 16, 0},
@@ -120,10 +122,94 @@ const OpDef kV2Ops[] = {
     {OP_CONV, 23, 24, 0, 21, 1280, 1024, 3, 0, ACT_L125},        // convsets_2
     {OP_CONV, 24, 25, 0, 22, 1024, 0, 1, 0, ACT_NONE},           // pred (1x1)
 };
-const ArchDef kArch[3] = {
-    {10, kSlimT, 10, kSlimOps, 10, 1, {9, -1}, {16.f, 0.f}},
-    {15, kTinyT, 16, kTinyOps, 13, 2, {13, 14}, {16.f, 32.f}},
-    {26, kV2T, 27, kV2Ops, 23, 1, {25, -1}, {32.f, 0.f}},
+// ---- myYOLOv3 / myYOLOv3Spp (models/yolo_v3.py:26-61, 203-231; models/yolo_v3_spp.py:31-36) on DarkNet-53
+// (backbone/darknet.py:112-161): built programmatically, weight slots in forward order (bf16 only)
+struct V3Graph {
+    std::vector<TensorDef> t;
+    std::vector<OpDef> ops;
+    int nlayers = 0;
+    int pred[3] = {0, 0, 0};
+    int T(int C, int div, int pred_ = 0) { t.push_back(TensorDef{C, div, pred_}); return (int)t.size() - 1; }
+    void conv(int in, int out, int choff, int cin, int cout, int k, int act, int stride2 = 0, int res = -1) {
+        ops.push_back(OpDef{OP_CONV, in, out, choff, nlayers++, cin, cout, k, 0, act, stride2, res + 1});
+    }
+    // resblock(ch) x n on tensor x (div d); the last block may write into `last_out` (a concat buffer, channel offset 0)
+    int resblocks(int x, int ch, int d, int n, int last_out = -1) {
+        for (int i = 0; i < n; ++i) {
+            const int mid = T(ch / 2 < 64 ? 64 : ch / 2, d);                 // >= 64 channels: the kernels write 64-channel blocks
+            conv(x, mid, 0, ch, ch / 2, 1, ACT_L100);
+            const int out = (i == n - 1 && last_out >= 0) ? last_out : T(ch, d);
+            conv(mid, out, 0, ch / 2, ch, 3, ACT_L100, 0, x);
+            x = out;
+        }
+        return x;
+    }
+    explicit V3Graph(bool spp) {
+        const int in = T(3, 1);
+        ops.push_back(OpDef{OP_INPUT, -1, in, 0, -1, 3, 3, 0, 0, 0, 0, 0});
+        int x = T(64, 1);                                                   // 32 real channels
+        conv(in, x, 0, 3, 32, 3, ACT_L100);
+        int y = T(64, 2);
+        conv(x, y, 0, 32, 64, 3, ACT_L100, 1);
+        x = resblocks(y, 64, 2, 1);
+        y = T(128, 4); conv(x, y, 0, 64, 128, 3, ACT_L100, 1);
+        x = resblocks(y, 128, 4, 2);
+        y = T(256, 8); conv(x, y, 0, 128, 256, 3, ACT_L100, 1);
+        const int cat1 = T(384, 8);                                          // [C_3 (256) | up(conv_1x1_2) (128)]
+        const int c3 = resblocks(y, 256, 8, 8, cat1);
+        y = T(512, 16); conv(c3, y, 0, 256, 512, 3, ACT_L100, 1);
+        const int cat2 = T(768, 16);                                         // [C_4 (512) | up(conv_1x1_3) (256)]
+        const int c4 = resblocks(y, 512, 16, 8, cat2);
+        y = T(1024, 32); conv(c4, y, 0, 512, 1024, 3, ACT_L100, 1);
+        int c5;
+        if (spp) {
+            const int sppb = T(4096, 32);                                    // [C_5 | pool5 | pool9 | pool13]
+            c5 = resblocks(y, 1024, 32, 4, sppb);
+            ops.push_back(OpDef{OP_SPP, c5, c5, 1024, -1, 1024, 3072, 0, 0, 0, 0, 0});
+        } else {
+            c5 = resblocks(y, 1024, 32, 4);
+        }
+        // conv_set_3
+        int a = T(512, 32); conv(c5, a, 0, spp ? 4096 : 1024, 512, 1, ACT_L125);
+        int b = T(1024, 32); conv(a, b, 0, 512, 1024, 3, ACT_L125);
+        a = T(512, 32); conv(b, a, 0, 1024, 512, 1, ACT_L125);
+        b = T(1024, 32); conv(a, b, 0, 512, 1024, 3, ACT_L125);
+        const int f3 = T(512, 32); conv(b, f3, 0, 1024, 512, 1, ACT_L125);
+        a = T(256, 32); conv(f3, a, 0, 512, 256, 1, ACT_L125);               // conv_1x1_3
+        ops.push_back(OpDef{OP_UPSAMPLE, a, cat2, 512, -1, 256, 256, 0, 0, 0, 0, 0});
+        // conv_set_2
+        a = T(256, 16); conv(cat2, a, 0, 768, 256, 1, ACT_L125);
+        b = T(512, 16); conv(a, b, 0, 256, 512, 3, ACT_L125);
+        a = T(256, 16); conv(b, a, 0, 512, 256, 1, ACT_L125);
+        b = T(512, 16); conv(a, b, 0, 256, 512, 3, ACT_L125);
+        const int f2 = T(256, 16); conv(b, f2, 0, 512, 256, 1, ACT_L125);
+        a = T(128, 16); conv(f2, a, 0, 256, 128, 1, ACT_L125);               // conv_1x1_2
+        ops.push_back(OpDef{OP_UPSAMPLE, a, cat1, 256, -1, 128, 128, 0, 0, 0, 0, 0});
+        // conv_set_1
+        a = T(128, 8); conv(cat1, a, 0, 384, 128, 1, ACT_L125);
+        b = T(256, 8); conv(a, b, 0, 128, 256, 3, ACT_L125);
+        a = T(128, 8); conv(b, a, 0, 256, 128, 1, ACT_L125);
+        b = T(256, 8); conv(a, b, 0, 128, 256, 3, ACT_L125);
+        const int f1 = T(128, 8); conv(b, f1, 0, 256, 128, 1, ACT_L125);
+        // heads: extra_conv_3 + pred_3, extra_conv_2 + pred_2, extra_conv_1 + pred_1 (models/yolo_v3.py:219-231)
+        a = T(1024, 32); conv(f3, a, 0, 512, 1024, 3, ACT_L125);
+        pred[2] = T(0, 32, 1); conv(a, pred[2], 0, 1024, 0, 1, ACT_NONE);
+        a = T(512, 16); conv(f2, a, 0, 256, 512, 3, ACT_L125);
+        pred[1] = T(0, 16, 1); conv(a, pred[1], 0, 512, 0, 1, ACT_NONE);
+        a = T(256, 8); conv(f1, a, 0, 128, 256, 3, ACT_L125);
+        pred[0] = T(0, 8, 1); conv(a, pred[0], 0, 256, 0, 1, ACT_NONE);
+    }
+    ArchDef arch() const {
+        return ArchDef{(int)t.size(), t.data(), (int)ops.size(), ops.data(), nlayers, 3, {pred[0], pred[1], pred[2]}, {8.f, 16.f, 32.f}};
+    }
+};
+const V3Graph kV3(false), kV3Spp(true);
+const ArchDef kArch[5] = {
+    {10, kSlimT, 10, kSlimOps, 10, 1, {9, -1, -1}, {16.f, 0.f, 0.f}},
+    {15, kTinyT, 16, kTinyOps, 13, 2, {13, 14, -1}, {16.f, 32.f, 0.f}},
+    {26, kV2T, 27, kV2Ops, 23, 1, {25, -1, -1}, {32.f, 0.f, 0.f}},
+    kV3.arch(),
+    kV3Spp.arch(),
 };
 
 struct Tensor {
@@ -310,6 +396,8 @@ struct y355_net {
     std::vector<void *> allocs;
 };
 
+static int in_kbytes(const y355_net *h, const OpDef &o);
+
 static int nmalloc(y355_net *h, void **p, size_t bytes, bool zero) {
     HIPCHK(hipMalloc(p, bytes ? bytes : 16));
     h->allocs.push_back(*p);
@@ -329,10 +417,9 @@ extern "C" void y355_net_destroy(y355_net *h) {
 
 extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (!cfg || !out) return y355_fail(Y355_EINVAL, "null argument");
-    if (cfg->arch != Y355_ARCH_SLIM_V2 && cfg->arch != Y355_ARCH_TINY_V3 && cfg->arch != Y355_ARCH_YOLO_V2)
-        return y355_fail(Y355_EINVAL, "unknown arch");
-    if (cfg->arch == Y355_ARCH_YOLO_V2 && cfg->dtype != Y355_DT_BF16)
-        return y355_fail(Y355_EINVAL, "yolo_v2 is built in bf16 only (the reference has no quantized form of it)");
+    if (cfg->arch < 0 || cfg->arch > Y355_ARCH_YOLO_V3_SPP) return y355_fail(Y355_EINVAL, "unknown arch");
+    if (cfg->arch >= Y355_ARCH_YOLO_V2 && cfg->dtype != Y355_DT_BF16)
+        return y355_fail(Y355_EINVAL, "yolo_v2 / yolo_v3 / yolo_v3_spp are built in bf16 only (the reference has no quantized form of them)");
     if (cfg->dtype != Y355_DT_BF16 && cfg->dtype != Y355_DT_INT8) return y355_fail(Y355_EINVAL, "unknown dtype");
     if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % 32 || cfg->width % 32)
         return y355_fail(Y355_EINVAL, "input size must be a positive multiple of 32");
@@ -347,8 +434,9 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     const int Hb = cfg->height / (int)A.stride[0], Wb = cfg->width / (int)A.stride[0];
     (void)Hb;
     (void)Wb;
-    if (N > Y355_NMS_CAP)
+    if (N > Y355_NMS_CAP && A.nlev < 3)
         return y355_fail(Y355_EINVAL, "more than 4096 anchors / sort bins per image not supported");
+    if (N > 16 * Y355_NMS_CAP) return y355_fail(Y355_EINVAL, "more than 65536 anchors per image not supported");
     HIPCHK(hipSetDevice(cfg->device_id));
     if (int e = y355_prepare_kernels()) return e;
     y355_net *h = new y355_net();
@@ -359,7 +447,8 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     h->predc = predc;
     h->sa.assign(A.ntensors, 0);
     h->N = N;
-    h->max_det = (cfg->max_det <= 0 || cfg->max_det > N) ? N : cfg->max_det;
+    const int ncand = N > Y355_NMS_CAP ? Y355_NMS_CAP : N;     // larger heads are thresholded and compacted first
+    h->max_det = (cfg->max_det <= 0 || cfg->max_det > ncand) ? ncand : cfg->max_det;
     if (!cfg->own_stream) h->stream = (hipStream_t)cfg->stream;
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -399,14 +488,17 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
             rc = nmalloc(h, (void **)&h->w0_dev, 2048, true);
         } else {
             const Tensor &ti = h->T[o.in];
-            L.kid = y355_convg_select((int)(ti.Cpad * h->es), L.cout, o.pool, ti.H, ti.W);
+            L.kid = y355_convg_select(in_kbytes(h, o), L.cout, o.pool, ti.H, ti.W, o.stride2 ? 2 : 1);
+            if (L.kid < 0) { rc = y355_fail(Y355_EINVAL, "no convolution kernel for a layer of this graph"); break; }
             const ConvGInfo &ki = *y355_convg_kernel(h->bf, L.kid);
+            if (in_kbytes(h, o) % ki.chb) { rc = y355_fail(Y355_EINVAL, "input channels not a multiple of the kernel's chunk"); break; }
             L.cout_pad = (L.cout + ki.bn - 1) / ki.bn * ki.bn;
+            if (!h->T[o.out].pred && o.choff + L.cout_pad > h->T[o.out].Cpad) { rc = y355_fail(Y355_EINVAL, "layer wider than its output buffer"); break; }
             if (h->T[o.out].pred && L.cout_pad > h->T[o.out].Cpad) {
                 rc = y355_fail(Y355_EINVAL, "prediction map wider than its buffer");
                 break;
             }
-            L.w_bytes = y355_convg_packed_bytes(ki, ti.Cpad * h->es, o.ksize * o.ksize, L.cout_pad);
+            L.w_bytes = y355_convg_packed_bytes(ki, in_kbytes(h, o), o.ksize * o.ksize, L.cout_pad);
             rc = nmalloc(h, (void **)&L.w_dev, L.w_bytes, true);
         }
         if (!rc) rc = nmalloc(h, (void **)&L.bias_dev, sizeof(float) * L.cout_pad, true);
@@ -430,6 +522,14 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (!rc) rc = nmalloc(h, &h->ws.dscore, sizeof(float) * cap * B, true);
     if (!rc) rc = nmalloc(h, &h->ws.dcls, sizeof(int) * cap * B, true);
     if (!rc) rc = nmalloc(h, &h->ws.ctype, sizeof(int) * cap * B, true);          // candidate groups
+    if (N > Y355_NMS_CAP) {
+        h->ws.rstride = (N + 3) / 4 * 4;
+        if (!rc) rc = nmalloc(h, &h->ws.rbox, sizeof(float) * 4 * (size_t)h->ws.rstride * B, true);
+        if (!rc) rc = nmalloc(h, &h->ws.rscore, sizeof(float) * (size_t)h->ws.rstride * B, true);
+        if (!rc) rc = nmalloc(h, &h->ws.rcls, sizeof(int) * (size_t)h->ws.rstride * B, true);
+        if (!rc) rc = nmalloc(h, &h->ws.rcount, sizeof(int) * B, true);
+        if (!rc) rc = nmalloc(h, &h->ws.ovf, sizeof(int) * B, true);
+    }
     if (!rc) rc = nmalloc(h, (void **)&h->cand_box, sizeof(float) * 4 * N * B, false);
     if (!rc) rc = nmalloc(h, (void **)&h->cand_score, sizeof(float) * N * B, false);
     if (!rc) rc = nmalloc(h, (void **)&h->cand_cls, sizeof(int) * N * B, false);
@@ -495,7 +595,7 @@ extern "C" int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, con
     } else {
         const ConvGInfo &ki = *y355_convg_kernel(1, L.kid);
         std::vector<char> packed(L.w_bytes);
-        y355_convg_pack(ki, w, nullptr, cout, cin, ksize, h->T[o.in].Cpad * h->es, L.cout_pad, packed.data());
+        y355_convg_pack(ki, w, nullptr, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, packed.data());
         HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
     }
     std::vector<float> bias(L.cout_pad, 0.f);
@@ -529,7 +629,7 @@ extern "C" int y355_net_load_layer_i8(y355_net *h, int idx, const int8_t *q_w, c
     } else {
         const ConvGInfo &ki = *y355_convg_kernel(0, L.kid);
         std::vector<char> packed(L.w_bytes);
-        y355_convg_pack(ki, nullptr, q_w, cout, cin, ksize, h->T[o.in].Cpad, L.cout_pad, packed.data());
+        y355_convg_pack(ki, nullptr, q_w, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, packed.data());
         HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
     }
     L.q_b.assign(q_b, q_b + cout);
@@ -652,6 +752,61 @@ __global__ void reorg_bf16_kernel(const char *in, char *out, int B, int Hin, int
     }
 }
 
+// utils.modules.SPP (utils/modules.py:66-72) on bf16 NHWC, in place in a 4C-channel buffer: channels [0, C) are x, the
+// kernel writes max_pool 5 / 9 / 13 (stride 1, windows clipped to the map = -inf padding) to [C,2C), [2C,3C), [3C,4C).
+// bf16 compares as fp32; 8 channels (16 bytes) per thread.
+__global__ void spp_bf16_kernel(char *buf, int B, int H, int W, int pb, int C) {
+    const int cg = C / 8;
+    const size_t total = (size_t)B * H * W * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int x = (int)((i / cg) % W), y = (int)((i / ((size_t)cg * W)) % H);
+        const size_t b = i / ((size_t)cg * W * H);
+        float m5[8], m9[8], m13[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m5[k] = m9[k] = m13[k] = -INFINITY;
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const uint4 v = *(const uint4 *)(buf + ((b * (H + 2) + yy + 1) * (size_t)(W + 2) + xx + 1) * pb + g * 16);
+                const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+                const int r = max(abs(dy), abs(dx));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float f = __uint_as_float((k & 1) ? (u[k >> 1] & 0xffff0000u) : (u[k >> 1] << 16));
+                    m13[k] = fmaxf(m13[k], f);
+                    if (r <= 4) m9[k] = fmaxf(m9[k], f);
+                    if (r <= 2) m5[k] = fmaxf(m5[k], f);
+                }
+            }
+        }
+        char *o = buf + ((b * (H + 2) + y + 1) * (size_t)(W + 2) + x + 1) * pb + g * 16;
+        auto pack = [](const float (&m)[8]) {
+            uint4 r;
+            unsigned int w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (__float_as_uint(m[2 * k]) >> 16) | (__float_as_uint(m[2 * k + 1]) & 0xffff0000u);
+            r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3];
+            return r;
+        };
+        *(uint4 *)(o + (size_t)C * 2) = pack(m5);
+        *(uint4 *)(o + (size_t)C * 4) = pack(m9);
+        *(uint4 *)(o + (size_t)C * 6) = pack(m13);
+    }
+}
+
+// bytes of input channels a convolution consumes per pixel (its K extent): o.cin rounded up to the channel quantum --
+// the whole pixel for ordinary tensors, a leading channel range for concat buffers read before they are complete
+static int in_kbytes(const y355_net *h, const OpDef &o) {
+    const int cq = h->bf ? 16 : 32;
+    int c = (o.cin + cq - 1) / cq * cq;
+    if (h->bf && c > 16) c = (c + 31) / 32 * 32;          // 64-byte k-steps beyond the thin (16-channel) path
+    return c * h->es;
+}
+
 static float act_slope(int act) { return act == ACT_L125 ? 0.125f : act == ACT_L100 ? 0.1f : 1.0f; }
 
 static int run_op(y355_net *h, int i, int B, const float *x_dev) {
@@ -708,12 +863,19 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
         p.H = ti.H;
         p.W = ti.W;
         p.in_pb = (int)ti.pb;
-        p.nchunks = ti.Cpad * h->es / ki.chb;
+        p.nchunks = in_kbytes(h, o) / ki.chb;
         p.out_pb = (int)to.pb;
         p.out_off = o.choff * ((to.pred && h->bf) ? 4 : h->es);
         p.out_halo = to.halo;
-        p.tiles_x = (ti.W + ki.tw - 1) / ki.tw;
-        p.tiles_y = (ti.H + ki.th - 1) / ki.th;
+        const int Ho = o.stride2 ? (ti.H + 1) / 2 : ti.H, Wo = o.stride2 ? (ti.W + 1) / 2 : ti.W;
+        p.tiles_x = (Wo + ki.tw - 1) / ki.tw;
+        p.tiles_y = (Ho + ki.th - 1) / ki.th;
+        if (o.res1) {
+            const Tensor &tr = h->T[o.res1 - 1];
+            p.res = tr.dev;
+            p.res_pb = (int)tr.pb;
+            p.res_off = 0;
+        }
         p.nblk = L.cout_pad / ki.bn;
         p.taps = o.ksize * o.ksize;
         p.slope = act_slope(o.act);
@@ -735,6 +897,11 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
         const size_t total = (size_t)B * to.H * to.W;
         hipLaunchKernelGGL(input_bf16_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, x_dev, to.dev, B,
                            to.H, to.W, (int)to.pb);
+    } else if (o.type == OP_SPP) {
+        const Tensor &t = h->T[o.in];
+        const size_t total = (size_t)B * t.H * t.W * (o.cin / 8);
+        hipLaunchKernelGGL(spp_bf16_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, t.dev, B, t.H, t.W,
+                           (int)t.pb, o.cin);
     } else if (o.type == OP_REORG) {
         const Tensor &ti = h->T[o.in], &to = h->T[o.out];
         const size_t total = (size_t)B * to.H * to.W * o.ksize * o.ksize * (o.cin / 8);
@@ -891,6 +1058,21 @@ extern "C" int y355_net_counters(y355_net *h, int64_t *saturated) {
     int64_t s = 0;
     for (auto &k : c) s += (int64_t)k.sat + (int64_t)k.in_sat;
     *saturated = s;
+    return 0;
+}
+
+// heads with more than 4096 anchors per image: 1 if, in any forward since the last call, more than 4096 anchors of an
+// image passed conf_thresh (the excess was dropped); synchronous; clears the flags
+extern "C" int y355_net_overflow(y355_net *h, int *overflow) {
+    if (!h || !overflow) return y355_fail(Y355_EINVAL, "null argument");
+    *overflow = 0;
+    if (!h->ws.ovf) return 0;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> v(h->cfg.max_batch, 0);
+    HIPCHK(hipMemcpy(v.data(), h->ws.ovf, sizeof(int) * v.size(), hipMemcpyDeviceToHost));
+    for (int x : v) *overflow |= x != 0;
+    if (*overflow) HIPCHK(hipMemset(h->ws.ovf, 0, sizeof(int) * v.size()));
     return 0;
 }
 

@@ -36,7 +36,7 @@ class NetConfig(C.Structure):
                 ("own_stream", C.c_int32)]
 
 
-ARCH_SLIM_V2, ARCH_TINY_V3, ARCH_YOLO_V2 = 0, 1, 2
+ARCH_SLIM_V2, ARCH_TINY_V3, ARCH_YOLO_V2, ARCH_YOLO_V3, ARCH_YOLO_V3_SPP = 0, 1, 2, 3, 4
 DT_INT8, DT_BF16 = 0, 1
 
 
@@ -118,6 +118,7 @@ _SIGS = {
     "y355_net_max_det": (C.c_int, [C.c_void_p]),
     "y355_net_num_anchors_total": (C.c_int, [C.c_void_p]),
     "y355_net_sync": (C.c_int, [C.c_void_p]),
+    "y355_net_overflow": (C.c_int, [C.c_void_p, P(C.c_int)]),
     "y355_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "y355_net_num_timers": (C.c_int, [C.c_void_p]),
     "y355_net_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),

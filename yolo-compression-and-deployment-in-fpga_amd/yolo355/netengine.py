@@ -9,7 +9,9 @@ import torch
 from . import _ffi
 from .engine import _require_gpu
 
-ARCH = {"slim_yolo_v2": _ffi.ARCH_SLIM_V2, "tiny_yolo_v3": _ffi.ARCH_TINY_V3, "yolo_v2": _ffi.ARCH_YOLO_V2}
+ARCH = {"slim_yolo_v2": _ffi.ARCH_SLIM_V2, "tiny_yolo_v3": _ffi.ARCH_TINY_V3, "yolo_v2": _ffi.ARCH_YOLO_V2,
+        "yolo_v3": _ffi.ARCH_YOLO_V3, "yolo_v3_spp": _ffi.ARCH_YOLO_V3_SPP}
+NLEV = {"slim_yolo_v2": 1, "tiny_yolo_v3": 2, "yolo_v2": 1, "yolo_v3": 3, "yolo_v3_spp": 3}
 DTYPE = {"int8": _ffi.DT_INT8, "bf16": _ffi.DT_BF16}
 
 
@@ -25,9 +27,9 @@ class Net:
         self.input_size = [int(input_size[0]), int(input_size[1])]
         self.num_classes = int(num_classes)
         self.anchors = [[float(a), float(b)] for a, b in anchors]
-        nlev = 2 if arch == "tiny_yolo_v3" else 1
+        nlev = NLEV[arch]
         if len(self.anchors) % nlev:
-            raise ValueError("tiny_yolo_v3 needs an even number of anchors")
+            raise ValueError("%s needs a multiple of %d anchors" % (arch, nlev))
         self.max_batch = int(max_batch)
         cfg = _ffi.NetConfig()
         cfg.device_id = self.device.index
@@ -141,9 +143,18 @@ class Net:
         B = xd.shape[0]
         ob, os_, oc, on = self.forward_device(xd, _ffi.F_TAP if tap else 0)
         n = on[:B].cpu().numpy()
+        if self.overflow():
+            raise _ffi.Y355Error(-1,
+                                 "more than 4096 anchors of an image pass conf_thresh: raise the threshold")
         boxes, scores, cls = ob[:B].cpu().numpy(), os_[:B].cpu().numpy(), oc[:B].cpu().numpy()
         return [(boxes[i, :n[i]].copy(), scores[i, :n[i]].copy(), cls[i, :n[i]].astype(np.int64))
                 for i in range(B)]
+
+    def overflow(self):
+        """True if a forward since the last call dropped candidates (heads with more than 4096 anchors per image)."""
+        v = C.c_int(0)
+        _ffi.check(self._lib.y355_net_overflow(self._h, C.byref(v)))
+        return bool(v.value)
 
     def candidates(self, batch):
         N = self.num_anchors_total
