@@ -119,7 +119,7 @@ constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
 }
 
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
     constexpr int NW = WM * WN;
     constexpr int NTHR = NW * 64;
     constexpr int NCH = CIN / 64, SPC = 9, KS = NCH * SPC;
@@ -215,6 +215,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_ring_kernel(const Con
     };
     stamp();
     stamp();
+    // two workgroups per CU (half-size tiles): the second half of the grid starts late, so that one workgroup's prologue and
+    // epilogue run under the other's k-loop instead of both doing the same phase at the same time
+    if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+        for (int i = 0; i < p.stagger; i += 16) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles per trip
+    }
     int b, y0, x0, nb;
     decode(tile, b, y0, x0, nb);
     int sl = 0;                                                // slab slot of the current chunk
@@ -638,9 +643,14 @@ struct ConvInstR {
         return (int)hipFuncSetAttribute((const void *)conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
-    static bool launch(const ConvParams &p, hipStream_t s) {
+    static bool launch(const ConvParams &p_in, hipStream_t s, int grid_max = 256, int stagger = 0) {
+        ConvParams p = p_in;
+        p.tiles_x = (p.W + TW - 1) / TW;
+        p.tiles_y = (p.H + TH - 1) / TH;
+        p.nblk = p_in.nblk * (p_in.tiles_x > 0 ? 1 : 1);
+        p.stagger = stagger;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
-        int grid = 256;                                        // one persistent workgroup per CU
+        int grid = grid_max;                                   // one persistent workgroup per CU (two for the half tiles)
         if (grid > total) grid = total;
         hipLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
         return true;
@@ -656,6 +666,9 @@ struct RSet {
     using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, 5, ROLL, DIRECT>;
     using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, 5, ROLL, DIRECT>;
     using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, 5, ROLL, DIRECT>;
+    // experiment (Y355_RING_HALF): half-size tiles, two 4-wave workgroups per CU, staggered start
+    using C67H = ConvInstR<256, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
+    using C5H = ConvInstR<128, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
     static int prepare() {
         int e = C3_2::prepare();
         if (!e) e = C4_1::prepare();
@@ -663,6 +676,8 @@ struct RSet {
         if (!e) e = C5::prepare();
         if (!e) e = C67::prepare();
         if (!e) e = PRED::prepare();
+        if (!e) e = C67H::prepare();
+        if (!e) e = C5H::prepare();
         return e;
     }
     static bool launch(int kid, const ConvParams &p, hipStream_t s) {
@@ -670,8 +685,16 @@ struct RSet {
         case Y355_K_CONV3_2: return C3_2::launch(p, s);
         case Y355_K_CONV4_1: return C4_1::launch(p, s);
         case Y355_K_CONV4_2: return C4_2::launch(p, s);
-        case Y355_K_CONV5: return C5::launch(p, s);
-        case Y355_K_CONV67: return C67::launch(p, s);
+        case Y355_K_CONV5: {
+            static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
+            if (half & 2) return C5H::launch(p, s, 512, half >> 8);
+            return C5::launch(p, s);
+        }
+        case Y355_K_CONV67: {
+            static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
+            if (half & 1) return C67H::launch(p, s, 512, half >> 8);
+            return C67::launch(p, s);
+        }
         case Y355_K_PRED: return PRED::launch(p, s);
         default: return false;
         }
