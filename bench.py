@@ -117,6 +117,7 @@ def cpu_baseline(n_images=256):
 TINY_MMAC = [74.760192, 199.360512, 199.360512, 199.360512, 199.360512, 199.360512, 797.442048, 398.721024,
              5.537792, 598.081536, 199.360512, 6.4896, 12.9792]
 PEAK_BF16_DENSE = 2.5e15
+PEAK_I8_MEASURED = 4.588e15      # scratch/ubench/mfma_peak.hip on an MI355X, 2 waves per SIMD (nominal 5.0e15 = PEAK_I8_DENSE)
 # myYOLOv2 on DarkNet-19 (models/yolo_v2.py, backbone/darknet.py:40-110), weight slots of csrc/net.hip kV2Ops:
 # (cin, cout, ksize, map side at 416x416 the convolution runs on); cout 0 = A * (5 + C)
 V2_LAYERS = [(3, 32, 3, 416), (32, 64, 3, 208), (64, 128, 3, 104), (128, 64, 1, 104), (64, 128, 3, 104),
@@ -473,6 +474,10 @@ def main():
                          "kernel": DOMINANT_KERNEL + " (conv6 and conv7: 2 launches/step, the largest share of "
                                    "the step of any kernel; int8 ops = 2 x 398.72e6 MAC x %d images per launch)" % B,
                          "launch_ms": round(dom_ms, 4),
+                         # MFMA-only microbenchmark on this part (scratch/ubench/mfma_peak.hip, profiles/r01_g_ablation.txt):
+                         # v_mfma_i32_16x16x64_i8 at two waves per SIMD sustains 4588 Tops/s (the clock drops to ~2.2 GHz)
+                         "peak_measured": PEAK_I8_MEASURED / 1e12,
+                         "frac_of_measured_peak": round(dom_tops * 1e12 / PEAK_I8_MEASURED, 4),
                          "all_conv_achieved": round(achieved, 2),
                          "all_conv_frac": round(achieved * 1e12 / PEAK_I8_DENSE, 4),
                          "whole_path_frac": round(value / world * OPS_PER_IMAGE / PEAK_I8_DENSE, 4),
