@@ -60,6 +60,16 @@ def main():
         out[tag + "_scores"] = np.asarray(s, np.float32)
         out[tag + "_cls"] = np.asarray(c, np.int64)
         print(tag, [grabbed[n].shape for n in grabbed], float(np.abs(grabbed["pred_3"]).max()), len(s))
+    # state_dict layouts (key order and shapes) of the three classes: what "checkpoints load unchanged" means
+    import json
+    layouts = {}
+    for modname, cls, anchors in (("models.yolo_v2", "myYOLOv2", synth.ANCHOR_SIZE), ("models.yolo_v3", "myYOLOv3", synth.MULTI_ANCHOR_SIZE),
+                                  ("models.yolo_v3_spp", "myYOLOv3Spp", synth.MULTI_ANCHOR_SIZE)):
+        m = getattr(importlib.import_module(modname), cls)("cpu", input_size=[224, 224], num_classes=20, trainable=False,
+                                                           anchor_size=anchors)
+        layouts[cls] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    with open(os.path.join(HERE, "models_wide_layout.json"), "w") as f:
+        json.dump(layouts, f)
     np.savez_compressed(os.path.join(HERE, "models_wide.npz"), **out)
 
 

@@ -318,3 +318,22 @@ def test_head_with_more_than_4096_anchors():
         assert np.abs(g[0] - w[0]).max() < 2e-5 and np.abs(g[1] - w[1]).max() < 2e-6
     with pytest.raises(Y355Error, match="4096"):
         E.head_f32(preds, (8, 16, 32), np.asarray(synth.MULTI_ANCHOR_SIZE, np.float32).reshape(3, A, 2), C, size, 1.0, 1e-6, 0.5)
+
+
+def test_wider_models_keep_the_reference_state_dict_layout():
+    """CPU: key order and shapes of myYOLOv2 / myYOLOv3 / myYOLOv3Spp equal the reference classes' (recorded by
+    tests/golden/gen_golden_models_wide.py), and the weight-slot lists of the GPU graphs cover every convolution once"""
+    import json
+    from yolo355 import synth
+    from yolo355.models.yolo_v2 import myYOLOv2
+    from yolo355.models.yolo_v3 import myYOLOv3, myYOLOv3Spp
+    lay = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "models_wide_layout.json")))
+    for cls, anchors, nconv in ((myYOLOv2, synth.ANCHOR_SIZE, 23), (myYOLOv3, synth.MULTI_ANCHOR_SIZE, 75), (myYOLOv3Spp, synth.MULTI_ANCHOR_SIZE, 75)):
+        m = cls("cpu", input_size=[224, 224], num_classes=20, trainable=False, anchor_size=anchors)
+        got = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        assert got == lay[cls.__name__]
+        mods = m._conv_modules()
+        convs = [mm[0] if hasattr(mm, "__getitem__") else mm for mm in mods]
+        assert len(convs) == nconv and len({id(c) for c in convs}) == nconv
+        import torch.nn as nn
+        assert sum(isinstance(x, nn.Conv2d) for x in m.modules()) == nconv
