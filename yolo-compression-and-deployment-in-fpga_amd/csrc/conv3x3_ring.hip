@@ -647,7 +647,6 @@ struct ConvInstR {
         ConvParams p = p_in;
         p.tiles_x = (p.W + TW - 1) / TW;
         p.tiles_y = (p.H + TH - 1) / TH;
-        p.nblk = p_in.nblk * (p_in.tiles_x > 0 ? 1 : 1);
         p.stagger = stagger;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
         int grid = grid_max;                                   // one persistent workgroup per CU (two for the half tiles)

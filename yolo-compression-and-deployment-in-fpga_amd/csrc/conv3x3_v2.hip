@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
     constexpr int OFF_W = 2 * SLABB;
     constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;                 // 1 KiB sink for padding pieces
     constexpr int OFF_STG = OFF_DUMMY + 1024;                      // int8 output tile, row-major
-    constexpr int SROWS = POOL ? MT * WM * 4 : MT * WM * 16;       // staged rows (pixels / windows)
+    // staged rows (pixels / windows): POOL ? MT * WM * 4 : MT * WM * 16 -- sized by the launcher (ConvInst2::SROWS)
     constexpr int SSTR = BN + 16;                                  // bytes per staged row (+pad)
     constexpr int OROWS = POOL ? BM / 4 : BM;                      // real rows of a tile
     constexpr int NIT = (OROWS * (BN / 16) + NTHR - 1) / NTHR;     // output stores per thread per tile (static)
