@@ -238,6 +238,10 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
             for (int c = 0; c < 3; ++c) v[k][xp][c] = xb[c * plane + o];
         }
     }
+    // 5 VALU ops per value: v_mul, v_rndne, v_med3 (clamp), v_max |r| (saturation DETECTED; counted exactly below only
+    // when it happened), v_cvt_i32_f32 with SDWA writing byte c of the pixel word.  Pixels outside the image are
+    // zeroed with one select per pixel.
+    float satm = 0.f;
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
         const int py = wave + 4 * k;
@@ -248,17 +252,36 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
             const int px = xp * 64 + lane;
             const int gx = x0 + px - 1;
             const bool inside = rowin && gx >= 0 && gx < W;
-            const bool own = inside && py >= 1 && py <= TH && px >= 1 && px <= TW;
             unsigned int w = 0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float r = rintf(v[k][xp][c] * sc);
-                const float rc = fminf(fmaxf(r, -127.f), 127.f);
-                nsat_in += (own && rc != r) ? 1u : 0u;
-                const int q = inside ? (int)rc : 0;
-                w |= (unsigned int)(q & 0xff) << (8 * c);
+                const float rc = __builtin_amdgcn_fmed3f(r, -127.f, 127.f);
+                satm = fmaxf(satm, fabsf(r));
+                if (c == 0) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(rc));
+                else if (c == 1) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(rc));
+                else asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(rc));
             }
-            if (px < PW && py < PH) patch[py * PW + px] = w;
+            if (px < PW && py < PH) patch[py * PW + px] = inside ? w : 0u;
+        }
+    }
+    if (!(satm <= 127.f)) {                          // cold (also taken for NaN): the exact count over the tile's own pixels
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int py = wave + 4 * k;
+            const int gy = y0 + py - 1;
+            const bool rowin = gy >= 0 && gy < H && py < PH;
+#pragma unroll
+            for (int xp = 0; xp < XP; ++xp) {
+                const int px = xp * 64 + lane;
+                const int gx = x0 + px - 1;
+                const bool own = rowin && gx >= 0 && gx < W && py >= 1 && py <= TH && px >= 1 && px <= TW;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float r = rintf(v[k][xp][c] * sc);
+                    nsat_in += (own && fminf(fmaxf(r, -127.f), 127.f) != r) ? 1u : 0u;
+                }
+            }
         }
     }
     }
