@@ -1,0 +1,23 @@
+#include <hip/hip_runtime.h>
+__global__ void k(const float *x, unsigned int *out) {
+    float a = x[threadIdx.x], b = x[threadIdx.x + 64], c = x[threadIdx.x + 128];
+    unsigned int w = 0;
+    asm volatile("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(a));
+    asm volatile("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(b));
+    asm volatile("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(c));
+    out[threadIdx.x] = w;
+}
+int main() {
+    float *x; unsigned int *o; hipMalloc(&x, 192 * 4); hipMalloc(&o, 256);
+    float h[192]; for (int i = 0; i < 192; ++i) h[i] = (float)((i * 37) % 255 - 127);
+    hipMemcpy(x, h, sizeof h, hipMemcpyHostToDevice);
+    k<<<1, 64>>>(x, o);
+    unsigned int r[64]; hipMemcpy(r, o, 256, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 64; ++i) {
+        unsigned int want = ((unsigned)(int)h[i] & 0xff) | (((unsigned)(int)h[i + 64] & 0xff) << 8) | (((unsigned)(int)h[i + 128] & 0xff) << 16);
+        bad += want != r[i];
+    }
+    printf("sdwa cvt pack: %d mismatches, sample %08x\n", bad, r[5]);
+    return bad != 0;
+}
