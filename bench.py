@@ -44,7 +44,7 @@ DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, fals
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/, collected with
     rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE runs at this workload); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
     try:
         with open(path) as f:
             for name, v in json.load(f)["kernels"].items():
