@@ -343,6 +343,8 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the extra 'sparse fixture' measurement (SURVEY.md 8d)")
+    ap.add_argument("--no-fuse-front", action="store_true",
+                    help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32 = the headline configuration (fp32 NCHW tensor resident in HBM); u8 = uint8 HWC BGR "
@@ -377,6 +379,8 @@ def main():
             e = Engine([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.01, nms_thresh=0.5,
                        max_batch=B, device=dev)
             e.load_quantized(quantized_layers(2))
+            if args.no_fuse_front:
+                e.set_option(1, 0)                       # Y355_OPT_FUSE_FRONT
         engines.append(e)
     eng = engines[0]
     # calibrate once (first-call semantics, slim_yolo_v2.py:25-27) on the seed-1 image, rank 0;

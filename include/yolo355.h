@@ -71,6 +71,12 @@ int y355_version(void);
 int y355_create(const y355_config *cfg, y355_engine **out);
 void y355_destroy(y355_engine *h);
 int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
+/* engine options.  Y355_OPT_FUSE_FRONT (default 1): run input quantisation, conv1, pool1, conv2 and pool2
+ * (models/slim_yolo_v2.py:218-244; first_conv + second_conv of c_embedding/yolo_forward.c:269-572) as one launch whose
+ * 16-channel intermediate map stays on chip; 0 = one launch per layer (then y355_get_feature(0) is current after a forward).
+ * Results are identical bit for bit either way. */
+#define Y355_OPT_FUSE_FRONT 1
+int y355_set_option(y355_engine *h, int option, int value);
 
 /* replaces load_state_dict of the quantized checkpoint: integer weights as produced by
  * quantize_layers (retune_bias_quantize.py:111-119): q_w[cout][cin][3][3] int8 with value

@@ -281,10 +281,10 @@ def test_forward_frames_equals_normalised_tensor():
     eng.calibrate(x[:1], [RangeTracker() for _ in range(11)])
     ref = eng.forward(x)
     ctr_ref = eng.counters()
-    feat_ref = [eng.get_feature(k, B).copy() for k in (0, 9)]
+    feat_ref = [eng.get_feature(k, B).copy() for k in (1, 9)]
     got = eng.forward_frames(frames)
     assert eng.counters() == ctr_ref                       # clamped inputs / outputs counted identically
-    for k, f in zip((0, 9), feat_ref):
+    for k, f in zip((1, 9), feat_ref):
         assert np.array_equal(eng.get_feature(k, B), f)
     for a, b in zip(ref, got):
         for u, v in zip(a, b):
@@ -293,6 +293,50 @@ def test_forward_frames_equals_normalised_tensor():
     for a, b in zip(ref, got2):
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
+    eng.close()
+
+
+@pytest.mark.parametrize("H,W,B,gain", [(416, 416, 3, 1.0), (96, 96, 2, 1.0), (320, 416, 2, 1.0), (240, 320, 2, 1.6),
+                                         (112, 64, 1, 2.5)])
+def test_fused_front_end_equals_layer_launches(H, W, B, gain):
+    """conv1 + pool1 + conv2 + pool2 as ONE launch (csrc/front.hip, the default) against the oracle's conv2 map and against
+    the one-launch-per-layer route: identical int8 maps, detections and saturation counters; fp32 tensors and uint8 frames;
+    edge tiles (sizes that are not multiples of the 52-pixel tile), inputs beyond the calibration range (clamped pixels and
+    outputs must be counted once although halo pixels are computed by two tiles)."""
+    from yolo355 import _ffi
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2, pred_gain=400.0, obj_bias=-4.0))
+    eng = Engine([H, W], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+    eng.load_quantized(ql)
+    frames = synth.make_frames_u8(11, B, H, W, "blocks")
+    xc = synth.normalize_frames(frames)[:1]
+    eng.calibrate(xc, [RangeTracker() for _ in range(11)])
+    otr = [O.RangeTracker() for _ in range(11)]
+    O.detect(xc, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2)
+    x = synth.normalize_frames(frames) * np.float32(gain)
+    r = O.detect(x, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2, saturate=True, keep=True)
+    res = {}
+    for fuse in (1, 0):
+        eng.set_option(_ffi.OPT_FUSE_FRONT, fuse)
+        dets = eng.forward(x)
+        res[fuse] = (dets, eng.counters(), eng.get_feature(1, B).copy(), eng.get_feature(9, B).copy())
+    assert np.array_equal(res[1][2], r["maps"][1].astype(np.int8)), "conv2 map of the fused launch differs from the oracle"
+    assert np.array_equal(res[1][3], r["pred_q"].astype(np.int8))
+    assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][3], res[0][3])
+    assert res[1][1] == res[0][1], "saturation counters differ between the fused and the per-layer route"
+    if gain > 1.0:
+        assert res[1][1][0] > 0
+    for a, b in zip(res[1][0], res[0][0]):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    if gain == 1.0:
+        for fuse in (1, 0):
+            eng.set_option(_ffi.OPT_FUSE_FRONT, fuse)
+            got = eng.forward_frames(frames)
+            assert eng.counters() == res[1][1]
+            assert np.array_equal(eng.get_feature(1, B), res[1][2]) and np.array_equal(eng.get_feature(9, B), res[1][3])
+            for a, b in zip(res[1][0], got):
+                for u, v in zip(a, b):
+                    assert np.array_equal(u, v)
     eng.close()
 
 

@@ -166,6 +166,7 @@ struct y355_engine {
     int max_det = 0;
     int stamp_layer = -1;
     int profile = 0;
+    int fuse_front = 1;             // conv1 + pool1 + conv2 + pool2 as one launch (front.hip) where eligible
     hipEvent_t ev[Y355_NUM_TIMERS + 1];
     bool ev_ok = false;
     std::vector<void *> allocs;
@@ -292,6 +293,14 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     }
     *out = h;
     return 0;
+}
+
+extern "C" int y355_set_option(y355_engine *h, int option, int value) {
+    if (!h) return fail(Y355_EINVAL, "null engine");
+    switch (option) {
+    case Y355_OPT_FUSE_FRONT: h->fuse_front = value ? 1 : 0; return 0;
+    default: return fail(Y355_EINVAL, "unknown option");
+    }
 }
 
 extern "C" int y355_set_thresholds(y355_engine *h, float conf, float nms) {
@@ -541,13 +550,47 @@ static HeadParams head_params(y355_engine *h, int sa_pred, float *ob, float *os,
     return p;
 }
 
+// conv1 + pool1 + conv2 + pool2 in one launch (front.hip); the 16-channel map never reaches HBM
+static int launch_front(y355_engine *h, int B, const float *x_dev) {
+    Layer &L0 = h->L[0], &L1 = h->L[1];
+    FrontParams p{};
+    p.x = x_dev;
+    p.x_u8 = x_dev ? nullptr : h->x_u8;
+    for (int c = 0; c < 3; ++c) { p.nmean[c] = h->nmean[c]; p.nstd[c] = h->nstd[c]; }
+    p.out = L1.out_dev;
+    p.w1 = h->w0_dev;
+    p.w2 = L1.w_dev;
+    p.bias1 = L0.bias_dev;
+    p.bias2 = L1.bias_dev;
+    p.ctr = h->ctr_dev;
+    p.B = B;
+    p.H = L0.Hin;
+    p.W = L0.Win;
+    y355_front_tiles(L0.Hin, L0.Win, &p.tiles_x, &p.tiles_y);
+    p.in_scale = std::ldexp(1.0f, h->sa[0]);
+    p.rq1 = L0.rq;
+    p.rq2 = L1.rq;
+    p.stamps = (h->stamp_layer == 0) ? h->stamps_dev : nullptr;
+    y355_launch_front(p, h->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // enqueue one forward on `s` (refresh_layer must have run)
 static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
                            int32_t *cls_dev, int32_t *count_dev, bool prof) {
     HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * 10, h->stream));
     const int guard = (flags & Y355_F_GUARD) ? 1 : 0;
+    // the fused front end covers the 32-bit epilogue without the head-room guard; conv2's packed weights must be the
+    // resident-weight layout (one n-block of 32 channels), which they are for this network
+    const bool fused = h->fuse_front && !guard && !h->L[0].rq.wide && !h->L[1].rq.wide && h->L[1].cout_pad == 32;
     for (int k = 0; k < 10; ++k) {
         if (prof) HIPCHK(hipEventRecord(h->ev[k], h->stream));
+        if (fused && k == 0) {
+            if (int rc = launch_front(h, batch, x_dev)) return rc;
+            continue;
+        }
+        if (fused && k == 1) continue;                    // timer slot 1 reads ~0: slot 0 holds conv1 + conv2
         if (int rc = launch_layer(h, k, batch, 0, guard, x_dev)) return rc;
     }
     if (prof) HIPCHK(hipEventRecord(h->ev[10], h->stream));

@@ -1,0 +1,437 @@
+// yolo355 -- fused front end of the q_bf path: input quantise -> conv1(3->16) -> bias -> LeakyReLU(0.125) ->
+// requantise -> 2x2 max-pool -> conv2(16->32) -> bias -> LeakyReLU -> requantise -> 2x2 max-pool, ONE kernel.
+//
+// Replaces models/slim_yolo_v2.py:218-244 (a_tracker_in, conv1, a_tracker1, pool1, conv2, a_tracker2, pool2)
+// and the FPGA driver's first_conv + second_conv (c_embedding/yolo_forward.c:269-572: the same fusion
+// boundary -- the camera frame goes in, the 32-channel quarter-resolution map comes out).
+//
+// Why: as three launches the 16- and 32-channel maps round-trip through HBM (45 MB + 23 MB written and read
+// back per 64-image batch) and each launch exposes its own load latency.  Here a persistent workgroup walks
+// tiles of TOY x TOX pooled conv2 outputs:
+//   Q   the fp32 (or uint8) input patch of the tile, prefetched into registers during the previous tile's
+//       MFMA phases, is quantised into an LDS patch of 4-byte pixels (r, g, b, 0);
+//   C1  conv1 on the matrix cores (one v_mfma_i32_16x16x64_i8 per 16 pixels x 16 channels, K = 3 filter rows
+//       x 4 pixels x 4 bytes, rows ordered as 2x2 pooling windows so the pool is a max over the lane's four
+//       accumulators) -> int8 pooled tile WITH its one-pixel halo in LDS (halo pixels are recomputed, pixels
+//       outside the image are zero: conv2's padding);
+//   C2  conv2 from that LDS tile (K = 9 taps x 16 channels in three 64-deep steps, weights resident in
+//       registers) -> pooled int8 tile staged in LDS;
+//   OUT 16-byte coalesced stores of the NHWC32 tile.
+// Integer semantics are those of conv1.hip / conv3x3_v2.hip, bit for bit; saturation is
+// detected with one op per output and counted exactly (own pixels only) in a cold second pass.
+#include "y355_common.h"
+#include <type_traits>
+#ifndef FRONT_PREFETCH
+#define FRONT_PREFETCH 0
+#endif
+#ifndef FRONT_OCC
+#define FRONT_OCC 3
+#endif
+#ifndef FRONT_DIAG
+#define FRONT_DIAG 0             // 1: s_memtime stamps at the phase boundaries of each workgroup's first tiles (y355_debug_stamps)
+#endif
+
+// 16-byte pixels: the LDS pitch (in pixels) that makes the A-fragment ds_read_b128 of 2x2-window-ordered
+// rows conflict-free under gfx950's 4 x 16 lane grouping (conv3x3_v2.hip: pitch = 8 mod 16)
+constexpr int front_pitch32(int pw) { int p = pw; while (p % 32 != 8) ++p; return p; }
+constexpr int front_pitch16(int pw) { int p = pw; while (p % 16 != 8) ++p; return p; }
+
+__device__ __forceinline__ void front_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int TOY, int TOX>
+struct FrontGeom {
+    static constexpr int P1H = 2 * TOY + 2, P1W = 2 * TOX + 2;     // pooled conv1 tile (windows), with halo
+    static constexpr int PH0 = 2 * P1H + 2;                        // input patch rows
+    static constexpr int NG = (2 * P1W + 4) / 4;                   // 4-pixel groups per patch row (16-byte aligned in x)
+    // patch pitch in pixels (= dwords): 8 mod 32, so that the three patch rows an A fragment's half-wave touches (eight
+    // consecutive dwords each) fall into disjoint LDS banks (pitch 60 made every ds_read_b32 a 2-way conflict)
+    static constexpr int P0 = front_pitch32(NG * 4);
+    static constexpr int NITEM = PH0 * NG;
+    static constexpr int IPT = (NITEM + 255) / 256;
+    static constexpr int P1P = front_pitch16(P1W);
+    static constexpr int MT1 = P1W / 4;                            // conv1 m-tiles (4 windows) per window row
+    static constexpr int NWIN = TOY * TOX;
+    static constexpr int MT2_TOT = (NWIN + 3) / 4;
+    static constexpr int MT2 = (MT2_TOT + 3) / 4;                  // conv2 m-tiles per wave
+    static_assert(P1W % 4 == 0, "window rows split into whole m-tiles (TOX odd)");
+};
+
+template <int TOY, int TOX, bool U8>
+__global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams p, const int total_tiles) {
+    using G = FrontGeom<TOY, TOX>;
+    constexpr int P1H = G::P1H, P1W = G::P1W, NG = G::NG, P0 = G::P0, NITEM = G::NITEM, IPT = G::IPT;
+    constexpr int P1P = G::P1P, MT1 = G::MT1, NWIN = G::NWIN, MT2 = G::MT2;
+    // separate LDS objects: the compiler then knows that the writes of one phase do not alias the reads of the same phase
+    // (with one array every ds_write of an m-tile fenced the next m-tile's ds_reads and the phases ran as serial chains)
+    __shared__ __attribute__((aligned(16))) unsigned int patch[G::PH0 * P0 + 4];
+    __shared__ __attribute__((aligned(16))) char p1[(P1H + 3) * P1P * 16];   // + slack: padding windows of C2 read past the tile
+    __shared__ __attribute__((aligned(16))) char stg[MT2 * 4 * 4 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned int lut[U8 ? 3 * 256 : 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int H = p.H, W = p.W;
+    const int Hp = H >> 1, Wp = W >> 1, Ho = H >> 2, Wo = W >> 2;
+    const size_t plane = (size_t)H * W;
+    const float sc = p.in_scale;
+
+    // ---- tile-independent per-thread geometry
+    // patch item k of this thread = tid + 256 k: row r, 4-pixel group j (256 = 17 rows + 1 group when NG = 15)
+    int r0 = tid / NG, j0 = tid % NG;
+    auto item_rj = [&](int k, int &r, int &j, bool &ok) {
+        const int jj = j0 + (256 % NG) * k;
+        const int wrap = jj / NG;                          // k * (256 % NG) + j0 < 4 * NG: a couple of compares
+        j = jj - wrap * NG;
+        r = r0 + (256 / NG) * k + wrap;
+        ok = tid + 256 * k < NITEM;
+    };
+    const int r4 = li & 3;
+    int lbase1 = ((r4 >> 1) + min(g, 2)) * P0 + 2 * (li >> 2) + (r4 & 1) + 1;
+    // conv2 A-fragment base of this lane's row in the wave's first m-tile; later m-tiles step 4 windows to the right
+    // with wrap-around (windows past the tile's last one read and write padding that is never copied out)
+    const int w2_0 = wave * MT2 * 4 + (li >> 2);
+    int wx2_0 = w2_0 % TOX;
+    int ab2_0 = ((2 * (w2_0 / TOX) + (r4 >> 1)) * P1P + 2 * wx2_0 + (r4 & 1)) * 16;
+    int kofs2[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int tap = min(4 * t + g, 8);
+        kofs2[t] = ((tap / 3) * P1P + tap % 3) * 16;
+    }
+    int oofs[2], orc[2];                                  // OUT: relative output offset, (row << 8) | col or -1
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = tid + 256 * k;
+        const int px = item >> 1, half = item & 1;
+        const int row = px / TOX, col = px % TOX;
+        orc[k] = item < NWIN * 2 ? ((row << 8) | col) : -1;
+        oofs[k] = (row * (Wo + 2) + col) * 32 + half * 16;
+    }
+    // weights and biases stay in registers for the whole launch
+    const v4i bw1 = *(const v4i *)(p.w1 + lane * 16);
+    v4i bw2[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bw2[t][n] = *(const v4i *)(p.w2 + (t * 2 + n) * 1024 + lane * 16);
+    const Requant rq1 = p.rq1, rq2 = p.rq2;
+    const int shl1 = rq1.shl + rq1.sh_l, shl2 = rq2.shl + rq2.sh_l;
+    const int bias1 = p.bias1[li] << rq1.sh_l;
+    const int bias2a = p.bias2[2 * li] << rq2.sh_l, bias2b = p.bias2[2 * li + 1] << rq2.sh_l;
+    auto requant1 = [&](int v) {
+        int x = (v << shl1) + bias1;
+        x = max(x, x << rq1.lk);
+        const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq1.sh_r, (unsigned int)rq1.bw);
+        return (x + rq1.hm1 + rb) >> rq1.sh_r;
+    };
+    auto requant2 = [&](int v, int bias) {
+        int x = (v << shl2) + bias;
+        x = max(x, x << rq2.lk);
+        const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq2.sh_r, (unsigned int)rq2.bw);
+        return (x + rq2.hm1 + rb) >> rq2.sh_r;
+    };
+    if constexpr (U8) {
+        // normalise + quantise is a function of the byte: per channel a 256-entry table built with the reference's
+        // fp32 operations in the reference's order ((u/255 - mean)/std, data/__init__.py:43-45; round(x * 2^sa),
+        // slim_yolo_v2.py:35); entry = the int8 value already in the pixel word's byte c, bit 24 = "was clamped"
+        // (byte 3 of a pixel multiplies zero weights)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = (float)tid;
+            t /= 255.0f;
+            t -= p.nmean[c];
+            t /= p.nstd[c];
+            const float r = rintf(t * sc);
+            const float rc = fminf(fmaxf(r, -127.f), 127.f);
+            lut[c * 256 + tid] = (((unsigned int)(int)rc & 0xffu) << (8 * c)) | (rc != r ? (1u << 24) : 0u);
+        }
+    }
+
+    const int G_ = gridDim.x;
+    const int vb = y355_xcd_remap(blockIdx.x, G_);
+    auto decode = [&](int t, int &b, int &ty, int &tx) {
+        tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        ty = t % p.tiles_y;
+        b = t / p.tiles_y;
+    };
+    // prefetch registers: IPT items x 3 channels x 4 pixels (fp32), or IPT x 12 bytes (uint8 HWC BGR)
+    float4 vf[U8 ? 1 : IPT][3];
+    uint3 vu[U8 ? IPT : 1];
+    auto load_tile = [&](int b, int ty, int tx) {
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            int r, j;
+            bool ok;
+            item_rj(k, r, j, ok);
+            const int gy = min(max(y0p + r, 0), H - 1);       // items past the patch re-read valid rows
+            const int gx = min(max(x0p + 4 * j, 0), W - 4);
+            const size_t o = (size_t)gy * W + gx;
+            if constexpr (U8) {
+                vu[k] = *(const uint3 *)(p.x_u8 + ((size_t)b * plane + o) * 3);
+            } else {
+                const float *xb = p.x + (size_t)b * 3 * plane + o;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vf[k][c] = *(const float4 *)(xb + c * plane);
+            }
+        }
+    };
+
+    int tile = vb;
+    if (tile >= total_tiles) return;
+    int nstamp = 0;
+    auto stamp = [&]() {
+#if FRONT_DIAG
+        if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
+#endif
+    };
+    (void)nstamp;
+    int b, ty, tx;
+    decode(tile, b, ty, tx);
+#if FRONT_PREFETCH
+    load_tile(b, ty, tx);
+#endif
+    if constexpr (U8) front_lds_barrier();              // the table is complete
+    unsigned int nsat_in = 0, nsat1 = 0, nsat2 = 0;
+
+    for (;;) {
+        // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
+        // out of the tile loop as a loop invariant and the kernel spills ~100 registers of precomputed addresses
+        asm volatile("" : "+v"(r0), "+v"(j0), "+v"(lbase1), "+v"(wx2_0), "+v"(ab2_0));
+        const int ntile = tile + G_;
+        const bool more = ntile < total_tiles;
+        int b2 = b, ty2 = ty, tx2 = tx;
+        if (more) decode(ntile, b2, ty2, tx2);
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+        stamp();
+#if !FRONT_PREFETCH
+        load_tile(b, ty, tx);
+#if FRONT_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();
+#endif
+#endif
+
+        // ---- Q: quantise the prefetched patch into LDS: q = clamp(rne(x * 2^sa0))  (slim_yolo_v2.py:33-35)
+        {
+            float satm = 0.f;
+            unsigned int sato = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                int r, j;
+                bool ok;
+                item_rj(k, r, j, ok);
+                const int gy = y0p + r, gx = x0p + 4 * j;
+                const bool inside = ok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                unsigned int w[4];
+                if constexpr (U8) {
+                    const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        // pixel px = bytes 3 px .. 3 px + 2 (B, G, R); RGB channel c = BGR byte 2 - c
+                        unsigned int e = 0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int bi = 3 * px + (2 - c);
+                            const unsigned int u = (d[bi >> 2] >> (8 * (bi & 3))) & 0xffu;
+                            e |= lut[c * 256 + u];
+                        }
+                        sato |= e;
+                        w[px] = e;
+                    }
+                } else {
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        w[px] = 0;
+                        float sat0 = 0.f, sat1 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float xv = px == 0 ? vf[k][c].x : px == 1 ? vf[k][c].y : px == 2 ? vf[k][c].z : vf[k][c].w;
+                            const float rr = rintf(xv * sc);
+                            const float rc = __builtin_amdgcn_fmed3f(rr, -127.f, 127.f);
+                            if (c == 0) sat0 = fabsf(rr);          // detection may see neighbours' pixels; the count below is exact
+                            else if (c == 1) sat1 = fabsf(rr);
+                            else satm = fmaxf(fmaxf(satm, sat0), fmaxf(sat1, fabsf(rr)));
+                            if (c == 0) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w[px]) : "v"(rc));
+                            else if (c == 1) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w[px]) : "v"(rc));
+                            else asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w[px]) : "v"(rc));
+                        }
+                    }
+                }
+                if (ok) {
+                    v4i wv;
+                    wv[0] = inside ? (int)w[0] : 0;
+                    wv[1] = inside ? (int)w[1] : 0;
+                    wv[2] = inside ? (int)w[2] : 0;
+                    wv[3] = inside ? (int)w[3] : 0;
+                    *(v4i *)(patch + r * P0 + 4 * j) = wv;
+                }
+            }
+            // cold (also taken for NaN): exact count of clamped input values over the pixels this tile OWNS
+            // (rows [3, 3 + 4 TOY), groups [1, TOX] of the patch: the tiles' exclusive input areas partition the image)
+            if (U8 ? (sato & (1u << 24)) != 0 : !(satm <= 127.f)) {
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) {
+                    int r, j;
+                    bool ok;
+                    item_rj(k, r, j, ok);
+                    const int gy = y0p + r, gx = x0p + 4 * j;
+                    const bool own = ok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W &&
+                                     r >= 3 && r < 3 + 4 * TOY && j >= 1 && j <= TOX;
+                    if constexpr (U8) {
+                        const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
+#pragma unroll
+                        for (int bi = 0; bi < 12; ++bi) {
+                            const unsigned int u = (d[bi >> 2] >> (8 * (bi & 3))) & 0xffu;
+                            nsat_in += (own && (lut[(2 - bi % 3) * 256 + u] >> 24)) ? 1u : 0u;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float xs[4] = {vf[k][c].x, vf[k][c].y, vf[k][c].z, vf[k][c].w};
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) {
+                                const float rr = rintf(xs[px] * sc);
+                                nsat_in += (own && fminf(fmaxf(rr, -127.f), 127.f) != rr) ? 1u : 0u;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        stamp();
+        front_lds_barrier();                              // B1: patch complete
+        stamp();
+
+        // ---- C1: conv1 + pool1 -> p1 (wave w owns window rows w, w + 4, ...)
+        const int gyp0 = 2 * TOY * ty - 1, gxp0 = 2 * TOX * tx - 1;     // pooled coordinates of window (0, 0)
+        const bool xborder = gxp0 < 0 || gxp0 + P1W > Wp;
+        auto c1 = [&](auto countc) {
+            constexpr bool COUNT = decltype(countc)::value;
+            unsigned int satx = 0;
+#pragma unroll 1
+            for (int wy = wave; wy < P1H; wy += 4) {
+                if ((unsigned)(gyp0 + wy) >= (unsigned)Hp) {          // row outside the image: conv2's zero padding
+                    if (!COUNT && lane < P1W) *(v4i *)(p1 + (wy * P1P + lane) * 16) = (v4i){0, 0, 0, 0};
+                    continue;
+                }
+                const unsigned int *src = patch + lbase1 + wy * 2 * P0;
+                char *dst = p1 + (wy * P1P + g) * 16 + li;
+                // the row's seven A fragments first, then seven independent MFMAs, then the epilogues: written in this
+                // order so that the LDS latency and the MFMA pipeline latency are paid once per row, not once per m-tile
+                v4i a[MT1], acc[MT1];
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt) {
+                    a[mt][0] = (int)src[mt * 8 + 0];
+                    a[mt][1] = (int)src[mt * 8 + 1];
+                    a[mt][2] = (int)src[mt * 8 + 2];
+                    a[mt][3] = (int)src[mt * 8 + 3];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mt], bw1, (v4i){0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt) {
+                    const int vmax = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
+                    const int qq = requant1(vmax);
+                    const int q = y355_clamp8<int>(qq);
+                    if constexpr (!COUNT) {
+                        satx += (unsigned int)(q ^ qq);
+                        dst[mt * 64] = (char)q;
+                    } else {
+                        int gl = g;
+                        asm volatile("" : "+v"(gl));              // cold path: nothing of it may be hoisted out of the tile loop
+                        const int wx = 4 * mt + gl;
+                        const bool own = wy >= 1 && wy < P1H - 1 && wx >= 1 && wx < P1W - 1 && gxp0 + wx < Wp;
+                        satx += (own && q != qq) ? 1u : 0u;
+                    }
+                }
+                if (!COUNT && xborder && lane < P1W && (unsigned)(gxp0 + lane) >= (unsigned)Wp)
+                    *(v4i *)(p1 + (wy * P1P + lane) * 16) = (v4i){0, 0, 0, 0};
+            }
+            return satx;
+        };
+        if (__builtin_amdgcn_ballot_w64(c1(std::false_type{}) != 0) != 0ull) nsat1 += c1(std::true_type{});
+        stamp();
+        front_lds_barrier();                              // B2: p1 complete
+        stamp();
+#if FRONT_PREFETCH
+        if (more) load_tile(b2, ty2, tx2);                // the next tile's input: in flight during C2 and OUT
+#endif
+
+        // ---- C2: conv2 + pool2 -> staged int8 tile (wave w owns m-tiles w * MT2 ..)
+        auto c2 = [&](auto countc) {
+            constexpr bool COUNT = decltype(countc)::value;
+            unsigned int satx = 0;
+            int ab = ab2_0, wx = wx2_0;
+#pragma unroll 2
+            for (int m = 0; m < MT2; ++m) {
+                v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const v4i a = *(const v4i *)(p1 + ab + kofs2[t]);
+                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw2[t][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw2[t][1], acc1, 0, 0, 0);
+                }
+                const int qq0 = requant2(max(max(acc0[0], acc0[1]), max(acc0[2], acc0[3])), bias2a);
+                const int qq1 = requant2(max(max(acc1[0], acc1[1]), max(acc1[2], acc1[3])), bias2b);
+                const int q0 = y355_clamp8<int>(qq0), q1 = y355_clamp8<int>(qq1);
+                int gl = g;
+                if constexpr (COUNT) asm volatile("" : "+v"(gl));  // cold path: nothing of it may be hoisted out of the tile loop
+                const int w = (wave * MT2 + m) * 4 + gl;
+                if constexpr (!COUNT) {
+                    satx += (unsigned int)(q0 ^ qq0) + (unsigned int)(q1 ^ qq1);
+                    *(unsigned short *)(stg + w * 32 + 2 * li) = (unsigned short)((q0 & 0xff) | ((q1 & 0xff) << 8));
+                } else {
+                    const bool own = w < NWIN && TOY * ty + w / TOX < Ho && TOX * tx + w % TOX < Wo;
+                    satx += (own && q0 != qq0 ? 1u : 0u) + (own && q1 != qq1 ? 1u : 0u);
+                }
+                wx += 4;
+                const bool wrap = wx >= TOX;
+                wx -= wrap ? TOX : 0;
+                ab += wrap ? (8 + 2 * P1P - 2 * TOX) * 16 : 8 * 16;
+            }
+            return satx;
+        };
+        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}) != 0) != 0ull) nsat2 += c2(std::true_type{});
+        stamp();
+        front_lds_barrier();                              // B3: staged tile complete
+        stamp();
+
+        // ---- OUT: NHWC32 with halo, 16 bytes per thread and item
+        {
+            int8_t *outb = p.out + (((size_t)b * (Ho + 2) + TOY * ty + 1) * (Wo + 2) + TOX * tx + 1) * 32;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = orc[k] >> 8, col = orc[k] & 0xff;
+                if (orc[k] >= 0 && TOY * ty + row < Ho && TOX * tx + col < Wo)
+                    *(v4i *)(outb + oofs[k]) = *(const v4i *)(stg + (tid + 256 * k) * 16);
+            }
+        }
+        if (!more) break;
+        tile = ntile;
+        b = b2; ty = ty2; tx = tx2;
+    }
+    if (nsat_in) atomicAdd(&p.ctr[0].in_sat, (unsigned long long)nsat_in);
+    if (nsat1) atomicAdd(&p.ctr[0].sat, (unsigned long long)nsat1);
+    if (nsat2) atomicAdd(&p.ctr[1].sat, (unsigned long long)nsat2);
+}
+
+void y355_front_tiles(int H, int W, int *tx, int *ty) {
+    *tx = (W / 4 + 12) / 13;
+    *ty = (H / 4 + 12) / 13;
+}
+
+void y355_launch_front(const FrontParams &p, hipStream_t s) {
+    const int total = p.tiles_x * p.tiles_y * p.B;
+    int grid = 256 * FRONT_OCC;
+    if (grid > total) grid = total;
+    if (p.x) hipLaunchKernelGGL((front_kernel<13, 13, false>), dim3(grid), dim3(256), 0, s, p, total);
+    else hipLaunchKernelGGL((front_kernel<13, 13, true>), dim3(grid), dim3(256), 0, s, p, total);
+}

@@ -80,6 +80,26 @@ struct Conv1Params {
     int guard;
 };
 
+// fused front end (front.hip): network input -> conv1 + pool1 -> conv2 + pool2
+struct FrontParams {
+    const float *x;       // fp32 NCHW [B][3][H][W]
+    const uint8_t *x_u8;  // or (x == nullptr) uint8 HWC BGR frames [B][H][W][3]
+    float nmean[3], nstd[3];
+    int8_t *out;          // conv2's pooled output: int8 NHWC32 with halo [B][H/4+2][W/4+2][32]
+    const int8_t *w1;     // conv1 fragment (y355_pack_conv1)
+    const int8_t *w2;     // conv2 fragments (y355_pack_weights of Y355_K_CONV2: 3 k-steps x 2 n-tiles x 1 KiB)
+    const int *bias1;     // [16]
+    const int *bias2;     // [32]
+    Counters *ctr;        // [0] conv1, [1] conv2
+    int B, H, W;
+    int tiles_x, tiles_y;
+    float in_scale;       // 2^sa[0]
+    Requant rq1, rq2;
+    unsigned long long *stamps;   // diagnostic builds only (-DFRONT_DIAG=1)
+};
+void y355_front_tiles(int H, int W, int *tx, int *ty);
+void y355_launch_front(const FrontParams &p, hipStream_t s);
+
 template <typename T>
 __device__ __forceinline__ T y355_rne_shift(T t, int sh) {
     if (sh > 0) {

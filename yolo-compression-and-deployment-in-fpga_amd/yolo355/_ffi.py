@@ -15,6 +15,7 @@ MAX_ANCHORS = 16
 NUM_TIMERS = 12
 F_GUARD, F_TAP = 1, 2
 OP_LEAKY, OP_POOL = 1, 2
+OPT_FUSE_FRONT = 1
 
 
 class Config(C.Structure):
@@ -59,6 +60,7 @@ _SIGS = {
     "y355_create": (C.c_int, [P(Config), P(C.c_void_p)]),
     "y355_destroy": (None, [C.c_void_p]),
     "y355_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "y355_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y355_load_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "y355_set_act_exponents": (C.c_int, [C.c_void_p, P(C.c_int32)]),
     "y355_get_act_exponents": (C.c_int, [C.c_void_p, P(C.c_int32)]),

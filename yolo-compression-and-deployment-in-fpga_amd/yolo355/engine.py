@@ -97,6 +97,10 @@ class Engine:
         arr = (C.c_int32 * 10)(*[int(v) for v in retune])
         _ffi.check(self._lib.y355_set_retune(self._h, arr))
 
+    def set_option(self, option, value):
+        """Engine options of include/yolo355.h, e.g. set_option(_ffi.OPT_FUSE_FRONT, 0): one launch per layer."""
+        _ffi.check(self._lib.y355_set_option(self._h, int(option), int(value)))
+
     def set_thresholds(self, conf_thresh, nms_thresh):
         self.conf_thresh, self.nms_thresh = float(conf_thresh), float(nms_thresh)
         _ffi.check(self._lib.y355_set_thresholds(self._h, self.conf_thresh, self.nms_thresh))
