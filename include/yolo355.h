@@ -145,10 +145,11 @@ int y355_num_anchors_total(y355_engine *h);    /* N = Hs*Ws*A */
 /* --- operator-level entry points (utils/modules.py Conv2d_fuse, unit tests) ----------------
  * One fused int8 layer on caller data, host pointers, synchronous:
  *   q_in  int8 [B][cin][H][W] (NCHW), q_w int8 [cout][cin][3][3], q_b int32 [cout]
- *   out   int8 [B][cout][Ho][Wo]; flags bit0 = LeakyReLU(0.125), bit1 = 2x2 max-pool
+ *   out   int8 [B][cout][Ho][Wo]; flags bit0 = LeakyReLU(0.125), bit1 = 2x2 max-pool, bit2 = ReLU
  * Requantisation: q_out = clamp(RNE(t' * 2^(sa_out - F'))), see DESIGN.md. */
 #define Y355_OP_LEAKY 1
 #define Y355_OP_POOL 2
+#define Y355_OP_RELU 4   /* ReLU instead of LeakyReLU(0.125): Conv2d_fuse(..., leakyReLU=False), utils/modules.py:26 */
 int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const int8_t *q_w, const int32_t *q_b,
                           int batch, int cin, int cout, int height, int width,
                           int sa_in, int e_w, int e_b, int sa_out, int flags,
@@ -235,7 +236,7 @@ typedef struct y355_net y355_net;
 typedef struct y355_net_config {
     int32_t device_id;
     int32_t arch, dtype;
-    int32_t height, width;        /* multiples of 32 */
+    int32_t height, width;        /* multiples of 32 (Y355_ARCH_SLIM_V2: of 16) */
     int32_t num_classes;
     int32_t num_anchors;          /* per prediction level */
     float anchors[2 * Y355_MAX_ANCHORS];

@@ -142,7 +142,10 @@ def conv_layer_int(q_in, q_w, q_b, sa_in, e_w, e_b, leaky):
     acc = conv3x3_int(q_in, q_w)
     Fx = max(sa_in + e_w, e_b)
     t = (acc << np.int64(Fx - sa_in - e_w)) + (q_b.astype(np.int64) << np.int64(Fx - e_b))[None, :, None, None]
-    if leaky:
+    if isinstance(leaky, str):
+        assert leaky == "relu"
+        t = np.maximum(t, 0)               # nn.ReLU of Conv2d_fuse(leakyReLU=False), utils/modules.py:26: exponent unchanged
+    elif leaky:
         t = np.where(t >= 0, t * 8, t)     # LeakyReLU(0.125): scale by 8, exponent +3
         Fx += 3
     return t, Fx, acc

@@ -85,11 +85,14 @@ int prepare_kernels() { return y355_prepare_kernels(); }
 
 // Fill the integer epilogue of one layer.  Returns Y355_ERANGE when the int32 path could
 // overflow for worst-case operands.
-int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool have_out, int leaky, int retune,
+// act: 0 none (prediction layer), 1 LeakyReLU(0.125) (t' = t >= 0 ? 8 t : t, F' = F + 3), 2 ReLU (utils/modules.py:26 with
+// leakyReLU=False: t' = max(t, 0), F' = F; runs on the generic kernels, whose epilogue honours neg_mul = 0)
+int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool have_out, int act, int retune,
                  const int32_t *q_b, int cout, int cout_pad, Requant *rq, int *frac_bits, std::vector<int32_t> *bias_t,
                  std::vector<long long> *bias_w) {
     const int F = std::max(sa_in + e_w, e_b);
     const int shl = F - sa_in - e_w, bshl = F - e_b;
+    const int leaky = act == 1 ? 1 : 0;
     const int Fp = F + (leaky ? 3 : 0);
     if (shl > 30 || bshl > 40) return fail(Y355_ERANGE, "exponent gap too large for the fixed-point epilogue");
     long long bmax = 0;
@@ -115,9 +118,9 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     if (!rq->wide && sh > 31) sh = 31;
     rq->shl = shl;
     rq->sh = sh;
-    rq->leaky = leaky;
+    rq->leaky = act ? 1 : 0;
     rq->lk = leaky ? 3 : 0;
-    rq->neg_mul = 1;
+    rq->neg_mul = act == 2 ? 0 : 1;
     rq->sh_l = sh < 0 ? -sh : 0;
     rq->sh_r = sh > 0 ? sh : 0;
     rq->hm1 = sh > 0 ? (int)((1ll << (sh - 1)) - 1) : 0;
@@ -850,7 +853,8 @@ extern "C" int y355_conv3x3_i8_raw(int device_id, const int8_t *q_in, const int8
                                    int flags, int64_t *out, int32_t *frac_bits) {
     if (!q_in || !q_w || !q_b || !out || !frac_bits) return fail(Y355_EINVAL, "null argument");
     if (batch < 1 || cin < 1 || cin > 256 || cout < 1 || H < 1 || W < 1) return fail(Y355_EINVAL, "bad shape (cin <= 256)");
-    const int leaky = (flags & Y355_OP_LEAKY) ? 1 : 0;
+    if ((flags & Y355_OP_LEAKY) && (flags & Y355_OP_RELU)) return fail(Y355_EINVAL, "LeakyReLU and ReLU are exclusive");
+    const int leaky = (flags & Y355_OP_LEAKY) ? 1 : ((flags & Y355_OP_RELU) ? 2 : 0);
     HIPCHK(hipSetDevice(device_id));
     if (int e = prepare_kernels()) return e;
     const int cpad = cin <= 16 ? 16 : cin <= 32 ? 32 : cin <= 64 ? 64 : cin <= 128 ? 128 : 256;
@@ -926,7 +930,8 @@ extern "C" int y355_conv3x3_i8_fused(int device_id, const int8_t *q_in, const in
                                      int sa_out, int flags, int8_t *out, y355_layer_stats *stats) {
     if (!q_in || !q_w || !q_b || !out) return fail(Y355_EINVAL, "null argument");
     if (batch < 1 || cin < 1 || cin > 256 || cout < 1 || H < 1 || W < 1) return fail(Y355_EINVAL, "bad shape (cin <= 256)");
-    const int pool = (flags & Y355_OP_POOL) ? 1 : 0, leaky = (flags & Y355_OP_LEAKY) ? 1 : 0;
+    if ((flags & Y355_OP_LEAKY) && (flags & Y355_OP_RELU)) return fail(Y355_EINVAL, "LeakyReLU and ReLU are exclusive");
+    const int pool = (flags & Y355_OP_POOL) ? 1 : 0, leaky = (flags & Y355_OP_LEAKY) ? 1 : ((flags & Y355_OP_RELU) ? 2 : 0);
     if (pool && ((H | W) & 1)) return fail(Y355_EINVAL, "pooling needs even H, W");
     HIPCHK(hipSetDevice(device_id));
     if (int e = prepare_kernels()) return e;

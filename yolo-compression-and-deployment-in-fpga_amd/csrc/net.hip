@@ -421,8 +421,11 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (cfg->arch >= Y355_ARCH_YOLO_V2 && cfg->dtype != Y355_DT_BF16)
         return y355_fail(Y355_EINVAL, "yolo_v2 / yolo_v3 / yolo_v3_spp are built in bf16 only (the reference has no quantized form of them)");
     if (cfg->dtype != Y355_DT_BF16 && cfg->dtype != Y355_DT_INT8) return y355_fail(Y355_EINVAL, "unknown dtype");
-    if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % 32 || cfg->width % 32)
-        return y355_fail(Y355_EINVAL, "input size must be a positive multiple of 32");
+    // SlimYOLOv2 has four 2x2 pools (stride 16: models/slim_yolo_v2.py:52); the other graphs reach stride 32
+    const int mult = cfg->arch == Y355_ARCH_SLIM_V2 ? 16 : 32;
+    if (cfg->height <= 0 || cfg->width <= 0 || cfg->height % mult || cfg->width % mult)
+        return y355_fail(Y355_EINVAL, cfg->arch == Y355_ARCH_SLIM_V2 ? "input size must be a positive multiple of 16"
+                                                                      : "input size must be a positive multiple of 32");
     const ArchDef &A = kArch[cfg->arch];
     if (cfg->num_anchors < 1 || cfg->num_anchors * A.nlev > Y355_HEAD_MAXA || cfg->num_classes < 1)
         return y355_fail(Y355_EINVAL, "bad anchors / classes");

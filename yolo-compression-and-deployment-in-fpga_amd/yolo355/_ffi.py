@@ -14,7 +14,7 @@ HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "yolo3
 MAX_ANCHORS = 16
 NUM_TIMERS = 12
 F_GUARD, F_TAP = 1, 2
-OP_LEAKY, OP_POOL = 1, 2
+OP_LEAKY, OP_POOL, OP_RELU = 1, 2, 4
 OPT_FUSE_FRONT = 1
 
 

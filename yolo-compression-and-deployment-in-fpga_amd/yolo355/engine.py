@@ -70,6 +70,21 @@ class Engine:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ stream ordering
+    # Every kernel goes to the stream that was current when the engine was built (the C ABI takes the stream at
+    # creation).  A caller that has since switched streams (`with torch.cuda.stream(s)`) is ordered explicitly: the
+    # engine's stream waits for the caller's pending work before a launch, and the caller's stream waits for the
+    # engine's before it reads results.  Same stream: no-ops.
+    def _enter(self):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self._stream:
+            self._stream.wait_stream(cur)
+        return cur
+
+    def _leave(self, cur):
+        if cur != self._stream:
+            cur.wait_stream(self._stream)
+
     # ------------------------------------------------------------------ weights / exponents
     def load_layer(self, idx, q_w, q_b, e_w, e_b):
         qw = np.ascontiguousarray(q_w, dtype=np.int8)
@@ -125,6 +140,7 @@ class Engine:
         B = xd.shape[0]
         lib, h = self._lib, self._h
         m = C.c_float()
+        self._enter()                                     # the calls below synchronise the engine's stream themselves
         _ffi.check(lib.y355_input_absmax(h, xd.data_ptr(), B, C.byref(m)))
         sa = [trackers[0].update(m.value, freeze)]
         self.calib_max = [float(m.value)]                 # max|.| seen by each tracker in this calibration
@@ -171,8 +187,10 @@ class Engine:
         rows >= B / entries >= count[b] undefined."""
         B = xd.shape[0]
         ob, os_, oc, on = out if out is not None else self._buffers(B)
+        cur = self._enter()
         _ffi.check(self._lib.y355_forward(self._h, xd.data_ptr(), B, int(flags), ob.data_ptr(), os_.data_ptr(),
                                           oc.data_ptr(), on.data_ptr()))
+        self._leave(cur)
         return ob, os_, oc, on
 
     def forward_frames_device(self, frames, flags=0, out=None):
@@ -186,8 +204,10 @@ class Engine:
         if B > self.max_batch:
             raise ValueError("batch %d > max_batch %d" % (B, self.max_batch))
         ob, os_, oc, on = out if out is not None else self._buffers(B)
+        cur = self._enter()
         _ffi.check(self._lib.y355_forward_u8(self._h, frames.data_ptr(), B, int(flags), ob.data_ptr(), os_.data_ptr(),
                                              oc.data_ptr(), on.data_ptr()))
+        self._leave(cur)
         return ob, os_, oc, on
 
     def forward_frames(self, frames, find=False):
@@ -223,7 +243,9 @@ class Engine:
             ob, os_, oc, on = self.forward_device(xd, flags)
         if wh.shape[0] != B:
             raise ValueError("sizes_wh has %d rows for a batch of %d" % (wh.shape[0], B))
+        cur = self._enter()
         _ffi.check(self._lib.y355_scale_boxes(self._h, ob.data_ptr(), on.data_ptr(), wh.data_ptr(), B))
+        self._leave(cur)
         n = on[:B].cpu().numpy()
         if find:
             sat, guard = self.counters()
@@ -292,8 +314,15 @@ class Engine:
         return list(arr)
 
 
-def conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=True, pool=False, device_id=0):
-    """Operator-level fused layer (y355_conv3x3_i8_fused): numpy int8 NCHW in/out."""
+def _act_flag(leaky, relu):
+    if leaky and relu:
+        raise ValueError("LeakyReLU and ReLU are exclusive")
+    return _ffi.OP_LEAKY if leaky else (_ffi.OP_RELU if relu else 0)
+
+
+def conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=True, pool=False, device_id=0, relu=False):
+    """Operator-level fused layer (y355_conv3x3_i8_fused): numpy int8 NCHW in/out.  relu=True (with leaky=False):
+    the ReLU epilogue of Conv2d_fuse(leakyReLU=False) (utils/modules.py:26)."""
     lib = _ffi.lib()
     if not torch.cuda.is_available():
         raise RuntimeError("yolo355 needs a GPU; there is no CPU fallback")
@@ -305,15 +334,15 @@ def conv3x3_i8_fused(q_in, q_w, q_b, sa_in, e_w, e_b, sa_out, leaky=True, pool=F
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     out = np.empty((B, cout, Ho, Wo), np.int8)
     st = _ffi.LayerStats()
-    flags = (_ffi.OP_LEAKY if leaky else 0) | (_ffi.OP_POOL if pool else 0)
+    flags = _act_flag(leaky, relu) | (_ffi.OP_POOL if pool else 0)
     _ffi.check(lib.y355_conv3x3_i8_fused(int(device_id), qi.ctypes.data, qw.ctypes.data, qb.ctypes.data, B, cin, cout,
                                          H, W, int(sa_in), int(e_w), int(e_b), int(sa_out), flags,
                                          out.ctypes.data, C.byref(st)))
     return out, dict(absmax_t=st.absmax_t, frac_bits=st.frac_bits, saturated=st.saturated, guard=st.guard)
 
 
-def conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=True, device_id=0):
-    """conv + bias + LeakyReLU(0.125) without requantisation (y355_conv3x3_i8_raw):
+def conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=True, device_id=0, relu=False):
+    """conv + bias + LeakyReLU(0.125) (or ReLU, or nothing) without requantisation (y355_conv3x3_i8_raw):
     returns (t' int64 [B,cout,H,W], F') with value = t' / 2^F'."""
     lib = _ffi.lib()
     if not torch.cuda.is_available():
@@ -326,7 +355,7 @@ def conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=True, device_id=0):
     out = np.empty((B, cout, H, W), np.int64)
     fb = C.c_int32()
     _ffi.check(lib.y355_conv3x3_i8_raw(int(device_id), qi.ctypes.data, qw.ctypes.data, qb.ctypes.data, B, cin, cout,
-                                       H, W, int(sa_in), int(e_w), int(e_b), _ffi.OP_LEAKY if leaky else 0,
+                                       H, W, int(sa_in), int(e_w), int(e_b), _act_flag(leaky, relu),
                                        out.ctypes.data, C.byref(fb)))
     return out, fb.value
 

@@ -13,7 +13,10 @@ Same constructor, attributes, state_dict layout and eval-mode return as
 
 What runs where: parameters live in torch modules (checkpoint compatibility only); every
 forward goes through the C ABI into the HIP kernels.  There is no PyTorch compute path:
-`quantization=False` (fp32 math) and `trainable=True` (losses) raise NotImplementedError.
+`quantization=True` runs the int8 engine (y355_engine), the default `quantization=False`
+(the call of test.py:84 / demo.py:81 / utils/vocapi_evaluator.py:67: trackers are the identity,
+fp32 math on whatever weights are loaded) runs the same graph on the bf16 MFMA (y355_net);
+`trainable=True` (losses) raises NotImplementedError.
 """
 import numpy as np
 import torch
@@ -106,8 +109,17 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
             raise NotImplementedError("yolo355 is an inference engine: the training branch "
                                       "(models/slim_yolo_v2.py:360-382) is out of scope")
         if not quantization:
-            raise NotImplementedError("yolo355: quantization=False (fp32 math on the loaded weights) is not "
-                                      "built; the engine runs the int8 power-of-two quantized path")
+            # models/slim_yolo_v2.py:212-358 with the default kwarg: every tracker returns its input (:17-18), so the
+            # forward is conv + bias + LeakyReLU(0.125) / max-pool in fp32 on the loaded (possibly dyadic) weights; `find`
+            # divides by 2^r weights that were multiplied by 2^r (:222-227), which cancels up to fp32 rounding.
+            # Runs as the SlimYOLOv2 graph without BatchNorm on the bf16 MFMA (fp32 accumulation): tolerance parity.
+            net = self._get_f32_net(int(x.shape[0]), find)
+            net.set_thresholds(self.conf_thresh, self.nms_thresh)
+            dets = net.forward(x)
+            if sizes_wh is not None:                        # the evaluators' `bboxes *= scale` (utils/vocapi_evaluator.py:69-70)
+                wh = np.asarray(sizes_wh, np.float32).reshape(-1, 2)
+                dets = [(b * np.array([[w, h, w, h]], np.float32), s, c) for (b, s, c), (w, h) in zip(dets, wh)]
+            return dets
         eng = self._get_engine(int(x.shape[0]), find)
         trackers = self._tracker_states()
         freeze = not self.trainable
@@ -163,6 +175,30 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
             self._engine.set_retune(prep.RETUNE)
             self._loaded_version, self._loaded_find = ver, find
         return self._engine
+
+    def _get_f32_net(self, batch, find):
+        """y355_net (Y355_ARCH_SLIM_V2, bf16) loaded with this model's conv weights and biases as they are."""
+        key = (tuple(self.input_size), self.num_classes, tuple(map(tuple, self.anchor_size.tolist())))
+        st = self.__dict__.setdefault("_f32", dict(net=None, key=None, ver=None))
+        if st["net"] is None or st["key"] != key or st["net"].max_batch < batch:
+            if st["net"] is not None:
+                st["net"].close()
+            dev = self.device if isinstance(self.device, (str, torch.device)) else "cuda:0"
+            st["net"] = Net("slim_yolo_v2", self.input_size, self.num_classes, self.anchor_size.tolist(), self.conf_thresh,
+                            self.nms_thresh, max_batch=max(batch, 1), device=dev, dtype="bf16")
+            st["key"], st["ver"] = key, None
+        ver = (self._weights_version(), bool(find))
+        if st["ver"] != ver:
+            mods = [getattr(self, n).convs[0] for n in _CONVS] + [self.pred]
+            for i, m in enumerate(mods):
+                w = m.weight.detach().float().cpu().numpy()
+                b = m.bias.detach().float().cpu().numpy()
+                if find:                                    # the checkpoint holds W * 2^r, the forward divides by 2^r
+                    sc = np.float32(2.0 ** -prep.RETUNE[i])
+                    w, b = w * sc, b * sc
+                st["net"].load_layer(i, w, b)
+            st["ver"] = ver
+        return st["net"]
 
     def _tracker_states(self):
         return [prep.RangeTracker(getattr(self, n).scale, int(getattr(self, n).first_a.item())) for n in _TRACKERS]

@@ -133,8 +133,14 @@ class Net:
     def forward_device(self, xd, flags=0, out=None):
         B = xd.shape[0]
         ob, os_, oc, on = out if out is not None else self._buffers(B)
+        # stream ordering as in engine.Engine: kernels run on the stream current at construction
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self._stream:
+            self._stream.wait_stream(cur)
         _ffi.check(self._lib.y355_net_forward(self._h, xd.data_ptr(), B, int(flags), ob.data_ptr(), os_.data_ptr(),
                                               oc.data_ptr(), on.data_ptr()))
+        if cur != self._stream:
+            cur.wait_stream(self._stream)
         return ob, os_, oc, on
 
     def forward(self, x, tap=False):

@@ -38,8 +38,8 @@ class _FusedBase(nn.Module):
     def forward(self, x):
         from ..engine import conv3x3_i8_raw
         q_in, sa_in, q_w, e_w, q_b, e_b = _int8_operands(self, x)
-        t, frac = conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=self.leaky,
-                                 device_id=x.device.index if x.is_cuda else 0)
+        t, frac = conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=self.leaky, relu=not self.leaky,
+                                 device_id=x.device.index if x.is_cuda and x.device.index is not None else 0)
         y = torch.from_numpy(t.astype(np.float32) * np.float32(2.0 ** (-frac)))
         return y.to(x.device)
 
@@ -111,11 +111,6 @@ class Conv2d_fuse(_FusedBase):
             nn.Conv2d(in_channels, out_channels, ksize, stride=stride, padding=padding, dilation=dilation),
             nn.LeakyReLU(0.125, inplace=True) if leakyReLU else nn.ReLU(inplace=True))
 
-    def forward(self, x):
-        if not self.leaky:
-            raise NotImplementedError("yolo355: ReLU epilogue is not used by slim-YOLOv2 and not built")
-        return super().forward(x)
-
 
 class Conv2d_fuse_nobias(_FusedBase):
     """conv (no bias) + LeakyReLU(0.125)/ReLU (utils/modules.py:31-40)."""
@@ -126,11 +121,6 @@ class Conv2d_fuse_nobias(_FusedBase):
         self.convs = nn.Sequential(
             nn.Conv2d(in_channels, out_channels, ksize, stride=stride, padding=padding, dilation=dilation, bias=False),
             nn.LeakyReLU(0.125, inplace=True) if leakyReLU else nn.ReLU(inplace=True))
-
-    def forward(self, x):
-        if not self.leaky:
-            raise NotImplementedError("yolo355: ReLU epilogue is not used by slim-YOLOv2 and not built")
-        return super().forward(x)
 
 
 class reorg_layer(nn.Module):
