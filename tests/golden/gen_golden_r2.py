@@ -152,9 +152,51 @@ def gen_ema(ref, out):
     out["ema/meta"] = np.array(size + [classes, cfg["batch"]] + cfg["seeds"], np.int64)
 
 
+EVAL = dict(weights=dict(seed=2, pred_gain=400.0, obj_bias=-4.0), size=[240, 320], classes=20, seeds=[51, 52, 53, 54, 59],
+            sizes=[(640, 480), (500, 375), (333, 500), (1280, 720), (320, 240)], conf=0.1)
+
+
+def gen_evaluator(ref, out):
+    """The reference's own evaluator loop (utils/vocapi_evaluator_mask.py:49-82) on a stub dataset: a fresh (un-calibrated)
+    q_bf model, quantization=True; the first image calibrates the trackers, every image is forwarded alone, boxes are
+    rescaled on the host.  Stored: all_boxes[cls][image].  The mAP code behind it needs the dataset files and is skipped."""
+    import importlib
+    import tempfile
+    ev_mod = importlib.import_module("utils.vocapi_evaluator_mask")
+    cfg = EVAL
+    size, classes = cfg["size"], cfg["classes"]
+    x = np.concatenate([synth.make_images(s, 1, size[0], size[1], "blocks") for s in cfg["seeds"]])
+
+    class Stub:
+        def __len__(self):
+            return len(x)
+
+        def pull_item(self, i):
+            w, h = cfg["sizes"][i]
+            return torch.from_numpy(x[i]), None, h, w
+    model = G.build_q_model(ref, synth.make_weights(**cfg["weights"], num_classes=classes), classes, ref.config.ANCHOR_SIZE,
+                            size, cfg["conf"], ref.rbq)
+    ev = object.__new__(ev_mod.VOCAPIEvaluator_mask)          # __init__ opens the dataset files
+    ev.dataset, ev.labelmap, ev.device = Stub(), list(range(classes)), "cpu"
+    ev.output_dir = tempfile.mkdtemp()
+    ev.map = 0.0
+    ev.evaluate_detections = lambda boxes: None
+    with torch.no_grad():
+        ev.evaluate(model, quantization=True, find=False)
+    tot = 0
+    for j in range(classes):
+        for i in range(len(x)):
+            a = np.asarray(ev.all_boxes[j][i], np.float32).reshape(-1, 5)
+            out["eval/boxes/%d/%d" % (j, i)] = a
+            tot += len(a)
+    out["eval/meta"] = np.array(size + [classes] + cfg["seeds"], np.int64)
+    print("eval: %d detections over %d images" % (tot, len(x)))
+
+
 def main():
     ref = G.import_reference()
     out = {}
+    gen_evaluator(ref, out)
     gen_qf32(ref, out)
     gen_relu(ref, out)
     gen_base_transform(ref, out)

@@ -74,3 +74,25 @@ def _model(sd, H, W):
     m.load_state_dict(sd, strict=False)
     m.eval()
     return m
+
+
+@pytest.mark.gpu
+def test_prepare_multi_batch_calibration():
+    """--calib-batch N: the calibration loop of retune_bias_quantize.py:357-369 (EMA trackers over batches, stop after
+    more than `calib_images` images) == the oracle's trackers driven the same way on the same quantized weights."""
+    from yolo355.tools import prepare as P
+    H, W = 96, 160
+    layers, sd = _fp32_sd(2)
+    frames = synth.make_frames_u8(7, 7, H, W, "blocks")
+    qm, package, report = P.prepare(sd, 2, synth.ANCHOR_SIZE_MASK, [H, W], frames, calib_batch=2, calib_images=4)
+    folded = [(w.numpy(), b.numpy()) for w, b in P.fold_model(_model(sd, H, W))]
+    ql = O.quantize_layers([("l%d" % i, w, b) for i, (w, b) in enumerate(folded)])
+    x = synth.normalize_frames(frames)
+    tr = [O.RangeTracker() for _ in range(11)]
+    for i0 in (0, 2, 4):                                    # the third batch takes the count past 4: the loop stops after it
+        O.forward_backbone_int(x[i0:i0 + 2], ql, tr, quant_freeze=False, saturate=True, keep=False)
+    assert [int(v) for v in package["sa"]] == [t.exponent() for t in tr]
+    got = [float(getattr(qm, n).scale.item()) for n in ("a_tracker_in", "a_tracker3_2", "a_tracker_pred")]
+    ref = [float(tr[i].scale.item()) for i in (0, 4, 10)]
+    assert np.allclose(got, ref, rtol=1e-6, atol=0)
+    assert all(int(getattr(qm, "a_tracker%s" % s).first_a.item()) == 1 for s in ("_in", "1", "_pred"))

@@ -135,6 +135,22 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
             return eng.forward_scaled(x, sizes_wh, find=find)
         return eng.forward(x, find=find)
 
+    def calibrate(self, x, freeze=False, find=False):
+        """One calibration step on a batch, the tracker side of the reference's calibration loop
+        (retune_bias_quantize.py:357-369: `model(images, target, quantization=True)` in training mode, whose loss branch is
+        out of scope here): every AveragedRangeTracker sees max|activation| over the batch -- first call: scale =
+        127 / max; later calls: scale = 0.9 scale + 0.1 * 127 / max (models/slim_yolo_v2.py:25-31), or unchanged with
+        freeze=True -- layer by layer on the GPU, each layer running with the exponent just updated.  The buffers
+        `a_tracker*.scale / first_a` are updated in place (they travel in the state_dict).  Returns the 11 exponents.
+        The weights must already be power-of-two quantized (prep.quantize_layers): the reference's loop runs its first
+        batch on the un-quantized weights and quantizes afterwards, which moves the first scales by < 2 % (measured,
+        tests/test_round2.py) and none of the exponents of the goldens."""
+        eng = self._get_engine(int(x.shape[0]), find)
+        trackers = self._tracker_states()
+        sa = eng.calibrate(x, trackers, freeze=freeze)
+        self._store_trackers(trackers)
+        return sa
+
     def forward_frames(self, frames, find=False):
         """New: detections for camera frames, uint8 [B,H,W,3] BGR at the network size --
         BaseTransform + BGR->RGB + HWC->CHW (data/__init__.py:30-56, test.py:79) run inside the first

@@ -38,10 +38,12 @@ def fold_model(fp32_model, corrected=False):
 
 
 def prepare(state_dict, num_classes, anchor_size, input_size, calib, device="cuda:0", corrected_fold=False,
-            conf_thresh=0.01, nms_thresh=0.5):
+            conf_thresh=0.01, nms_thresh=0.5, calib_batch=0, calib_images=1000):
     """Returns (q_model, package dict, report list).  calib: fp32 NCHW tensor/array (already normalised) or
-    uint8 [B,H,W,3] BGR frames (normalised like BaseTransform); its FIRST image calibrates the trackers
-    (first-call rule, models/slim_yolo_v2.py:25-27)."""
+    uint8 [B,H,W,3] BGR frames (normalised like BaseTransform).  calib_batch = 0: its FIRST image calibrates the
+    trackers (first-call rule of an eval-mode model, models/slim_yolo_v2.py:25-27).  calib_batch = N > 0: the reference's
+    calibration loop (retune_bias_quantize.py:357-369): batches of N images, first batch sets every scale, every
+    further batch moves it by the EMA of :30-31, stop once more than `calib_images` images were seen (:365-367)."""
     fp = SlimYOLOv2(device, input_size=input_size, num_classes=num_classes, anchor_size=anchor_size)
     fp.load_state_dict(state_dict, strict=False)
     fp.eval()
@@ -61,8 +63,17 @@ def prepare(state_dict, num_classes, anchor_size, input_size, calib, device="cud
     x = np.asarray(calib)
     if x.dtype == np.uint8:
         x = synth.normalize_frames(x)
-    x = torch.from_numpy(np.ascontiguousarray(x[:1], dtype=np.float32))
-    qm(x, quantization=True)                               # first call: calibrates every tracker on the GPU
+    if calib_batch > 0:
+        seen = 0
+        for i0 in range(0, x.shape[0], calib_batch):
+            xb = torch.from_numpy(np.ascontiguousarray(x[i0:i0 + calib_batch], dtype=np.float32))
+            qm.calibrate(xb, freeze=False)
+            seen += xb.shape[0]
+            if seen > calib_images:                         # retune_bias_quantize.py:365-367
+                break
+    else:
+        x = torch.from_numpy(np.ascontiguousarray(x[:1], dtype=np.float32))
+        qm(x, quantization=True)                           # first call: calibrates every tracker on the GPU
     eng = qm._engine
     sa = eng.get_act_exponents()
     # head-room report: max |conv output| * 2^retune against 2^15 (retune_bias_quantize_findbest.py:122-141)
@@ -110,12 +121,17 @@ def main(argv=None):
     ap.add_argument("--anchors", default="mask", choices=sorted(ANCHORS))
     ap.add_argument("--size", type=int, nargs=2, default=[416, 416], metavar=("H", "W"))
     ap.add_argument("--calib", help=".npy with uint8 [B,H,W,3] BGR frames or fp32 [B,3,H,W]; default: a synthetic frame")
+    ap.add_argument("--calib-batch", type=int, default=0,
+                    help="N > 0: the reference's calibration loop (retune_bias_quantize.py:357-369) over the --calib file in "
+                         "batches of N (EMA trackers); 0: first image only (the eval-mode first-call rule)")
+    ap.add_argument("--calib-images", type=int, default=1000, help="stop the loop once more images than this were seen (:365)")
     ap.add_argument("--corrected-fold", action="store_true", help="exact BN fold instead of utils/bn_fuse.py's formula")
     ap.add_argument("--device", default="cuda:0")
     args = ap.parse_args(argv)
     sd = torch.load(args.weights, map_location="cpu")
     calib = np.load(args.calib) if args.calib else synth.make_frames_u8(1, 1, args.size[0], args.size[1], "blocks")
-    qm, package, report = prepare(sd, args.num_classes, ANCHORS[args.anchors], args.size, calib, args.device, args.corrected_fold)
+    qm, package, report = prepare(sd, args.num_classes, ANCHORS[args.anchors], args.size, calib, args.device, args.corrected_fold,
+                                  calib_batch=args.calib_batch, calib_images=args.calib_images)
     torch.save(qm.state_dict(), args.out + ".pth")
     np.savez_compressed(args.out + ".npz", **package)
     for r in report:

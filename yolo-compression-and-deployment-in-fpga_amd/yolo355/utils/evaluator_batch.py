@@ -20,19 +20,31 @@ def _batches(n, bs):
 
 
 def _run(net, x, sizes_wh, **kw):
+    """One batched forward with the evaluators' rescale.  Only the keyword arguments the model's forward_batch declares
+    are passed (decided from its signature, never by catching TypeError: an exception raised inside a forward must
+    surface); asking a model for `quantization=True` / `find=True` that it cannot honour is an error, not a silent
+    fp32 evaluation.  A q_bf model whose trackers are still un-calibrated is first run on image 0 alone: the
+    reference's per-image loop freezes every tracker on its first image (models/slim_yolo_v2.py:25-27), a batched
+    first call would calibrate on the maximum over the whole batch."""
+    import inspect
     if not hasattr(net, "forward_batch"):
         raise TypeError("evaluator batching needs a yolo355 model (forward_batch)")
-    try:
-        return net.forward_batch(x, sizes_wh=sizes_wh, **kw)
-    except TypeError:
-        # models without the fused rescale (the composed wider families): rescale like the reference, per image
-        out = net.forward_batch(x, **{k: v for k, v in kw.items() if k not in ("quantization", "find")})
-        res = []
-        for (b, s, c), (w, h) in zip(out, sizes_wh):
-            b = b.copy()
-            b *= np.array([[w, h, w, h]])
-            res.append((b, s, c))
-        return res
+    params = inspect.signature(net.forward_batch).parameters
+    for k in ("quantization", "find"):
+        if kw.get(k) and k not in params:
+            raise TypeError("%s.forward_batch does not take %s=True" % (type(net).__name__, k))
+    call = {k: v for k, v in kw.items() if k in params}
+    if call.get("quantization") and hasattr(net, "_tracker_states") and any(t.first_a == 0 for t in net._tracker_states()):
+        net.forward_batch(x[:1], **call)
+    if "sizes_wh" in params:
+        return net.forward_batch(x, sizes_wh=sizes_wh, **call)
+    # models without the fused rescale (the composed wider families): rescale like the reference, per image
+    res = []
+    for (b, s, c), (w, h) in zip(net.forward_batch(x, **call), sizes_wh):
+        b = b.copy()
+        b *= np.array([[w, h, w, h]])
+        res.append((b, s, c))
+    return res
 
 
 def voc_all_boxes(net, dataset, num_classes, batch_size=64, quantization=False, find=False, num_images=None):
