@@ -41,18 +41,22 @@ LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "co
 DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, false, false>"
 
 
+TRAFFIC_FILES = ["r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/, collected with
-    rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE runs at this workload); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            for name, v in json.load(f)["kernels"].items():
-                if kernel in name:
-                    return v["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """(HBM bytes per launch of `kernel`, source file) from the committed PMC passes (profiles/, collected with
+    rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE runs at this workload, scratch/pmc_traffic.sh); (None, None)
+    if absent.  The number is read from the committed file, not measured in this run."""
+    for fn in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                for name, v in json.load(f)["kernels"].items():
+                    if kernel in name:
+                        return v["hbm_bytes_per_launch"], "profiles/" + fn
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
 
 
 def quantized_layers(seed=2, **kw):
@@ -98,23 +102,44 @@ def sparse_fixture(args, dev, streams, x):
             "weights": "make_weights(2, pred_gain=400, obj_bias=-4)", "detections_per_step": int(out[3][:B].sum().item())}
 
 
-def cpu_baseline(n_images=256):
+def _omp_threads(n):
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
+def cpu_baseline(n_images=128):
     """The plain-C oracle (oracle/yolo_oracle.c: int8 direct conv + shifts + C head, OpenMP) timed on
     the host cores on a bounded sample of the same workload.  Checker code, used here only as the
-    reported baseline; its exponents come from the numpy oracle's first-call calibration."""
+    reported baseline; its exponents come from the numpy oracle's first-call calibration.
+    Returns (headline entry = all cores, batch 64; grid of SURVEY.md 8d: batch 1 / 64 x all cores / 1 core)."""
     from oracle import yolo_oracle as O
     from oracle import c_oracle
     ql = O.quantize_layers(synth.make_weights(2, num_classes=NUM_CLASSES))
     tr = [O.RangeTracker() for _ in range(11)]
     sa = O.detect(synth.make_images(1, 1, H, W), ql, tr, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES)["sa"]
     c_oracle.detect(synth.make_images(0, 1, H, W), ql, sa, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES)   # warm-up
-    x = synth.make_images(1000, n_images, H, W)
-    t0 = time.perf_counter()
-    c_oracle.detect(x, ql, sa, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES, 0.01, 0.5)
-    dt = time.perf_counter() - t0
-    return dict(value=round(n_images / dt, 2), unit="images/sec", cores=os.cpu_count(), kind="port",
-                sample="%d images (4 steps' worth), 416x416, whole path (conv1..pred, decode, NMS) through "
-                       "oracle/yolo_oracle.c with OpenMP, %.1f s" % (n_images, dt))
+    ncores = os.cpu_count()
+
+    def run(batch, calls, threads):
+        _omp_threads(threads)
+        x = synth.make_images(1000, batch, H, W)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            c_oracle.detect(x, ql, sa, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES, 0.01, 0.5)
+        dt = time.perf_counter() - t0
+        return dict(value=round(batch * calls / dt, 3), unit="images/sec", cores=threads, batch=batch,
+                    sample="%d call(s) of %d image(s), %.1f s" % (calls, batch, dt))
+    main = run(64, max(1, n_images // 64), ncores)
+    grid = {"c_b64_all_cores": main, "c_b1_all_cores": run(1, 4, ncores), "c_b1_1_core": run(1, 1, 1),
+            # one core at batch 64 would take minutes: a 4-image call on one thread measures the same per-image rate
+            "c_b64_1_core": dict(run(4, 1, 1), note="4-image sample of the batch-64 case (one thread: the rate per image is batch-independent)")}
+    _omp_threads(ncores)
+    head = dict(value=main["value"], unit="images/sec", cores=ncores, kind="port",
+                sample="%s, 416x416, whole path (conv1..pred, decode, NMS) through oracle/yolo_oracle.c with OpenMP" % main["sample"])
+    return head, grid
 
 
 # conv MMAC per image of YOLOv3tiny at 416x416, 20 classes (SURVEY.md 8d: 3090.17), graph order
@@ -134,11 +159,15 @@ V2_LAYERS = [(3, 32, 3, 416), (32, 64, 3, 208), (64, 128, 3, 104), (128, 64, 1, 
 def bench_net(args):
     """configs[2] (SlimYOLOv2 fp32 weights on bf16 MFMA, batch 64) and configs[3] (YOLOv3tiny int8 /
     bf16, batch 128) through the table-driven executor; one GPU."""
-    from yolo355.netengine import Net
     if args.workload == "yolo_v2_bf16":
         return bench_yolo_v2(args)
     if args.workload in ("yolo_v3_bf16", "yolo_v3_spp_bf16"):
         return bench_yolo_v3(args)
+    print(json.dumps(measure_net(args)))
+
+
+def measure_net(args):
+    from yolo355.netengine import Net
     arch = "slim_yolo_v2" if args.workload == "slim_fp32" else "tiny_yolo_v3"
     dtype = "int8" if args.workload == "tiny_int8" else "bf16"
     classes = 2 if arch == "slim_yolo_v2" else 20
@@ -185,7 +214,7 @@ def bench_net(args):
     peak = PEAK_I8_DENSE if dtype == "int8" else PEAK_BF16_DENSE
     op_ms = float(ms[:-2].sum())
     achieved = B * 2e6 * mmac / (op_ms * 1e-3) / 1e12
-    print(json.dumps({
+    return ({
         "metric": "images/sec %s %s 416x416" % (arch, "int8" if dtype == "int8" else "fp32 weights on bf16 MFMA"),
         "value": round(B * args.steps / dt, 1), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
@@ -196,7 +225,7 @@ def bench_net(args):
                      "frac": round(achieved * 1e12 / peak, 4), "traffic": None,
                      "kernel": "convg_kernel, all conv launches of the graph (%.1f MMAC/image)" % mmac,
                      "op_ms": [round(float(v), 4) for v in ms[:-2]], "head_ms": round(float(ms[-2]), 4),
-                     "nms_ms": round(float(ms[-1]), 4)}}))
+                     "nms_ms": round(float(ms[-1]), 4)}})
 
 
 def bench_yolo_v2(args):
@@ -325,18 +354,43 @@ def bench_yolo_v3(args):
 def cpu_baseline_torch(n_images=16):
     """the reference's PyTorch CPU route -- the same forward restated with stock torch CPU
     ops (oracle/yolo_oracle.py: conv2d on the fake-quantised operands, numpy NMS), pinned bit-equal to the
-    imported reference by tests/golden/e2e.npz.  Checker code, timed here only as a reported baseline."""
+    imported reference by tests/golden/e2e.npz.  Checker code, timed here only as a reported baseline.
+    Returns (all-cores batch-16 entry, grid with batch 1 on all cores and on one core)."""
     from oracle import yolo_oracle as O
     ql = O.quantize_layers(synth.make_weights(2, num_classes=NUM_CLASSES))
     tr = [O.RangeTracker() for _ in range(11)]
     O.detect(synth.make_images(1, 1, H, W), ql, tr, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES)
-    x = synth.make_images(1000, n_images, H, W)
-    t0 = time.perf_counter()
-    O.detect(x, ql, tr, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES, 0.01, 0.5)
-    dt = time.perf_counter() - t0
-    return dict(value=round(n_images / dt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample="%d images, 416x416, whole path through oracle/yolo_oracle.py (torch CPU conv2d + numpy "
-                       "head/NMS), %.1f s" % (n_images, dt))
+    nthr = torch.get_num_threads()
+
+    def run(batch, threads):
+        torch.set_num_threads(threads)
+        x = synth.make_images(1000, batch, H, W)
+        t0 = time.perf_counter()
+        O.detect(x, ql, tr, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES, 0.01, 0.5)
+        dt = time.perf_counter() - t0
+        return dict(value=round(batch / dt, 3), unit="images/sec", cores=threads, batch=batch, sample="%d image(s), %.1f s" % (batch, dt))
+    main = run(n_images, nthr)
+    grid = {"torch_b16_all_cores": main, "torch_b1_all_cores": run(1, nthr), "torch_b1_1_core": run(1, 1)}
+    torch.set_num_threads(nthr)
+    head = dict(value=main["value"], unit="images/sec", cores=nthr, kind="port",
+                sample="%s, 416x416, whole path through oracle/yolo_oracle.py (torch CPU conv2d + numpy head/NMS)" % main["sample"])
+    return head, grid
+
+
+def _spawn_torchrun(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the one-process-per-GPU job as a CHILD process
+    before this process touches the GPU (a process that has initialised HIP must never exec, and silently running on
+    one GPU while reporting N would be worse)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -344,9 +398,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="the timed region of EXACTLY --steps steps is run this many times; value = median (min / max reported)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the extra 'sparse fixture' measurement (SURVEY.md 8d)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[2] / configs[3] measurements")
     ap.add_argument("--no-fuse-front", action="store_true",
                     help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
@@ -361,6 +418,12 @@ def main():
         return bench_net(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if torch.cuda.device_count() < args.gpus:           # device_count() does not initialise the GPU on this image
+            sys.exit("bench.py: --gpus %d but %d GPU(s) are visible" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(_spawn_torchrun(args))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -370,7 +433,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     B = args.batch
 
-    # Two engine handles per GPU, each on its own HIP stream; steps alternate between them, so the
+    # Engine handles per GPU, each on its own HIP stream; steps alternate between them, so the
     # detection head / NMS of one batch (few, latency-bound workgroups) and the kernel-boundary
     # bubbles of one stream are filled by the convolutions of the next batch on the other stream.
     # Handles are independent by contract (include/yolo355.h); every step is still one whole pass
@@ -391,7 +454,8 @@ def main():
     # every rank gets the same 11 exponents
     sa = None
     if rank == 0:
-        sa = eng.calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
+        with torch.cuda.stream(streams[0]):
+            sa = eng.calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
     sa = shard.broadcast_exponents(sa, 0, dev)
     for e in engines:
         e.set_act_exponents(sa)
@@ -401,59 +465,82 @@ def main():
     frames = torch.from_numpy(synth.make_frames_u8(1000 + rank, B, H, W)).to(dev) if args.input == "u8" else None
     nbuf = 2 * nstreams
     bufs = [tuple(torch.empty_like(t) for t in eng._buffers(B)) for _ in range(nbuf)]
+    gsend = grecv = None
+    if world > 1:
+        rb = shard.record_bytes(eng.max_det)
+        gsend = [torch.empty((B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        grecv = [torch.empty((world * B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     torch.cuda.synchronize()
 
-    def step(i, pending):
+    def step(i, pending, ns):
         k = i % nbuf
         if world > 1 and pending[k] is not None:     # buffer reuse: its gather must be done
             for w in pending[k]:
                 w.wait()
-            streams[i % nstreams].wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(streams[i % nstreams]):      # the engine's own stream: no cross-stream waits are inserted
+            streams[i % ns].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(streams[i % ns]):      # the engine's own stream: no cross-stream waits are inserted
             if frames is not None:
-                out = engines[i % nstreams].forward_frames_device(frames, 0, bufs[k])
+                out = engines[i % ns].forward_frames_device(frames, 0, bufs[k])
             else:
-                out = engines[i % nstreams].forward_device(x, 0, bufs[k])
+                out = engines[i % ns].forward_device(x, 0, bufs[k])
         if world > 1:
-            torch.cuda.current_stream().wait_stream(streams[i % nstreams])
-            _g, works = shard.allgather_detections(*[t[:B] for t in out], async_op=True)
+            # one packed all-gather per batch, asynchronous: it overlaps the next batches' kernels
+            torch.cuda.current_stream().wait_stream(streams[i % ns])
+            _finish, works = shard.allgather_detections(*[t[:B] for t in out], async_op=True, send=gsend[k], recv=grecv[k])
             pending[k] = works
         return out
 
-    pending = [None] * nbuf
-    for i in range(args.warmup):
-        step(i, pending)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i, pending)
-    for p in pending:
-        if p is not None:
-            for w in p:
-                w.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(ns, steps, warmup, repeats):
+        """`repeats` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both
+        sides; per region the MAX over ranks.  Returns (list of seconds, last outputs)."""
+        pending = [None] * nbuf
+        out = None
+        for i in range(warmup):
+            out = step(i, pending, ns)
+        times = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                out = step(i, pending, ns)
+            for p in pending:
+                if p is not None:
+                    for w in p:
+                        w.wait()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            times.append(dt)
+        return times, out
+
+    reps = max(1, args.repeats)
+    times, out = timed(nstreams, args.steps, args.warmup, reps)
+    dt = float(np.median(times))
+    one = None
+    if nstreams > 1:
+        t1, _ = timed(1, args.steps, min(args.warmup, 5), max(3, reps // 3))
+        one = float(np.median(t1))
 
     # per-kernel device time with HIP events on the engine's stream (separate profiled steps)
     eng.profile(True)
     acc = np.zeros(12)
     nprof = max(5, min(args.steps, 20))
-    for i in range(nprof):
-        if frames is not None:
-            eng.forward_frames_device(frames, 0, bufs[0])
-        else:
-            eng.forward_device(x, 0, bufs[0])
-        acc += np.array(eng.profile_ms())
+    with torch.cuda.stream(streams[0]):
+        for i in range(nprof):
+            if frames is not None:
+                eng.forward_frames_device(frames, 0, bufs[0])
+            else:
+                eng.forward_device(x, 0, bufs[0])
+            acc += np.array(eng.profile_ms())
     eng.profile(False)
     layer_ms = acc / nprof
     ndet = int(out[3][:B].sum().item())
@@ -465,9 +552,18 @@ def main():
         achieved = B * OPS_PER_IMAGE / (conv_ms * 1e-3) / 1e12
         dom_ms = float(layer_ms[7] + layer_ms[8]) / 2
         dom_tops = B * 2e6 * LAYER_MMAC[7] / (dom_ms * 1e-3) / 1e12
-        layers = {n: dict(ms=round(float(layer_ms[i]), 4),
-                          tops=round(B * 2e6 * LAYER_MMAC[i] / (layer_ms[i] * 1e-3) / 1e12, 1))
-                  for i, n in enumerate(LAYER_NAMES)}
+        fused = not args.no_fuse_front and layer_ms[1] < 0.2 * layer_ms[0]     # slot 0 then holds conv1 + conv2 (one launch)
+        layers = {}
+        for i, n in enumerate(LAYER_NAMES):
+            if fused and i == 0:
+                layers["conv1+conv2 (fused front end)"] = dict(
+                    ms=round(float(layer_ms[0] + layer_ms[1]), 4),
+                    tops=round(B * 2e6 * (LAYER_MMAC[0] + LAYER_MMAC[1]) / ((layer_ms[0] + layer_ms[1]) * 1e-3) / 1e12, 1))
+            elif fused and i == 1:
+                continue
+            else:
+                layers[n] = dict(ms=round(float(layer_ms[i]), 4), tops=round(B * 2e6 * LAYER_MMAC[i] / (layer_ms[i] * 1e-3) / 1e12, 1))
+        traffic, traffic_src = pmc_traffic(DOMINANT_KERNEL)
         res = {
             "metric": "images/sec slim_yolo_v2 int8 416x416", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -477,9 +573,15 @@ def main():
                        "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
                        "streams_per_gpu": nstreams, "input": args.input,
                        "detections_per_step_rank0": ndet},
+            # the timed region (exactly `steps` steps between barrier + synchronize) was run `repeats` times: value and
+            # ms_per_step are the MEDIAN region; with 3 engine handles ms_per_step is a throughput period, not a latency
+            "timing": {"repeats": reps, "ms_per_step_min": round(min(times) / args.steps * 1e3, 4),
+                       "ms_per_step_max": round(max(times) / args.steps * 1e3, 4),
+                       "value_min": round(world * B * args.steps / max(times), 1),
+                       "value_max": round(world * B * args.steps / min(times), 1)},
             "roofline": {"bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": round(dom_tops * 1e12 / PEAK_I8_DENSE, 4),
-                         "traffic": pmc_traffic(DOMINANT_KERNEL),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": DOMINANT_KERNEL + " (conv6 and conv7: 2 launches/step, the largest share of "
                                    "the step of any kernel; int8 ops = 2 x 398.72e6 MAC x %d images per launch)" % B,
                          "launch_ms": round(dom_ms, 4),
@@ -493,11 +595,31 @@ def main():
                          "layers": layers,
                          "head_ms": round(float(layer_ms[10]), 4), "nms_ms": round(float(layer_ms[11]), 4)},
         }
+        if one is not None:
+            v1 = world * B * args.steps / one
+            res["one_stream"] = {"value": round(v1, 1), "unit": "images/sec", "ms_per_step": round(one / args.steps * 1e3, 4),
+                                 "whole_path_frac": round(v1 / world * OPS_PER_IMAGE / PEAK_I8_DENSE, 4),
+                                 "note": "one engine handle on one stream: ms_per_step is the latency of a batch"}
         if world == 1 and not args.no_sparse:
             res["sparse_fixture"] = sparse_fixture(args, dev, streams, x)
+        if world == 1 and not args.no_other_configs:
+            # BASELINE.json configs[2] / configs[3], a few steps each: a driver-visible number for them
+            import copy
+            oc = {}
+            for wl in ("slim_fp32", "tiny_int8"):
+                a2 = copy.copy(args)
+                a2.workload, a2.steps, a2.warmup, a2.batch = wl, min(args.steps, 10), 3, PER_GPU_BATCH
+                r = measure_net(a2)
+                oc[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "images/sec",
+                          "ms_per_step": r["ms_per_step"], "steps": r["steps"], "dtype": r["dtype"],
+                          "conv_roofline_frac": r["roofline"]["frac"], "conv_achieved_tflops": r["roofline"]["achieved"],
+                          "peak_tflops": r["roofline"]["peak"]}
+            res["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
-            res["cpu_baseline_pytorch"] = cpu_baseline_torch()
+            res["cpu_baseline"], grid = cpu_baseline()
+            res["cpu_baseline_pytorch"], grid2 = cpu_baseline_torch()
+            grid.update(grid2)
+            res["cpu_baseline_grid"] = grid
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

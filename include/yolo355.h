@@ -202,6 +202,32 @@ int y355_head_f32(int device_id, int nlev, const float *const *pred, const int *
 int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred,
                   float *boxes, float *scores, int32_t *cls, int32_t *count);
 
+/* --- multi-GPU exchange: the batch is sharded over the GPUs of one node (one process per GPU, rank r owns a
+ * contiguous range of images, weights replicated, no collective on the data path).  The only exchange is ONE RCCL
+ * all-gather per batch of the padded detections, packed into one buffer of fixed-size records:
+ *   record = i32 count (-1: padding record of a ragged shard), i32 pad[3], f32 boxes[max_det][4], f32 scores[max_det],
+ *            i32 cls[max_det], rounded up to 16 bytes = y355_packed_det_bytes(max_det); entries past `count` are zero.
+ * The reference has no multi-GPU code; these are the entry points a multi-process host binds.  RCCL is bound at run time
+ * (the copy already loaded in the process, e.g. PyTorch's, is reused).
+ *   y355_comm_unique_id   rank 0 makes the 128-byte id and ships it to the other ranks by any host channel
+ *   y355_comm_init        every rank, after hipSetDevice-able device_id is known; collective
+ *   y355_pack_dets        outputs of y355_forward (batch images) -> `records` >= batch records (the extra ones count -1)
+ *   y355_allgather_dets   recv holds world * records records in rank order = global image order; asynchronous on `stream`
+ *   y355_unpack_dets      records -> padded arrays: record r goes to row slot[r] (slot[r] < 0: dropped) */
+typedef struct y355_comm y355_comm;
+#define Y355_COMM_ID_BYTES 128
+size_t y355_packed_det_bytes(int max_det);
+int y355_comm_unique_id(void *id_out /*[Y355_COMM_ID_BYTES]*/);
+int y355_comm_init(y355_comm **out, int world, int rank, const void *id, int device_id);
+void y355_comm_destroy(y355_comm *c);
+int y355_comm_world(y355_comm *c);
+int y355_comm_rank(y355_comm *c);
+int y355_pack_dets(const float *boxes_dev, const float *scores_dev, const int32_t *cls_dev, const int32_t *count_dev,
+                   int batch, int records, int max_det, void *packed_dev, void *stream);
+int y355_allgather_dets(y355_comm *c, const void *packed_send_dev, void *packed_recv_dev, int records, int max_det, void *stream);
+int y355_unpack_dets(const void *packed_dev, const int32_t *slot_dev, int records, int max_det, float *boxes_dev,
+                     float *scores_dev, int32_t *cls_dev, int32_t *count_dev, void *stream);
+
 /* --- measurement helpers: HIP events on the engine's stream ------------------------------ */
 int y355_sync(y355_engine *h);
 /* per-kernel device time of the last forward run with profiling enabled (ms);

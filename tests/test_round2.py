@@ -326,3 +326,55 @@ def test_config4_full_batch_tiny_int8():
     assert fr >= 0.6 and fg >= 0.6, "int8 tiny vs the reference's fp32 detections: matched %.3f / %.3f" % (fr, fg)
     assert abs(len(dets[0][1]) - len(gref[1])) <= 0.15 * len(gref[1])
     net.close()
+
+
+@pytest.mark.gpu
+def test_gather_of_real_engine_output_world1():
+    """SURVEY.md 8e check "gathered detections equal the single-GPU run bit for bit" with what one GPU allows: the real
+    engine's padded outputs through (a) shard.allgather_detections under the nccl (= RCCL) backend with world size 1 and
+    (b) the C ABI route (y355_comm_init / y355_pack_dets / y355_allgather_dets / y355_unpack_dets); ragged case: the
+    global batch is smaller than the engine's padded batch."""
+    import socket
+    import torch.distributed as dist
+    from yolo355 import shard
+    from yolo355.engine import Engine
+    dev = torch.device("cuda", 0)
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2, pred_gain=400.0, obj_bias=-4.0))
+    eng = Engine([96, 160], 2, synth.ANCHOR_SIZE_MASK, conf_thresh=0.05, max_batch=3, device=dev)
+    eng.load_quantized(ql)
+    x = synth.make_images(3, 3, 96, 160, "blocks")
+    eng.calibrate(x[:1], [prep.RangeTracker() for _ in range(11)])
+    direct = eng.forward(x)
+    ob, os_, oc, on = eng.forward_device(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    assert int(on[:3].sum()) > 0
+
+    def check(g):
+        got = shard.unpack(*g)
+        assert len(got) == 3
+        for a, b in zip(direct, got):
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        check(shard.allgather_detections(ob[:3], os_[:3], oc[:3], on[:3]))
+        finish, works = shard.allgather_detections(ob[:3], os_[:3], oc[:3], on[:3], async_op=True)
+        for w in works:
+            w.wait()
+        check(finish())
+        rg = shard.RcclGather(1, 0, dev)
+        g = rg.allgather(ob[:3], os_[:3], oc[:3], on[:3])
+        torch.cuda.synchronize()
+        check(g)
+        # the C pack kernel and the torch pack produce the same bytes
+        rec_t = shard.pack_detections(ob[:3], os_[:3], oc[:3], on[:3], records=4)
+        assert torch.equal(rg._keep[0], rec_t[:3])
+        rg.close()
+    finally:
+        dist.destroy_process_group()
+    eng.close()

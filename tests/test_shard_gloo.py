@@ -46,10 +46,21 @@ def _worker(rank, world, port, global_batch, max_det, q):
         cls = torch.from_numpy(np.stack([p[2] for p in per]))
         count = torch.tensor([p[3] for p in per], dtype=torch.int32)
         sa = shard.broadcast_exponents([5, 5, 6, 7, 8, 8, 10, 10, 11, 11, 4] if rank == 0 else None, 0)
-        (gb, gs, gc, gn), works = shard.allgather_detections(boxes, scores, cls, count, async_op=True)
+        # ONE collective per batch: the four tensors travel packed in one buffer of fixed-size records
+        calls = []
+        orig = dist.all_gather_into_tensor
+
+        def counting(*a, **k):
+            calls.append(1)
+            return orig(*a, **k)
+        dist.all_gather_into_tensor = counting
+        finish, works = shard.allgather_detections(boxes, scores, cls, count, global_batch=global_batch, async_op=True)
+        dist.all_gather_into_tensor = orig
         for w in works:
             w.wait()
+        gb, gs, gc, gn = finish()
         dets = shard.unpack(gb, gs, gc, gn)
+        assert len(calls) == 1 and len(works) == 1
         ok = sa == [5, 5, 6, 7, 8, 8, 10, 10, 11, 11, 4] and len(dets) == global_batch
         for i in range(global_batch):
             b, s, c, n = _fake_dets(i, max_det)
@@ -69,9 +80,33 @@ def test_shard_range_partitions_the_batch():
     assert shard.shard_range(512, 8, 3) == (192, 256)        # rank r gets images [64r, 64r+64)
 
 
+def test_pack_unpack_roundtrip_and_record_layout():
+    """the wire format of include/yolo355.h ("multi-GPU exchange"): 16-byte header + boxes + scores + cls, rounded up to
+    16 bytes; entries past count zeroed; padding records carry count -1 and are dropped"""
+    for md in (16, 7):
+        per = [_fake_dets(i, md) for i in range(3)]
+        boxes = torch.from_numpy(np.stack([p[0] for p in per]))
+        scores = torch.from_numpy(np.stack([p[1] for p in per]))
+        cls = torch.from_numpy(np.stack([p[2] for p in per]))
+        count = torch.tensor([p[3] for p in per], dtype=torch.int32)
+        scores[0, per[0][3]:] = 9.0                          # garbage past count must not travel
+        rec = shard.pack_detections(boxes, scores, cls, count, records=5)
+        assert rec.shape == (5, shard.record_bytes(md)) and shard.record_bytes(md) % 16 == 0
+        assert shard.record_bytes(16) == 16 + 24 * 16 and shard.record_bytes(7) == 16 + 176
+        r32 = rec.view(torch.int32)
+        assert r32[:, 0].tolist() == [per[0][3], per[1][3], per[2][3], -1, -1] and int(r32[:, 1:4].abs().sum()) == 0
+        b, s, c, n = shard.unpack_records(rec, md, 3)
+        assert n.tolist() == [p[3] for p in per]
+        for i, p in enumerate(per):
+            assert np.array_equal(b[i].numpy()[:p[3]], p[0][:p[3]]) and np.array_equal(s[i].numpy()[:p[3]], p[1][:p[3]])
+            assert np.array_equal(c[i].numpy()[:p[3]], p[2][:p[3]]) and float(s[i, p[3]:].abs().sum()) == 0.0
+
+
 @pytest.mark.timeout(300)
-def test_allgather_of_padded_detections_world2():
-    world, gbatch, max_det = 2, 8, 16
+@pytest.mark.parametrize("gbatch", [8, 7])
+def test_allgather_of_padded_detections_world2(gbatch):
+    """world 2, gloo; gbatch 7 = ragged shards (4 + 3 images: the short rank sends a padding record)"""
+    world, max_det = 2, 16
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -98,6 +98,15 @@ _SIGS = {
     "y355_debug_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "y355_debug_nms_stamps": (C.c_int, [C.c_void_p]),
     "y355_head_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_packed_det_bytes": (C.c_size_t, [C.c_int]),
+    "y355_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "y355_comm_init": (C.c_int, [P(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "y355_comm_destroy": (None, [C.c_void_p]),
+    "y355_comm_world": (C.c_int, [C.c_void_p]),
+    "y355_comm_rank": (C.c_int, [C.c_void_p]),
+    "y355_pack_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "y355_allgather_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "y355_unpack_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y355_sync": (C.c_int, [C.c_void_p]),
     "y355_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "y355_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
