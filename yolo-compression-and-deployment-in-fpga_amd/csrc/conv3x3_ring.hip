@@ -675,8 +675,10 @@ struct RSet {
         if (!e) e = C5::prepare();
         if (!e) e = C67::prepare();
         if (!e) e = PRED::prepare();
+#ifdef Y355_EXPERIMENTS
         if (!e) e = C67H::prepare();
         if (!e) e = C5H::prepare();
+#endif
         return e;
     }
     static bool launch(int kid, const ConvParams &p, hipStream_t s) {
@@ -685,13 +687,17 @@ struct RSet {
         case Y355_K_CONV4_1: return C4_1::launch(p, s);
         case Y355_K_CONV4_2: return C4_2::launch(p, s);
         case Y355_K_CONV5: {
+#ifdef Y355_EXPERIMENTS
             static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
             if (half & 2) return C5H::launch(p, s, 512, half >> 8);
+#endif
             return C5::launch(p, s);
         }
         case Y355_K_CONV67: {
+#ifdef Y355_EXPERIMENTS
             static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
             if (half & 1) return C67H::launch(p, s, 512, half >> 8);
+#endif
             return C67::launch(p, s);
         }
         case Y355_K_PRED: return PRED::launch(p, s);

@@ -493,8 +493,12 @@ struct ConvInst2 {
     static constexpr int SROWS = POOL ? ((MTT + WM - 1) / WM) * WM * 4 : ((MTT + WM - 1) / WM) * WM * 16;
     static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(WRES ? G::KS : 4) * WB + 1024 + (size_t)SROWS * (BN + 16);
     static size_t lds_launch() {
+#ifdef Y355_EXPERIMENTS
         static const bool solo = getenv("Y355_V2_SOLO") != nullptr;       // experiment: one workgroup per CU
         return (solo && LDS < 84 * 1024) ? 84 * 1024 : LDS;
+#else
+        return LDS;
+#endif
     }
     static int prepare() {
         return (int)hipFuncSetAttribute((const void *)conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>,
@@ -527,15 +531,20 @@ using V2_CONV5 = ConvInst2<128, 128, 13, 26, false, 4, 2, false>;
 using V2_CONV67 = ConvInst2<256, 128, 13, 26, false, 4, 2, false>;
 using V2_PRED = ConvInst2<256, 64, 13, 13, false, 8, 1, false>;
 
+// The production library uses this file for the two thin layers only (conv2, conv3_1: resident weights); the deep layers
+// run conv3x3_ring.hip.  Their instantiations here are the fallbacks of the experiment builds (Y355_NO_RING_MASK); two of
+// them spill registers, which the counted waits do not allow (check_kernels.py), so they are not even compiled by default.
 int y355_prepare_conv_v2(void) {
     int e = V2_CONV2::prepare();
     if (!e) e = V2_CONV3_1::prepare();
+#ifdef Y355_EXPERIMENTS
     if (!e) e = V2_CONV3_2::prepare();
     if (!e) e = V2_CONV4_1::prepare();
     if (!e) e = V2_CONV4_2::prepare();
     if (!e) e = V2_CONV5::prepare();
     if (!e) e = V2_CONV67::prepare();
     if (!e) e = V2_PRED::prepare();
+#endif
     return e;
 }
 
@@ -544,12 +553,14 @@ bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s) {
     switch (kid) {
     case Y355_K_CONV2: return V2_CONV2::launch(p, s);
     case Y355_K_CONV3_1: return V2_CONV3_1::launch(p, s);
+#ifdef Y355_EXPERIMENTS
     case Y355_K_CONV3_2: return V2_CONV3_2::launch(p, s);
     case Y355_K_CONV4_1: return V2_CONV4_1::launch(p, s);
     case Y355_K_CONV4_2: return V2_CONV4_2::launch(p, s);
     case Y355_K_CONV5: return V2_CONV5::launch(p, s);
     case Y355_K_CONV67: return V2_CONV67::launch(p, s);
     case Y355_K_PRED: return V2_PRED::launch(p, s);
+#endif
     default: return false;
     }
 }

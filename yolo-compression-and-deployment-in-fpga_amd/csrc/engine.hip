@@ -442,6 +442,9 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.rq = L.rq;
         p.mode = mode;
         p.guard = guard;
+        // kernel-selection switches of the experiment builds (make EXTRA=-DY355_EXPERIMENTS); the default library has one
+        // fixed kernel per layer and reads no environment variable
+#ifdef Y355_EXPERIMENTS
         static const bool no_v2 = getenv("Y355_NO_V2") != nullptr;
         static const int v2dbg = getenv("Y355_V2_DBG") ? atoi(getenv("Y355_V2_DBG")) : 0;
         if (mode == 0) p.mode |= v2dbg << 8;
@@ -449,6 +452,10 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         if (mode == 0 && fine) p.mode |= 1 << 16;
         static const int no_v2_mask = getenv("Y355_NO_V2_MASK") ? atoi(getenv("Y355_NO_V2_MASK")) : 0;
         static const int no_ring_mask = getenv("Y355_NO_RING_MASK") ? atoi(getenv("Y355_NO_RING_MASK")) : 0;
+#else
+        constexpr bool no_v2 = false;
+        constexpr int no_v2_mask = 0, no_ring_mask = 0;
+#endif
         if (!no_v2 && !((no_ring_mask >> k) & 1) && y355_launch_conv_ring(L.kid, p, h->stream)) {
             HIPCHK(hipGetLastError());
             return 0;
@@ -616,7 +623,11 @@ extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int f
         if (int rc = refresh_layer(h, k, true)) return rc;
     }
     const bool prof = h->profile != 0;
-    static const bool use_graph = getenv("Y355_GRAPH") != nullptr;
+#ifdef Y355_EXPERIMENTS
+    static const bool use_graph = getenv("Y355_GRAPH") != nullptr;     // hipGraph replay of the launches: measured, no gain
+#else
+    constexpr bool use_graph = false;
+#endif
     if (!use_graph || prof) return enqueue_forward(h, x_dev, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, prof);
     // ---- the 14 launches of a step replayed as one hipGraph (same pointers, batch, thresholds)
     if (changed) {

@@ -739,7 +739,11 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     wk.tiny = (int *)ws.tiny;
     wk.ntiny = (int *)ws.ntiny;
     static unsigned long long *g_stamps = nullptr;
+#ifdef Y355_EXPERIMENTS
     static const bool want = getenv("Y355_NMS_STAMPS") != nullptr;
+#else
+    constexpr bool want = false;
+#endif
     if (want && !g_stamps) {
         if (hipMalloc((void **)&g_stamps, 8 * 8 * 256 * 4) != hipSuccess) g_stamps = nullptr;
         else (void)hipMemset(g_stamps, 0, 8 * 8 * 256 * 4);
