@@ -105,6 +105,7 @@ def test_end_to_end(golden, tag):
         assert np.array_equal(got, r["maps"][li].astype(np.int8)), (tag, li)
         assert crc(got) == int(golden[tag + "/calib/map_crc/%d" % (li + 1)][0]), (tag, li)
     assert np.array_equal(eng.get_feature(9, 1), golden[tag + "/calib/pred_q"])
+    modes = []
     for ci, conf in enumerate(confs):
         eng.set_thresholds(conf, 0.5)
         dets = eng.forward(xc, find=(tag == "find"), tap=True)
@@ -120,6 +121,9 @@ def test_end_to_end(golden, tag):
         ob, os_, oc, _ = O.postprocess(r["box"][0], r["cls_scores"][0], conf, 0.5, C)
         ok, msg = dets_match((ob, os_, oc), dets[0], BOX_TOL, SCORE_TOL, all_scores=r["cls_scores"][0].max(1))
         assert ok, (tag, conf, "vs oracle", msg)
+        modes.append(msg.split(":")[0])
+        # the oracle orders ties like the engine (score desc, anchor index asc): on the tie-free fixture the lists are identical
+        assert tag != "diverse" or msg == "exact", (tag, conf, msg)
     # frozen trackers, whole batch at once == the reference run one image at a time (G7)
     eng.set_thresholds(confs[0], 0.5)
     xs = np.concatenate([synth.make_images(s, 1, H, W, pattern) for s in img_seeds])
@@ -134,6 +138,8 @@ def test_end_to_end(golden, tag):
             assert ok, (tag, si, msg)
         ok, msg = dets_match(rb["dets"][si][:3], dets[si], BOX_TOL, SCORE_TOL, all_scores=rb["cls_scores"][si].max(1))
         assert ok, (tag, si, "vs oracle", msg)
+        modes.append(msg.split(":")[0])
+    print("%s: comparison modes vs the oracle: %s" % (tag, modes))       # pytest -s / -rP shows how many were exact
     eng.close()
 
 
