@@ -302,10 +302,11 @@ struct ConvInst {
     }
 };
 
+// conv3_1's tile (shared with conv3x3_v2.hip through y355_common.h: the weight packing depends on WN)
 static const ConvKernelInfo g_kernels[Y355_K_COUNT] = {
     //        CIN  BN  TH  TW  POOL  WM WN      tuned for 416x416
     ConvInst<16, 32, 16, 52, true, 4, 1>::info(),     // conv2    208x208
-    ConvInst<32, 64, 13, 26, false, 2, 2>::info(),    // conv3_1  104x104
+    ConvInst<32, 64, Y355_C31_TH, Y355_C31_TW, false, Y355_C31_GWM, Y355_C31_WN>::info(),    // conv3_1  104x104
     ConvInst<64, 64, 26, 26, true, 4, 1>::info(),     // conv3_2  104x104
     ConvInst<64, 128, 13, 26, false, 2, 2>::info(),   // conv4_1  52x52
     ConvInst<128, 64, 26, 26, true, 4, 1>::info(),    // conv4_2  52x52

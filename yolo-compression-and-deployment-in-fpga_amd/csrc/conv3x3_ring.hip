@@ -26,6 +26,9 @@
 #ifndef Y355_ABL
 #define Y355_ABL 0               // timing ablations (WRONG RESULTS): 1 no A reads, 2 no B reads, 4 no refill DMAs, 8 no barriers
 #endif
+#ifndef Y355_RING_YSWZ
+#define Y355_RING_YSWZ 0         // 1: row-dependent chunk swizzle for the pooled (window-ordered) tiles: measured, no gain (profiles/r02_notes.md)
+#endif
 #ifndef Y355_RING_DMA_AT2
 #define Y355_RING_DMA_AT2 -2     // >= 0: the younger half of the workgroup (waves NW/2..) refills after this m-tile instead
 #endif
@@ -171,7 +174,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
     constexpr int PSTEP = NW * 16 / PWL;
     const int pix0 = wave * 16 + (lane >> 2);
     const int ppy0 = pix0 / PWL, ppx0 = min(pix0 % PWL, PW - 1);     // pitch padding re-reads column PW-1
-    const int pwithin = ((lane & 3) ^ ((lane >> 3) & 3)) << 4;
+    // Pooled (2x2-window ordered) tiles: chunk ^ (((x >> 1) + 2 y) & 3).  With the x-only swizzle an A-fragment read of a
+    // window-ordered m-tile costs 8.56 LDS cycles (4 = conflict-free; scratch/bank_sim_ring.py reproduces the measured
+    // 39 % conflict share); adding 2 y brings it to 4.84.  Rows one apart then differ in address bit 5: the three taps of
+    // the middle filter row read at (base ^ 32), everything else is unchanged.
+    constexpr bool YSWZ = POOL && Y355_RING_YSWZ;
+    static_assert(!YSWZ || (PWL % 16 == 0 && PSTEP % 2 == 0), "a 16-pixel DMA piece stays inside one patch row; pieces step an even number of rows");
+    const int pwithin = ((lane & 3) ^ ((((lane >> 3) & 3) + (YSWZ ? 2 * ppy0 : 0)) & 3)) << 4;
     auto decode = [&](int tile, int &b, int &y0, int &x0, int &nb) {
         nb = tile % p.nblk;
         tile /= p.nblk;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
         }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
-            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ (((ox + dx) >> 1) & 3)) << 4);
+            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ ((((ox + dx) >> 1) + (YSWZ ? 2 * oy : 0)) & 3)) << 4);
     }
     const Requant rq = p.rq;
     unsigned int nsat = 0;
@@ -358,9 +367,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                 v4i af[MT];
                 wq = wrap(wq + 1);
                 if constexpr (Y355_RING_AORDER == 0) {
+                    const int yx = (YSWZ && t / 3 == 1) ? 32 : 0;              // middle filter row of a y-swizzled slab
+                    const int yx2 = (YSWZ && (t + 1) / 3 == 1) ? 32 : 0;
                     if (t == 0 && (!(Y355_ABL & 1) || c == 0)) {
-                        af[0] = *(const v4i *)(smem + abase[0][acol] + soff + ko);
-                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + abase[1][acol] + soff + ko);
+                        af[0] = *(const v4i *)(smem + (abase[0][acol] ^ yx) + soff + ko);
+                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + (abase[1][acol] ^ yx) + soff + ko);
                     } else {
                         af[0] = afp[0];
                         if constexpr (MT > 1) af[1] = afp[1];
@@ -382,12 +393,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        if (!(Y355_ABL & 1) && m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
+                        if (!(Y355_ABL & 1) && m + 2 < MT) af[m + 2] = *(const v4i *)(smem + (abase[m + 2][acol] ^ yx) + soff + ko);
                         if (!(Y355_ABL & 1) && m == MT - 1 && t + 1 < SPC) {   // next step's first A fragments (same slab)
                             const int ko2 = ((t + 1) / 3) * PWL * 64;
                             const int acol2 = (t + 1) % 3;
-                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
-                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                            afp[0] = *(const v4i *)(smem + (abase[0][acol2] ^ yx2) + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + (abase[1][acol2] ^ yx2) + soff + ko2);
                         }
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
@@ -417,6 +428,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                     // then the next step's first two A fragments -- and every m-tile waits (counted, LDS returns
                     // in order) only for its own fragment.
                     static_assert(Y355_RING_AORDER == 0 || MT == 6 || MT == 2, "hand-placed step: 6 or 2 m-tiles");
+                    static_assert(Y355_RING_AORDER == 0 || !YSWZ, "the hand-placed step does not implement the row swizzle");
                     const bool has_b = s_idx + 1 < KS;
                     const bool has_a = t + 1 < SPC;
                     unsigned abs_off = (unsigned)(soff + ko);

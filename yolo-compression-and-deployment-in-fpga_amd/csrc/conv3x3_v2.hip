@@ -25,6 +25,9 @@
 #ifndef Y355_DIAG
 #define Y355_DIAG 0
 #endif
+#ifndef Y355_C32_WRES
+#define Y355_C32_WRES 0          // 1: conv3_2 on the resident-weight kernel of this file instead of conv3x3_ring.hip (measured: 37.0 vs 35.0 us, not used)
+#endif
 #ifndef Y355_SLAB_AUX
 #define Y355_SLAB_AUX 2
 #endif
@@ -107,7 +110,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
     constexpr int WSLOTS = WRES ? KS : 4;
     constexpr int OFF_W = 2 * SLABB;
     constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;                 // 1 KiB sink for padding pieces
-    constexpr int OFF_STG = OFF_DUMMY + 1024;                      // int8 output tile, row-major
+    // int8 output tile, row-major.  Resident-weight kernels of 64-channel layers (two 57 KiB slab slots + the layer's
+    // weights) have no room for a staging buffer of their own: they stage through the slab slot of the tile that just
+    // finished (one extra barrier per tile: every wave's last A-fragment read must have returned first)
+    constexpr bool STG_ALIAS = WRES && CC == 64;
+    constexpr int OFF_STG = OFF_DUMMY + 1024;
     // staged rows (pixels / windows): POOL ? MT * WM * 4 : MT * WM * 16 -- sized by the launcher (ConvInst2::SROWS)
     constexpr int SSTR = BN + 16;                                  // bytes per staged row (+pad)
     constexpr int OROWS = POOL ? BM / 4 : BM;                      // real rows of a tile
@@ -388,7 +395,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
             int bias[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) bias[t] = p.bias_t[nb * BN + ncol + t];
-            char *stg = smem + OFF_STG;
+            char *stg = STG_ALIAS ? smem + (sl ^ 1) * SLABB : smem + OFF_STG;       // `sl` already points at the next tile's slot
+            if constexpr (STG_ALIAS) {
+                static_assert(!STG_ALIAS || (POOL ? MT * WM * 4 : MT * WM * 16) * SSTR <= SLABB, "the staged tile fits a slab slot");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             // sh_l (a left requant shift; sh_r = 0 then) folded into the accumulator shift and the bias;
             // saturation is detected with one v_xad per output and counted exactly only when it happened
             const int shl2 = rq.shl + rq.sh_l;
@@ -491,7 +503,8 @@ struct ConvInst2 {
     static constexpr int WB = (BN / 16) * 1024;
     static constexpr int MTT = (TH * TW + 15) / 16;
     static constexpr int SROWS = POOL ? ((MTT + WM - 1) / WM) * WM * 4 : ((MTT + WM - 1) / WM) * WM * 16;
-    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(WRES ? G::KS : 4) * WB + 1024 + (size_t)SROWS * (BN + 16);
+    static constexpr bool STG_ALIAS = WRES && G::CC == 64;
+    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(WRES ? G::KS : 4) * WB + 1024 + (STG_ALIAS ? 0 : (size_t)SROWS * (BN + 16));
     static size_t lds_launch() {
 #ifdef Y355_EXPERIMENTS
         static const bool solo = getenv("Y355_V2_SOLO") != nullptr;       // experiment: one workgroup per CU
@@ -521,8 +534,12 @@ struct ConvInst2 {
 
 // must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
 using V2_CONV2 = ConvInst2<16, 32, 16, 52, true, 4, 1, true>;
-using V2_CONV3_1 = ConvInst2<32, 64, 13, 26, false, 4, 2, true>;
+using V2_CONV3_1 = ConvInst2<32, 64, Y355_C31_TH, Y355_C31_TW, false, Y355_C31_WM, Y355_C31_WN, true>;
+#if Y355_C32_WRES
+using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 8, 1, true>;      // weights (36 KiB) resident: no per-step barrier, no weight re-streaming
+#else
 using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 8, 1, false>;
+#endif
 using V2_CONV4_1 = ConvInst2<64, 128, 13, 26, false, 4, 2, false>;
 using V2_CONV4_2 = ConvInst2<128, 64, 26, 26, true, 8, 1, false>;
 // conv5..7 at batch 64: 256 work items either way, but a 13x26 strip x 128 channels fetches 36 % fewer
@@ -537,6 +554,9 @@ using V2_PRED = ConvInst2<256, 64, 13, 13, false, 8, 1, false>;
 int y355_prepare_conv_v2(void) {
     int e = V2_CONV2::prepare();
     if (!e) e = V2_CONV3_1::prepare();
+#if Y355_C32_WRES && !defined(Y355_EXPERIMENTS)
+    if (!e) e = V2_CONV3_2::prepare();
+#endif
 #ifdef Y355_EXPERIMENTS
     if (!e) e = V2_CONV3_2::prepare();
     if (!e) e = V2_CONV4_1::prepare();
@@ -548,11 +568,21 @@ int y355_prepare_conv_v2(void) {
     return e;
 }
 
+bool y355_conv_v2_preferred(int kid) {
+#if Y355_C32_WRES
+    if (kid == Y355_K_CONV3_2) return true;
+#endif
+    return kid == Y355_K_CONV2 || kid == Y355_K_CONV3_1;
+}
+
 bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s) {
     if ((p.mode & 0xff) != 0 || p.rq.wide || p.guard) return false;   // those go to conv3x3.hip
     switch (kid) {
     case Y355_K_CONV2: return V2_CONV2::launch(p, s);
     case Y355_K_CONV3_1: return V2_CONV3_1::launch(p, s);
+#if Y355_C32_WRES && !defined(Y355_EXPERIMENTS)
+    case Y355_K_CONV3_2: return V2_CONV3_2::launch(p, s);
+#endif
 #ifdef Y355_EXPERIMENTS
     case Y355_K_CONV3_2: return V2_CONV3_2::launch(p, s);
     case Y355_K_CONV4_1: return V2_CONV4_1::launch(p, s);

@@ -456,6 +456,11 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         constexpr bool no_v2 = false;
         constexpr int no_v2_mask = 0, no_ring_mask = 0;
 #endif
+        // layers whose whole weight tensor stays resident in LDS run conv3x3_v2.hip (no per-k-step barrier); the others the ring
+        if (!no_v2 && y355_conv_v2_preferred(L.kid) && y355_launch_conv_v2(L.kid, p, h->stream)) {
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
         if (!no_v2 && !((no_ring_mask >> k) & 1) && y355_launch_conv_ring(L.kid, p, h->stream)) {
             HIPCHK(hipGetLastError());
             return 0;

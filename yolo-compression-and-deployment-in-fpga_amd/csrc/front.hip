@@ -27,6 +27,9 @@
 #ifndef FRONT_OCC
 #define FRONT_OCC 3
 #endif
+#ifndef FRONT_P0_PAD
+#define FRONT_P0_PAD 1           // 1: conflict-free patch pitch (72 pixels); 0: dense pitch (60): 2.8 KiB less LDS per workgroup
+#endif
 #ifndef FRONT_DIAG
 #define FRONT_DIAG 0             // 1: s_memtime stamps at the phase boundaries of each workgroup's first tiles (y355_debug_stamps)
 #endif
@@ -49,7 +52,7 @@ struct FrontGeom {
     static constexpr int NG = (2 * P1W + 4) / 4;                   // 4-pixel groups per patch row (16-byte aligned in x)
     // patch pitch in pixels (= dwords): 8 mod 32, so that the three patch rows an A fragment's half-wave touches (eight
     // consecutive dwords each) fall into disjoint LDS banks (pitch 60 made every ds_read_b32 a 2-way conflict)
-    static constexpr int P0 = front_pitch32(NG * 4);
+    static constexpr int P0 = FRONT_P0_PAD ? front_pitch32(NG * 4) : NG * 4;
     static constexpr int NITEM = PH0 * NG;
     static constexpr int IPT = (NITEM + 255) / 256;
     static constexpr int P1P = front_pitch16(P1W);

@@ -148,6 +148,16 @@ __device__ __forceinline__ unsigned long long y355_wave_max_u64(unsigned long lo
     return v;
 }
 
+// conv3_1 (32 -> 64 channels at a quarter of the input resolution) tile geometry, shared by the generic kernel
+// (conv3x3.hip, always 4 waves: GWM x WN) and the production kernel (conv3x3_v2.hip, WM x WN waves)
+#ifndef Y355_C31_TH
+#define Y355_C31_TH 13
+#define Y355_C31_TW 26
+#define Y355_C31_WM 4
+#define Y355_C31_WN 2
+#endif
+#define Y355_C31_GWM (4 / Y355_C31_WN)
+
 // ---- host-side launch table --------------------------------------------------------------
 struct ConvKernelInfo {
     int cin, bn, th, tw, pool, wm, wn;
@@ -173,6 +183,7 @@ enum {
 // production conv kernels (conv3x3_v2.hip): false = not available for this launch, use ki.launch
 bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_v2(void);
+bool y355_conv_v2_preferred(int kid);     // true: this layer's production kernel is the resident-weight one of conv3x3_v2.hip
 // deep-prefetch ring kernels (conv3x3_ring.hip), layers with >= 64 input channels
 bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_ring(void);
