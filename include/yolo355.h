@@ -126,6 +126,14 @@ int y355_forward(y355_engine *h, const float *x_dev, int batch, int flags,
 int y355_set_normalization(y355_engine *h, const float *mean_bgr, const float *std_bgr);
 int y355_forward_u8(y355_engine *h, const uint8_t *frames_dev, int batch, int flags,
                     float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev);
+/* frames of ANY size: the cv2.resize(image, (W, H)) of BaseTransform (data/__init__.py:36) runs on the GPU in front of
+ * y355_forward_u8.  frames_dev uint8 HWC BGR [B][src_h][src_w][3]; INTER_LINEAR (cv2's default) as OpenCV computes it for
+ * 8-bit images (fixed-point coefficients of 11 bits, imgproc/resize.cpp).  OpenCV is a third-party dependency the
+ * reference does not vendor: parity of this stage is unpinned (oracle/resize_oracle.py restates the published algorithm).
+ * resized_out_dev (or NULL): [B][H][W][3] copy of the resized frames.  All four output pointers NULL: resize only. */
+int y355_forward_u8_resized(y355_engine *h, const uint8_t *frames_dev, int src_h, int src_w, int batch, int flags,
+                            float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev,
+                            uint8_t *resized_out_dev);
 /* same, host pointers in and out (copies through engine-owned staging buffers); synchronous. */
 int y355_forward_host(y355_engine *h, const float *x_host, int batch, int flags,
                       float *boxes, float *scores, int32_t *cls, int32_t *count);

@@ -378,3 +378,47 @@ def test_gather_of_real_engine_output_world1():
     finally:
         dist.destroy_process_group()
     eng.close()
+
+
+# ---- the resize stage of BaseTransform (cv2.resize, data/__init__.py:36): parity UNPINNED (OpenCV is not vendored by the
+# reference and not installed here); the GPU stage is held bit-exact to the numpy restatement of OpenCV's 8-bit algorithm
+def test_resize_oracle_properties():
+    from oracle.resize_oracle import resize_linear_u8, linear_tables
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (2, 37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(resize_linear_u8(a, 37, 53), a)                       # equal sizes: a copy
+    b = rng.integers(0, 256, (1, 40, 60, 3), dtype=np.uint8)
+    area = ((b[:, 0::2, 0::2].astype(int) + b[:, 0::2, 1::2] + b[:, 1::2, 0::2] + b[:, 1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(resize_linear_u8(b, 20, 30), area)                    # exact 2x decimation = OpenCV's area-fast path
+    assert np.unique(resize_linear_u8(np.full((1, 11, 17, 3), 200, np.uint8), 416, 416)).tolist() == [200]
+    ofs, coef = linear_tables(4, 8)                                             # 2x upscale: quarter-pixel phases, clamped borders
+    assert ofs.tolist() == [0, 0, 0, 1, 1, 2, 2, 3]
+    assert coef.tolist() == [[2048, 0], [1536, 512], [512, 1536], [1536, 512], [512, 1536], [1536, 512], [512, 1536], [2048, 0]]
+    up = resize_linear_u8(np.array([[[[0, 0, 0], [100, 100, 100]]]], np.uint8), 1, 4)[0, 0, :, 0]
+    assert up.tolist() == [0, 25, 75, 100]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", [((480, 640), (416, 416)), ((375, 500), (320, 416)), ((120, 160), (240, 320)),
+                                     ((96, 160), (96, 160)), ((833, 417), (416, 416))])
+def test_resize_stage_matches_oracle(src, dst):
+    """y355_forward_u8_resized: the resized frames equal the oracle's bit for bit (down- and up-scaling, non-integer ratios,
+    odd sizes, equal sizes), and the detections equal y355_forward_u8 on the oracle-resized frames."""
+    from oracle.resize_oracle import resize_linear_u8
+    from yolo355.engine import Engine
+    B = 2
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2, pred_gain=400.0, obj_bias=-4.0))
+    eng = Engine(list(dst), 2, synth.ANCHOR_SIZE_MASK, conf_thresh=0.05, max_batch=B)
+    eng.load_quantized(ql)
+    frames = synth.make_frames_u8(77, B, src[0], src[1], "blocks")
+    want = resize_linear_u8(frames, dst[0], dst[1])
+    got = eng.resize_frames(frames).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want), int((got != want).sum())
+    eng.calibrate(synth.normalize_frames(want[:1]), [prep.RangeTracker() for _ in range(11)])
+    a = eng.forward_frames(frames)                      # any size in: resize on the GPU, then the fused uint8 route
+    b = eng.forward_frames(want)
+    assert sum(len(d[1]) for d in a) > 0
+    for u, v in zip(a, b):
+        for s, t in zip(u, v):
+            assert np.array_equal(s, t)
+    eng.close()

@@ -152,6 +152,10 @@ struct y355_engine {
     float nmean[3] = {0.485f, 0.456f, 0.406f};   // BaseTransform constants, RGB order (data/__init__.py:50 lists BGR)
     float nstd[3] = {0.229f, 0.224f, 0.225f};
     const uint8_t *x_u8 = nullptr;  // uint8 frames of the forward being enqueued (y355_forward_u8)
+    // cv2.resize stage of BaseTransform (y355_forward_u8_resized): frames at the network size + coefficient tables
+    uint8_t *rs_frames = nullptr;
+    int *rs_tab = nullptr;          // [xofs W | xa 2W | yofs H | yb 2H]
+    int rs_src_h = 0, rs_src_w = 0;
     int8_t *w0_dev = nullptr;       // conv1 fragment
     Counters *ctr_dev = nullptr;    // [10]
     unsigned int *absmax_dev = nullptr;
@@ -710,6 +714,76 @@ extern "C" int y355_forward_u8(y355_engine *h, const uint8_t *frames_dev, int ba
     const int rc = enqueue_forward(h, nullptr, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, h->profile != 0);
     h->x_u8 = nullptr;
     return rc;
+}
+
+// ---- cv2.resize(image, (W, H)) of BaseTransform (data/__init__.py:36) for uint8 HWC frames, INTER_LINEAR: OpenCV's 8-bit
+// fixed-point bilinear (imgproc/resize.cpp: 11-bit coefficients, horizontal pass in int32, vertical pass
+// (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2).  The coefficient tables are computed on the host with
+// OpenCV's own float / double expressions, so the kernel only gathers and does integer arithmetic.
+static void linear_tables(int src, int dst, int *ofs, int *coef) {
+    const double scale = (double)src / (double)dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int sx = (int)std::floor(f);
+        f -= (float)sx;
+        if (sx < 0) { sx = 0; f = 0.f; }
+        if (sx >= src - 1) { sx = src - 1; f = 0.f; }
+        ofs[d] = sx;
+        const long c0 = std::lrintf((1.f - f) * 2048.f), c1 = std::lrintf(f * 2048.f);     // saturate_cast<short>: round half to even
+        coef[2 * d] = (int)std::min(32767l, std::max(-32768l, c0));
+        coef[2 * d + 1] = (int)std::min(32767l, std::max(-32768l, c1));
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t *src, uint8_t *dst, const int *tab, int sh, int sw, int dh, int dw) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= dh * dw) return;
+    const int dy = i / dw, dx = i % dw;
+    const int *xofs = tab, *xa = tab + dw, *yofs = tab + 3 * dw, *yb = tab + 3 * dw + dh;
+    const int sx0 = xofs[dx], sx1 = min(sx0 + 1, sw - 1), a0 = xa[2 * dx], a1 = xa[2 * dx + 1];
+    const int sy0 = yofs[dy], sy1 = min(sy0 + 1, sh - 1), b0 = yb[2 * dy], b1 = yb[2 * dy + 1];
+    const uint8_t *s = src + (size_t)b * sh * sw * 3;
+    uint8_t *d = dst + ((size_t)b * dh * dw + i) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int d0 = (int)s[((size_t)sy0 * sw + sx0) * 3 + c] * a0 + (int)s[((size_t)sy0 * sw + sx1) * 3 + c] * a1;
+        const int d1 = (int)s[((size_t)sy1 * sw + sx0) * 3 + c] * a0 + (int)s[((size_t)sy1 * sw + sx1) * 3 + c] * a1;
+        const int v = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+        d[c] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// frames of any size: cv2.resize to the network size on the GPU, then y355_forward_u8.  frames_dev uint8 [B][src_h][src_w][3].
+// `resized_out_dev` (optional, [B][H][W][3]) receives the resized frames (parity tap).
+extern "C" int y355_forward_u8_resized(y355_engine *h, const uint8_t *frames_dev, int src_h, int src_w, int batch, int flags,
+                                       float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev,
+                                       uint8_t *resized_out_dev) {
+    if (!h || !frames_dev) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    if (src_h < 1 || src_w < 1 || src_h > 16384 || src_w > 16384) return fail(Y355_EINVAL, "bad frame size");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const int H = h->cfg.height, W = h->cfg.width;
+    if (!h->rs_frames) {
+        if (int rc = dmalloc(h, (void **)&h->rs_frames, (size_t)h->cfg.max_batch * H * W * 3, false)) return rc;
+        if (int rc = dmalloc(h, (void **)&h->rs_tab, sizeof(int) * 3 * (size_t)(H + W), false)) return rc;
+    }
+    if (h->rs_src_h != src_h || h->rs_src_w != src_w) {
+        std::vector<int> tab(3 * (size_t)(H + W));
+        linear_tables(src_w, W, tab.data(), tab.data() + W);
+        linear_tables(src_h, H, tab.data() + 3 * W, tab.data() + 3 * W + H);
+        HIPCHK(hipStreamSynchronize(h->stream));          // a previous forward may still read the old tables
+        HIPCHK(hipMemcpy(h->rs_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+        h->rs_src_h = src_h;
+        h->rs_src_w = src_w;
+    }
+    hipLaunchKernelGGL(resize_u8_kernel, dim3((H * W + 255) / 256, batch), dim3(256), 0, h->stream, frames_dev, h->rs_frames, h->rs_tab,
+                       src_h, src_w, H, W);
+    HIPCHK(hipGetLastError());
+    if (resized_out_dev)
+        HIPCHK(hipMemcpyAsync(resized_out_dev, h->rs_frames, (size_t)batch * H * W * 3, hipMemcpyDeviceToDevice, h->stream));
+    if (!boxes_dev && !scores_dev && !cls_dev && !count_dev) return 0;      // resize only
+    return y355_forward_u8(h, h->rs_frames, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev);
 }
 
 extern "C" int y355_forward_host(y355_engine *h, const float *x_host, int batch, int flags, float *boxes,

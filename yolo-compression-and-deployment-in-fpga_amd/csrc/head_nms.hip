@@ -221,6 +221,9 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     float box[4][4], score[4];
     int cls[4], orig[4], key[4], rk[4], ktu[4];
     bool valid[4];
+    int tkt = -1;                                          // group of this thread's candidates (mixed: more than one)
+    bool mixed = false;
+    unsigned int tst[4] = {0u, 0u, 0x7f7fffffu, 0u};
     {
         // this thread's four anchors np = 4 tid .. 4 tid + 3 of the decode (NMS_CAP is a multiple of 4)
         const size_t o4 = (size_t)b * NMS_CAP + (size_t)tid * 4;
@@ -267,10 +270,50 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 key[u] = kt * HWb + by * p.Wb + bx;
                 ktu[u] = kt;
                 rk[u] = atomicAdd(&hist[key[u]], 1);
-                atomicMax(&sstat[kt][0], __float_as_uint(w));
-                atomicMax(&sstat[kt][1], __float_as_uint(h));
-                atomicMin(&sstat[kt][2], __float_as_uint(ar));
-                atomicMax(&sstat[kt][3], __float_as_uint(ar));
+                // per-group extents: accumulated per thread, merged per wave below (four same-address LDS atomics per
+                // candidate serialised the whole workgroup: 29 k cycles, bank-conflict share 0.89)
+                if (tkt >= 0 && tkt != kt) mixed = true;
+                tkt = kt;
+                tst[0] = max(tst[0], __float_as_uint(w));
+                tst[1] = max(tst[1], __float_as_uint(h));
+                tst[2] = min(tst[2], __float_as_uint(ar));
+                tst[3] = max(tst[3], __float_as_uint(ar));
+            }
+        }
+    }
+    {
+        // a wave covers 256 consecutive positions of the (level, anchor, cell) enumeration: one group, except at the few
+        // group boundaries.  Uniform wave: butterfly reduction, four atomics per wave; otherwise per-candidate atomics.
+        const unsigned long long vm = __ballot(tkt >= 0);
+        if (vm) {
+            const int first = __ffsll((long long)vm) - 1;
+            const int kt0 = __shfl(tkt, first, 64);
+            const bool uni = __all(tkt < 0 || (tkt == kt0 && !mixed));
+            if (uni) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    tst[0] = max(tst[0], (unsigned int)__shfl_xor((int)tst[0], o, 64));
+                    tst[1] = max(tst[1], (unsigned int)__shfl_xor((int)tst[1], o, 64));
+                    tst[2] = min(tst[2], (unsigned int)__shfl_xor((int)tst[2], o, 64));
+                    tst[3] = max(tst[3], (unsigned int)__shfl_xor((int)tst[3], o, 64));
+                }
+                if ((tid & 63) == first) {
+                    atomicMax(&sstat[kt0][0], tst[0]);
+                    atomicMax(&sstat[kt0][1], tst[1]);
+                    atomicMin(&sstat[kt0][2], tst[2]);
+                    atomicMax(&sstat[kt0][3], tst[3]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (valid[u]) {
+                        const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
+                        atomicMax(&sstat[ktu[u]][0], __float_as_uint(w));
+                        atomicMax(&sstat[ktu[u]][1], __float_as_uint(h));
+                        atomicMin(&sstat[ktu[u]][2], __float_as_uint(ar));
+                        atomicMax(&sstat[ktu[u]][3], __float_as_uint(ar));
+                    }
+                }
             }
         }
     }
@@ -409,7 +452,9 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     const bool fast = thr >= 1e-4f && thr < 1e4f;
     const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
     const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
-    const float *as = wk.astat + (size_t)b * MAXA * 4;
+    __shared__ float as[MAXA * 4];                         // per-group extents: read inside the walk (were global loads per group)
+    if (tid < MAXA * 4) as[tid] = wk.astat[(size_t)b * MAXA * 4 + tid];
+    __syncthreads();
     const float4 bi = vi ? sbox[i] : make_float4(0, 0, 0, 0);
     const int ci = vi ? scls[i] : -1;
     const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
@@ -574,6 +619,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     __shared__ __attribute__((aligned(16))) unsigned int sedge[LDS_EDGE_CAP];   // (early << 12) | late
     __shared__ unsigned char state[NMS_CAP];          // 0 undecided, 1 kept, 2 dead
     __shared__ unsigned char blocked[NMS_CAP];
+    __shared__ unsigned int skey[2 * NMS_CAP];        // NMS order key of a candidate: (score bits, ~anchor index); later the emit scratch
     __shared__ unsigned long long keepn[64];          // survivors by anchor index
     __shared__ int wbase[64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -589,6 +635,10 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     for (int pos = tid; pos < NMS_CAP; pos += 1024) {
         state[pos] = (pos < M && brute) ? 0 : 1;          // kept unless it is an endpoint of an edge (below)
         blocked[pos] = 0;
+        // scores are non-negative floats: their bit patterns order like the values.  Staged once, coalesced: the
+        // orientation loop below used to gather cs / co from global memory per edge (15 k cycles of dependent loads)
+        skey[2 * pos] = pos < M ? __float_as_uint(cs[pos]) : 0u;
+        skey[2 * pos + 1] = pos < M ? (unsigned int)co[pos] : 0u;
     }
     if (tid < 64) keepn[tid] = 0ull;
     __syncthreads();
@@ -598,8 +648,8 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
         for (int e = tid; e < ne; e += 1024) {
             const unsigned int pq = ge[e];
             const int i = (int)(pq >> 12), q = (int)(pq & 0xfffu);
-            const float si = cs[i], sq = cs[q];
-            const bool i_first = si > sq || (si == sq && co[i] < co[q]);
+            const unsigned int si = skey[2 * i], sq = skey[2 * q];
+            const bool i_first = si > sq || (si == sq && skey[2 * i + 1] < skey[2 * q + 1]);
             sedge[tid + mine * 1024] = i_first ? pq : (((unsigned int)q << 12) | (unsigned int)i);
             state[i] = 0;                                 // both endpoints are undecided
             state[q] = 0;
@@ -684,7 +734,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     // ---- emit: survivors in anchor-index order
     for (int pos = tid; pos < M; pos += 1024) {
         if (state[pos] == 1) {
-            const int n = co[pos];
+            const int n = (int)skey[2 * pos + 1];
             atomicOr(&keepn[n >> 6], 1ull << (n & 63));
         }
     }
@@ -706,7 +756,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     int *oc = p.out_cls + (size_t)b * p.max_det;
     for (int pos = tid; pos < M; pos += 1024) {
         if (state[pos] == 1) {
-            const int n = co[pos];
+            const int n = (int)skey[2 * pos + 1];
             const unsigned long long bits = keepn[n >> 6];
             const int dst = wbase[n >> 6] + __popcll(bits & ((1ull << (n & 63)) - 1ull));
             if (dst < p.max_det) {

@@ -196,19 +196,38 @@ class Engine:
     def forward_frames_device(self, frames, flags=0, out=None):
         """Asynchronous batched forward on camera frames: CUDA uint8 [B,H,W,3] BGR at the network size
         (BaseTransform fused into the first layer, y355_forward_u8)."""
-        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3 or \
-                list(frames.shape[1:3]) != self.input_size or not frames.is_cuda:
-            raise ValueError("expected a CUDA uint8 tensor [B,%d,%d,3]" % tuple(self.input_size))
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3 or not frames.is_cuda:
+            raise ValueError("expected a CUDA uint8 tensor [B,h,w,3]")
         frames = frames.contiguous()
         B = frames.shape[0]
         if B > self.max_batch:
             raise ValueError("batch %d > max_batch %d" % (B, self.max_batch))
         ob, os_, oc, on = out if out is not None else self._buffers(B)
         cur = self._enter()
-        _ffi.check(self._lib.y355_forward_u8(self._h, frames.data_ptr(), B, int(flags), ob.data_ptr(), os_.data_ptr(),
-                                             oc.data_ptr(), on.data_ptr()))
+        if list(frames.shape[1:3]) == self.input_size:
+            _ffi.check(self._lib.y355_forward_u8(self._h, frames.data_ptr(), B, int(flags), ob.data_ptr(), os_.data_ptr(),
+                                                 oc.data_ptr(), on.data_ptr()))
+        else:       # frames of another size: BaseTransform's cv2.resize (data/__init__.py:36) on the GPU first
+            _ffi.check(self._lib.y355_forward_u8_resized(self._h, frames.data_ptr(), int(frames.shape[1]), int(frames.shape[2]), B,
+                                                         int(flags), ob.data_ptr(), os_.data_ptr(), oc.data_ptr(), on.data_ptr(), None))
         self._leave(cur)
         return ob, os_, oc, on
+
+    def resize_frames(self, frames):
+        """cv2.resize(image, (W, H)) of BaseTransform for a batch of uint8 [B,h,w,3] frames on the GPU (the stage
+        y355_forward_u8_resized runs in front of the network); returns a CUDA uint8 tensor [B,H,W,3]."""
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(frames)
+        fd = frames.to(self.device).contiguous()
+        B = fd.shape[0]
+        if B > self.max_batch:
+            raise ValueError("batch %d > max_batch %d" % (B, self.max_batch))
+        out = torch.empty((B, self.input_size[0], self.input_size[1], 3), dtype=torch.uint8, device=self.device)
+        cur = self._enter()
+        _ffi.check(self._lib.y355_forward_u8_resized(self._h, fd.data_ptr(), int(fd.shape[1]), int(fd.shape[2]), B, 0,
+                                                     None, None, None, None, out.data_ptr()))
+        self._leave(cur)
+        return out
 
     def forward_frames(self, frames, find=False):
         """frames: uint8 [B,H,W,3] BGR (numpy or torch).  Same return as forward(normalised tensor)."""
