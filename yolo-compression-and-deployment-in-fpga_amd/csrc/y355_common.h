@@ -152,7 +152,7 @@ __device__ __forceinline__ unsigned long long y355_wave_max_u64(unsigned long lo
 // (conv3x3.hip, always 4 waves: GWM x WN) and the production kernel (conv3x3_v2.hip, WM x WN waves)
 #ifndef Y355_C31_TH
 #define Y355_C31_TH 13
-#define Y355_C31_TW 26
+#define Y355_C31_TW 52
 #define Y355_C31_WM 4
 #define Y355_C31_WN 2
 #endif
