@@ -31,3 +31,10 @@ for k in range(3):
         d = (cur-prev)[ok]
         print("   slot",s,"median %.0f max %.0f ticks (n=%d)"%(np.median(d), d.max(), ok.sum()))
         prev = np.where(ok, cur, prev)
+# per-wave end-of-walk times (pairs, experiment build): block 3 = [wg*2 + wave/8][wave%8] of the first 128 workgroups
+pw = buf[3].reshape(128, 16)
+t1 = buf[1][:128, 1].astype(np.int64)            # staging done (wave 0)
+for wg in range(0, 8):
+    ends = (pw[wg] & np.uint64(0xffffffffff)).astype(np.int64) - (t1[wg] & 0xffffffffff)
+    trips = (pw[wg] >> np.uint64(40)).astype(np.int64)
+    print("pairs wg", wg, "per-wave walk cycles", ends.tolist(), "trips", trips.tolist())

@@ -418,183 +418,201 @@ __device__ __forceinline__ bool suppresses(const float4 a, float area_a, const f
 // provided the union is not degenerate (area sum >= 1e-10) and thr >= 1e-4.
 // grid (CAP/1024, batch), 1024 threads: one thread per candidate i.  Every unordered pair is
 // visited once, from its lower compact position: partners q > i inside the window.  The image's
-// candidates and bin starts are staged in LDS (97 KB) so the walk never waits on global memory;
-// suppressing pairs are buffered in LDS and appended to the image's edge list with one atomic
-// per workgroup.
+// candidates, their groups and the bin starts are staged in LDS so the walk never waits on global memory.
+//
+// The walk is written for few instructions and few branches (the first version spent its time in control flow: 290
+// branches / 265 exec-mask saves in 4 650 instructions, 3-4 k cycles per trip of four partners):
+//   * a trip loads four partners and evaluates the whole predicate branch-free; only a quotient within 8e-6 of the
+//     threshold (rare) takes a wave-uniform branch to the IEEE division;
+//   * hits go to a per-WAVE edge buffer in LDS: position = wave-uniform count + rank in the ballot, no atomics; a full
+//     buffer (and every wave at its end) is flushed to the image's global list with one global atomic;
+//   * the next bin row's range is read while the current row is walked.
+#define WAVE_EDGE_CAP (WG_EDGE_CAP / 16)
 __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const HeadWork wk, float thr) {
     extern __shared__ __attribute__((aligned(16))) char plds[];
     float4 *sbox = (float4 *)plds;                                   // [CAP]
-    int *scls = (int *)(plds + NMS_CAP * 16);                        // [CAP]
+    int *scls = (int *)(plds + NMS_CAP * 16);                        // [CAP] class | group << 16
     int *sbin = (int *)(plds + NMS_CAP * 20);                        // [CAP + 8]
-    unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 20 + (NMS_CAP + 8) * 4);   // [WG_EDGE_CAP]
-    __shared__ int nedge_s, gbase_s;
+    unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 20 + (NMS_CAP + 8) * 4);   // [16][WAVE_EDGE_CAP]
+    __shared__ float as[MAXA * 4];                         // per-group extents
     const int b = blockIdx.y;
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 0);
     const int M = wk.count[b];
     if ((int)blockIdx.x * 64 >= M) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int A = p.group_by_area ? NGROUP : p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // candidate groups, bin grid
     {
         const float4 *cbx4 = (const float4 *)(wk.cbox + (size_t)b * NMS_CAP * 4);
         const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
+        const int *cty = wk.ctype + (size_t)b * NMS_CAP;
         const int *bs = wk.binstart + (size_t)b * (NMS_CAP + 8);
-        for (int q = tid; q < M; q += 1024) { sbox[q] = cbx4[q]; scls[q] = ccl[q]; }
-        for (int q = tid; q <= A * HW; q += 1024) sbin[q] = bs[q];
-        if (tid == 0) nedge_s = 0;
+        // all loads of a thread issued together (one global latency, not one per iteration)
+        float4 vb[NMS_CAP / 1024];
+        int vc[NMS_CAP / 1024], vt[NMS_CAP / 1024], vs[NMS_CAP / 1024 + 1];
+#pragma unroll
+        for (int u = 0; u < NMS_CAP / 1024; ++u) {
+            const int q = tid + u * 1024;
+            vb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vc[u] = 0; vt[u] = 0;
+            if (q < M) { vb[u] = cbx4[q]; vc[u] = ccl[q]; vt[u] = cty[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u <= NMS_CAP / 1024; ++u) {
+            const int q = tid + u * 1024;
+            vs[u] = (q <= A * HW) ? bs[q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < NMS_CAP / 1024; ++u) {
+            const int q = tid + u * 1024;
+            if (q < M) { sbox[q] = vb[u]; scls[q] = (vc[u] & 0xffff) | (vt[u] << 16); }
+        }
+#pragma unroll
+        for (int u = 0; u <= NMS_CAP / 1024; ++u) {
+            const int q = tid + u * 1024;
+            if (q <= A * HW) sbin[q] = vs[u];
+        }
+        if (tid < MAXA * 4) as[tid] = wk.astat[(size_t)b * MAXA * 4 + tid];
     }
     __syncthreads();
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 1);
-    // 64-candidate runs are dealt round-robin to the image's workgroups: neighbours in (anchor, bin)
+    // 64-candidate runs are dealt round-robin to the image's workgroups: neighbours in (group, bin)
     // order have windows of similar size, so a wave stays uniform while every workgroup gets the same
     // mix of cheap and expensive waves
-    const int i = (((tid >> 6) * (int)gridDim.x + (int)blockIdx.x) << 6) + (tid & 63);
+    const int wave = tid >> 6;
+    const int i = ((wave * (int)gridDim.x + (int)blockIdx.x) << 6) + lane;
     const bool vi = i < M;
     const bool fast = thr >= 1e-4f && thr < 1e4f;
     const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
     const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
-    __shared__ float as[MAXA * 4];                         // per-group extents: read inside the walk (were global loads per group)
-    if (tid < MAXA * 4) as[tid] = wk.astat[(size_t)b * MAXA * 4 + tid];
-    __syncthreads();
     const float4 bi = vi ? sbox[i] : make_float4(0, 0, 0, 0);
-    const int ci = vi ? scls[i] : -1;
+    const int cti = vi ? scls[i] : -1;                     // class | group << 16: equal classes <=> equal low halves
+    const int ci = cti & 0xffff;
     const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
     const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
     bool lost = false;
-    unsigned int eb0 = 0, eb1 = 0, eb2 = 0, eb3 = 0;
-    int ne_l = 0;
-    auto push = [&](unsigned int ed) {                   // one edge, straight to the lists
-        const int e = atomicAdd(&nedge_s, 1);
-        if (e < WG_EDGE_CAP) {
-            sedge[e] = ed;
-        } else {                                         // LDS buffer full: the image's global list
-            const int g = atomicAdd(&wk.nedges[b * 2], 1);
-            if (g < EDGE_CAP) wk.edges[(size_t)b * EDGE_CAP + g] = ed;
+    unsigned int *wedge = sedge + wave * WAVE_EDGE_CAP;
+    unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
+    int wcount = 0;                                        // wave-uniform: edges in this wave's buffer
+    int dbg_trips = 0;
+    (void)dbg_trips;
+    auto flush = [&]() {                                   // wave-uniform call
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&wk.nedges[b * 2], wcount);
+        g = __builtin_amdgcn_readfirstlane(g);
+        for (int e = lane; e < wcount; e += 64) {
+            if (g + e < EDGE_CAP) ge[g + e] = wedge[e];
             else lost = true;
         }
+        wcount = 0;
     };
-    auto test = [&](int q, const float4 bj, const int cj) {
+    // the reference's predicate (slim_yolo_v2.py:159-171) for partner q of candidate i, branch-free; `ok` = q is a real
+    // partner of this lane's trip
+    auto test = [&](int q, bool ok, const float4 bj, const int ctj) {
         const float wj = bj.z - bj.x, hj = bj.w - bj.y, aj = wj * hj;
-        bool cand = (q > i) && (cj == ci);
+        bool cand = ok && (q > i) && ((ctj & 0xffff) == ci);
         if (fast) {
             const float dx = fabsf(cxi - 0.5f * (bj.x + bj.z)), dy = fabsf(cyi - 0.5f * (bj.y + bj.w));
-            const bool far = dx >= kr * (wi + wj) + PRUNE_EPS || dy >= kr * (hi + hj) + PRUNE_EPS ||
-                             fminf(ai, aj) <= thr_lo * fmaxf(ai, aj);
-            cand = cand && !(far && (ai + aj >= AREA_MIN));
+            const bool far = (dx >= kr * (wi + wj) + PRUNE_EPS) | (dy >= kr * (hi + hj) + PRUNE_EPS) |
+                             (fminf(ai, aj) <= thr_lo * fmaxf(ai, aj));
+            cand = cand & !(far & (ai + aj >= AREA_MIN));
         }
-        if (cand) {
-            // the reference's predicate (slim_yolo_v2.py:159-171); IEEE division only near the threshold
-            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-            const float iw = fmaxf(1e-28f, xx2 - xx1), ih = fmaxf(1e-28f, yy2 - yy1);
-            const float inter = iw * ih, den = ai + aj - inter;
-            const float qv = inter * __builtin_amdgcn_rcpf(den);
-            bool s;
-            if (fast && den > 1e-30f && den < 1e30f && (qv > q_hi || qv < q_lo)) s = qv > q_hi;
-            else s = !(inter / den <= thr);
-            if (s) {
-                // a candidate has a couple of suppressing partners on average: keep the first four in
-                // registers and append them wave-wide after the walk (one LDS atomic per wave and slot
-                // instead of thousands of serialised same-address atomics inside the divergent loop)
-                const unsigned int ed = ((unsigned int)i << 12) | (unsigned int)q;
-                if (ne_l == 0) eb0 = ed;
-                else if (ne_l == 1) eb1 = ed;
-                else if (ne_l == 2) eb2 = ed;
-                else if (ne_l == 3) eb3 = ed;
-                else push(ed);
-                ++ne_l;
+        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+        const float iw = fmaxf(1e-28f, xx2 - xx1), ih = fmaxf(1e-28f, yy2 - yy1);
+        const float inter = iw * ih, den = ai + aj - inter;
+        const float qv = inter * __builtin_amdgcn_rcpf(den);
+        const bool sure = fast & (den > 1e-30f) & (den < 1e30f) & ((qv > q_hi) | (qv < q_lo));
+        bool hit = cand & sure & (qv > q_hi);
+        if (__any(cand & !sure)) {                         // rare: the correctly rounded quotient decides
+            if (cand & !sure) hit = !(inter / den <= thr);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            if (hit) {
+                const int e = wcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                wedge[e] = ((unsigned int)i << 12) | (unsigned int)q;
             }
+            wcount += (int)__popcll(m);
         }
     };
-    auto walk = [&](int q0, int q1) {
-        for (int q = q0; q < q1; q += 4) {
+    // Every loop below is WAVE-UNIFORM (bounds through __any, lanes without work carry ok = false): the edge count of the
+    // wave's buffer is a scalar only if all lanes see every update.
+    auto walk = [&](int q0, int q1) {                      // partners [q0, q1) of this lane (empty: q0 >= q1)
+        for (int q = q0; __any(q < q1); q += 4) {
+#ifdef Y355_EXPERIMENTS
+            ++dbg_trips;
+#endif
             float4 bj[4];
             int cj[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int qq = min(q + u, q1 - 1);
+                const int qq = max(min(q + u, q1 - 1), 0);
                 bj[u] = sbox[qq];
                 cj[u] = scls[qq];
             }
+            if (wcount > WAVE_EDGE_CAP - 256) flush();     // room for this trip's 4 x 64 hits
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (q + u < q1) test(q + u, bj[u], cj[u]);
+            for (int u = 0; u < 4; ++u) test(q + u, q + u < q1, bj[u], cj[u]);
         }
     };
-    if (vi) {
-        // own anchor and bin (same formula as head_kernel)
-        const int a_i = wk.ctype[(size_t)b * NMS_CAP + i];
+    {
+        // own group and bin row (same formula as head_kernel); lanes past M walk nothing (a_i = A)
+        const int a_i = vi ? (cti >> 16) : A;
         const int by_i = min(Hs - 1, max(0, (int)(cyi * (float)Hs)));
-        for (int a2 = a_i; a2 < A; ++a2) {              // lower anchors only hold positions < i
+        for (int a2 = 0; a2 < A; ++a2) {
             const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1], amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
-            if (amax < amin) continue;                         // no candidate of this anchor
+            if (amax < amin) continue;                         // no candidate of this group (uniform)
+            bool act = a2 >= a_i;                              // lower groups only hold positions < i
             int bx0 = 0, bx1 = Ws - 1, by0 = 0, by1 = Hs - 1;
             if (fast && (ai + amin >= AREA_MIN)) {
-                if (ai <= thr_lo * amin || amax <= thr_lo * ai) continue;    // area ratio rules the anchor out
+                if (ai <= thr_lo * amin || amax <= thr_lo * ai) act = false;     // area ratio rules the group out
                 const float rx = kr * (wi + wmax) + PRUNE_EPS, ry = kr * (hi + hmax) + PRUNE_EPS;
                 bx0 = max(0, (int)floorf((cxi - rx) * (float)Ws));
                 bx1 = min(Ws - 1, (int)floorf((cxi + rx) * (float)Ws));
                 by0 = max(0, (int)floorf((cyi - ry) * (float)Hs));
                 by1 = min(Hs - 1, (int)floorf((cyi + ry) * (float)Hs));
             }
-            if (a2 == a_i) by0 = max(by0, by_i);               // earlier bin rows of my anchor are < i
-            // two bin rows per trip and four partners per trip: the LDS reads of a trip are independent,
-            // so their latency overlaps (one dependent read per partner made this loop latency-bound)
-            for (int by = by0; by <= by1; by += 2) {
-                const int k0 = a2 * HW + by * Ws;
-                const bool two = by + 1 <= by1;
-                const int ra = sbin[k0 + bx0], rb = sbin[k0 + bx1 + 1];
-                const int rc = two ? sbin[k0 + Ws + bx0] : 0, rd = two ? sbin[k0 + Ws + bx1 + 1] : 0;
-                walk(max(ra, i + 1), rb);
-                if (two) walk(max(rc, i + 1), rd);
+            if (a2 == a_i) by0 = max(by0, by_i);               // earlier bin rows of my group are < i
+            if (!act || by0 > by1 || bx0 > bx1) { by0 = 0; by1 = -1; bx0 = 0; bx1 = 0; }   // an empty window, valid addresses
+            if (!__any(by0 <= by1)) continue;
+            int k0 = a2 * HW + by0 * Ws;
+            int ra = sbin[k0 + bx0], rb = sbin[k0 + bx1 + 1];
+            for (int by = by0; __any(by <= by1); ++by) {
+                // the next row's range is in flight while this row is walked (past the window it is read and dropped)
+                const int kn = min(k0 + Ws, A * HW - Ws);
+                const int nra = sbin[kn + bx0], nrb = sbin[kn + bx1 + 1];
+                const bool row = by <= by1;
+                walk(row ? max(ra, i + 1) : 0, row ? rb : 0);
+                ra = nra; rb = nrb;
+                k0 = kn;
             }
         }
-        if (fast && ai < AREA_MIN) {                               // degenerate boxes see each other
-            const int nt = wk.ntiny[b];
-            const int *tl = wk.tiny + (size_t)b * NMS_CAP;
-            for (int t = 0; t < nt; ++t) { const int q = tl[t]; test(q, sbox[q], scls[q]); }
-        }
-    }
-    // buffered edges: slot k of every lane that has one, appended with one atomic per wave
-    {
-        const int lane = tid & 63;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool has = ne_l > k;
-            const unsigned long long m = __ballot(has);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&nedge_s, __popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (has) {
-                    const int e = base + __popcll(m & ((1ull << lane) - 1ull));
-                    const unsigned int ed = k == 0 ? eb0 : k == 1 ? eb1 : k == 2 ? eb2 : eb3;
-                    if (e < WG_EDGE_CAP) {
-                        sedge[e] = ed;
-                    } else {
-                        const int g = atomicAdd(&wk.nedges[b * 2], 1);
-                        if (g < EDGE_CAP) wk.edges[(size_t)b * EDGE_CAP + g] = ed;
-                        else lost = true;
-                    }
+        {                                                          // degenerate boxes see each other
+            const bool tiny_i = fast && vi && ai < AREA_MIN;
+            if (__any(tiny_i)) {
+                const int nt = wk.ntiny[b];
+                const int *tl = wk.tiny + (size_t)b * NMS_CAP;
+                for (int t0 = 0; t0 < nt; ++t0) {
+                    if (wcount > WAVE_EDGE_CAP - 64) flush();
+                    const int q = tl[t0];
+                    test(q, tiny_i, sbox[q], scls[q]);
                 }
             }
         }
     }
-    __syncthreads();
-    NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 2);
-    const int ne = min(nedge_s, WG_EDGE_CAP);
-    if (tid == 0) {
-        gbase_s = atomicAdd(&wk.nedges[b * 2], ne);
-        if (nedge_s > WG_EDGE_CAP) wk.nedges[b * 2 + 1] = 1;
+#ifdef Y355_EXPERIMENTS
+    if (wk.stamps) {                                   // per-wave end of the walk and the wave-wide trip count (max over lanes)
+        int mt = dbg_trips;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mt = max(mt, __shfl_xor(mt, o, 64));
+        const int wgl = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && wgl < 128)
+            wk.stamps[(3 * 256 + wgl * 2 + (tid >> 9)) * 8 + ((tid >> 6) & 7)] =
+                (__builtin_amdgcn_s_memtime() & 0xffffffffffull) | ((unsigned long long)mt << 40);
     }
+#endif
+    if (wcount > 0) flush();
     if (lost) wk.nedges[b * 2 + 1] = 1;
-    __syncthreads();
-    NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 3);
-    const int gb = gbase_s;
-    unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
-    for (int e = tid; e < ne; e += 1024) {
-        if (gb + e < EDGE_CAP) ge[gb + e] = sedge[e];
-        else wk.nedges[b * 2 + 1] = 1;
-    }
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 7);
 }
 #define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
@@ -613,12 +631,14 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
 // Survivors are then written in anchor-index order into the padded outputs.
 // Fallback (an edge list overflowed, or more edges than the LDS list holds): the textbook walk over
 // the candidates sorted by score, with the reference's predicate evaluated on the fly.
-#define LDS_EDGE_CAP 28672          // edges of one image held in LDS (112 KiB)
+#define LDS_EDGE_CAP 28672          // most edges of one image the rounds handle (the sorted walk takes over beyond)
+#define RE_REG 7                    // edge slots per thread held in registers (7168 edges)
+#define RE_NONE 0x00ffffffu          // a retired / absent edge: (4095, 4095), never a real pair (i < q)
 
 __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, const HeadWork wk, float thr) {
-    __shared__ __attribute__((aligned(16))) unsigned int sedge[LDS_EDGE_CAP];   // (early << 12) | late
-    __shared__ unsigned char state[NMS_CAP];          // 0 undecided, 1 kept, 2 dead
-    __shared__ unsigned char blocked[NMS_CAP];
+    __shared__ __attribute__((aligned(16))) unsigned int sedge[LDS_EDGE_CAP - RE_REG * 1024];   // edges past the register slots; sort keys of the fallback walk
+    __shared__ __attribute__((aligned(16))) unsigned char state[NMS_CAP];        // 0 undecided, 1 kept, 2 dead
+    __shared__ __attribute__((aligned(16))) unsigned char blocked[NMS_CAP];
     __shared__ unsigned int skey[2 * NMS_CAP];        // NMS order key of a candidate: (score bits, ~anchor index); later the emit scratch
     __shared__ unsigned long long keepn[64];          // survivors by anchor index
     __shared__ int wbase[64];
@@ -642,52 +662,89 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     }
     if (tid < 64) keepn[tid] = 0ull;
     __syncthreads();
-    int mine = 0;                                     // live edges in my slots tid, tid + 1024, ...
     if (!brute) {
-        // orient every pair by the NMS order
-        for (int e = tid; e < ne; e += 1024) {
-            const unsigned int pq = ge[e];
+        // The first RE_REG entries of a thread's edge slots (slot k of thread tid = list entry tid + 1024 k) live in registers,
+        // the rest (only images with more than 7168 suppressing pairs have any) in LDS; the candidate states in LDS.
+        // A round is two LDS round trips and two barriers:
+        //   A  all state reads of my live edges issued together, then the writes (dead / blocked marks);
+        //   B  every thread settles its own four candidates (one dword of `state`, one of `blocked`).
+        // (Measured before: edges compacted in LDS, three dependent LDS stages per trip of four edges: 4-6 k cycles per
+        // round, 16-17 rounds.)
+        const int kmax = __builtin_amdgcn_readfirstlane((ne + 1023) >> 10);
+        unsigned int ed[RE_REG];
+        auto orient = [&](unsigned int pq) {
+            // orient the pair by the NMS order (score desc, anchor index asc); both endpoints become undecided
             const int i = (int)(pq >> 12), q = (int)(pq & 0xfffu);
-            const unsigned int si = skey[2 * i], sq = skey[2 * q];
-            const bool i_first = si > sq || (si == sq && skey[2 * i + 1] < skey[2 * q + 1]);
-            sedge[tid + mine * 1024] = i_first ? pq : (((unsigned int)q << 12) | (unsigned int)i);
-            state[i] = 0;                                 // both endpoints are undecided
+            const uint2 ki = *(const uint2 *)&skey[2 * i], kq = *(const uint2 *)&skey[2 * q];
+            const bool i_first = ki.x > kq.x || (ki.x == kq.x && ki.y < kq.y);
+            state[i] = 0;
             state[q] = 0;
-            ++mine;
+            return i_first ? pq : (((unsigned int)q << 12) | (unsigned int)i);
+        };
+#pragma unroll
+        for (int k = 0; k < RE_REG; ++k) {
+            const int e = tid + k * 1024;
+            ed[k] = e < ne ? ge[e] : RE_NONE;
         }
-    }
-    __syncthreads();
-    NSTAMP(2, blockIdx.x, 1);
-    if (!brute) {
+#pragma unroll
+        for (int k = 0; k < RE_REG; ++k)
+            if (ed[k] != RE_NONE) ed[k] = orient(ed[k]);
+        for (int k = RE_REG; k < kmax; ++k) {
+            const int e = tid + k * 1024;
+            sedge[e - RE_REG * 1024] = e < ne ? orient(ge[e]) : RE_NONE;
+        }
+        __syncthreads();
+        NSTAMP(2, blockIdx.x, 1);
+        // one step of A for an edge whose endpoint states were read as (sa, sc): returns the edge, or RE_NONE once it retires
+        auto settle = [&](unsigned int e, int sa, int sc) {
+            if (e == RE_NONE || sc == 2 || sa == 2) return RE_NONE;             // settled without this edge
+            const int c = (int)(e & 0xfffu);
+            if (sa == 1) { state[c] = 2; return RE_NONE; }                        // earlier endpoint kept: the later one dies
+            blocked[c] = 1;                                                        // earlier endpoint undecided
+            return e;
+        };
+        int nround = 0;
+        (void)nround;
         for (;;) {
-            int n2 = 0;
-            for (int k0 = 0; k0 < mine; k0 += 4) {                  // 4 edges per trip: the LDS reads overlap
-                unsigned int ed[4];
-                int sa[4], sc[4];
+            ++nround;
+            {
+                int sa[RE_REG], sc[RE_REG];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ed[u] = sedge[tid + min(k0 + u, mine - 1) * 1024];
+                for (int k = 0; k < RE_REG; ++k) {                                  // RE_NONE reads candidate 4095: harmless
+                    sa[k] = state[ed[k] >> 12];
+                    sc[k] = state[ed[k] & 0xfffu];
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { sa[u] = state[ed[u] >> 12]; sc[u] = state[ed[u] & 0xfffu]; }
+                for (int k = 0; k < RE_REG; ++k) ed[k] = settle(ed[k], sa[k], sc[k]);
+            }
+            for (int k = RE_REG; k < kmax; ++k) {                                   // rare: the LDS-resident tail
+                const unsigned int e = sedge[tid + (k - RE_REG) * 1024];
+                if (e != RE_NONE) sedge[tid + (k - RE_REG) * 1024] = settle(e, state[e >> 12], state[e & 0xfffu]);
+            }
+            __syncthreads();
+#ifdef Y355_EXPERIMENTS
+            if (nround == 1) NSTAMP(2, blockIdx.x, 3);
+#endif
+            unsigned int st = *(const unsigned int *)&state[4 * tid], bl = *(const unsigned int *)&blocked[4 * tid];
+            int pending = 0;
+            if (((st - 0x01010101u) & ~st & 0x80808080u) != 0u) {                      // some byte of st is 0 (undecided)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (k0 + u >= mine || sc[u] == 2 || sa[u] == 2) continue;
-                    const int c = (int)(ed[u] & 0xfffu);
-                    if (sa[u] == 1) { state[c] = 2; continue; }
-                    blocked[c] = 1;
-                    sedge[tid + n2 * 1024] = ed[u];
-                    ++n2;
+                    if (((st >> (8 * u)) & 0xffu) == 0u) {
+                        if (((bl >> (8 * u)) & 0xffu) == 0u) st |= 1u << (8 * u);
+                        else pending = 1;
+                    }
                 }
+                *(unsigned int *)&state[4 * tid] = st;
             }
-            mine = n2;
-            __syncthreads();
-            int pending = 0;
-            for (int pos = tid; pos < M; pos += 1024) {
-                if (state[pos] == 0) {
-                    if (!blocked[pos]) state[pos] = 1;
-                    else { blocked[pos] = 0; pending = 1; }
-                }
-            }
-            if (!__syncthreads_or(pending)) break;
+            if (bl) *(unsigned int *)&blocked[4 * tid] = 0u;
+            const int again = __syncthreads_or(pending);
+#ifdef Y355_EXPERIMENTS
+            if (nround == 1) NSTAMP(2, blockIdx.x, 4);
+            if (nround == 2) NSTAMP(2, blockIdx.x, 5);
+            if (!again && wk.stamps && tid == 0 && blockIdx.x < 256) wk.stamps[((2 * 256 + blockIdx.x) * 8) + 6] = wk.stamps[((2 * 256 + blockIdx.x) * 8) + 5] + nround;
+#endif
+            if (!again) break;
         }
     } else {
         // ---- fallback: sort all candidates by (score desc, anchor index asc), walk them one at a time
