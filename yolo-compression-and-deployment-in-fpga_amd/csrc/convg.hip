@@ -65,6 +65,8 @@ __device__ __forceinline__ long long requant_g(int acc, long long bias, const Re
     return y355_rne_shift<long long>(t, rq.sh);
 }
 
+// ---- four waves per workgroup (round 1): one tile per workgroup, stage -> barrier -> k-steps -> barrier per chunk.  Kept for
+// the thin layers and the small / stride-2 tiles, where its 2-3 workgroups per CU overlap each other's phases.
 template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S>
 __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
     constexpr bool THIN = (CHB == 32);           // 32 B per pixel: a k-step covers two taps
@@ -302,16 +304,304 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
     }
 }
 
+
+// ---- eight waves per workgroup (round 2)
+// One tile per workgroup, eight waves (96 accumulators per wave instead of 176: two waves per SIMD).  The input patch is staged
+// in chunks of CHB bytes per pixel through TWO LDS slabs: the global loads of chunk c + 1 are issued before the k-steps of
+// chunk c and written to the other slab after them, one barrier per chunk.  B fragments come straight from global memory
+// (L2-resident), two k-steps ahead.  Measured (B = 64, slim fp32 / B = 128, tiny int8): 59.9 -> 63.8 k and 50.8 -> 63.1 k img/s.
+// Persistent workgroups with the next tile's first chunk prefetched across the epilogue were built too and were SLOWER
+// (58.2 k / 49.2 k): the extra live state spills, and one 8-wave workgroup per CU has nothing to overlap its epilogue with.
+// What bounds this kernel now is the B path: 16-32 KB of fragments per k-step per CU through the vector-memory pipe
+// (profiles/r02_notes.md); the int8 ring kernels avoid exactly that with LDS-DMA weight rings.
+template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S>
+__global__ __launch_bounds__(WM * WN * 64) void convg8_kernel(const ConvGParams p, const int total) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr bool THIN = (CHB == 32);           // 32 B per pixel: a k-step covers two taps
+    // input patch of a TH x TW output tile: S*(T-1)+3 pixels a side (stride S, 3x3, pad 1)
+    constexpr int PW = S * (TW - 1) + 3, PH = S * (TH - 1) + 3, NPIX = PH * PW;
+    static_assert(S == 1 || (S == 2 && !POOL && !THIN), "stride 2: plain 64-byte-chunk tiles only");
+    constexpr int STRIDE = CHB + 16;             // 16-byte pad: conflict-free ds_read_b128 across pixels
+    constexpr int CPP = CHB / 16;
+    constexpr int SUB = THIN ? 1 : CHB / 64;     // k-steps per tap and chunk
+    constexpr int BM = TH * TW;
+    constexpr int MT_TOT = (BM + 15) / 16;
+    constexpr int MT = (MT_TOT + WM - 1) / WM;
+    constexpr int NT = BN / 16 / WN;
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int SLAB = (NPIX * STRIDE + 15) / 16 * 16;
+    static_assert(!POOL || (TH % 2 == 0 && TW % 2 == 0), "pooled tiles are even");
+    using ACC = typename std::conditional<BF, v4f, v4i>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int H = p.H, W = p.W;
+    const int taps = p.taps;
+    const int kpc = THIN ? 5 : SUB * taps;       // k-steps per chunk
+    const int KS = kpc * p.nchunks;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, g = lane >> 4;
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int row = (wm * MT + m) * 16 + li;
+        row = min(row, BM - 1);
+        int oy, ox;
+        if constexpr (POOL) {
+            const int w = row >> 2, r = row & 3;
+            oy = 2 * (w / (TW / 2)) + (r >> 1);
+            ox = 2 * (w % (TW / 2)) + (r & 1);
+        } else {
+            oy = row / TW;
+            ox = row % TW;
+        }
+        abase[m] = (S * oy * PW + S * ox) * STRIDE + (THIN ? 0 : g * 16);
+    }
+    int kofs[THIN ? 5 : 1];
+    if constexpr (THIN) {
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int tap = min(2 * ks + (g >> 1), 8);
+            kofs[ks] = ((tap / 3) * PW + tap % 3) * STRIDE + (g & 1) * 16;
+        }
+    } else {
+        kofs[0] = 0;
+    }
+
+    int bid = y355_xcd_remap(blockIdx.x, gridDim.x);
+    if (bid >= total) return;
+    const int nb = bid % p.nblk;
+    bid /= p.nblk;
+    const int x0 = (bid % p.tiles_x) * TW;
+    bid /= p.tiles_x;
+    const int y0 = (bid % p.tiles_y) * TH;
+    const int b = bid / p.tiles_y;
+
+    // ---- staging: CHB bytes of every patch pixel, 16 B per thread per item (tail clamped: duplicates rewrite the same
+    // bytes).  The item -> address arithmetic is recomputed per chunk on purpose: hoisted out of the loops it costs three
+    // registers per item for the whole kernel.
+    constexpr int ITEMS = NPIX * CPP;
+    constexpr int NIT = (ITEMS + NTHR - 1) / NTHR;
+    v4i stg[NIT];
+    auto stage_load = [&](int bb, int yy, int xx, int ch) {
+        const char *src0 = p.in + (size_t)bb * (H + 2) * (W + 2) * p.in_pb + ch * CHB;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int it = min(tl + u * NTHR, ITEMS - 1);
+            const int pix = it / CPP, c = it % CPP;
+            const int py = pix / PW, px = pix % PW;
+            const int gy = min(S * yy + py, H + 1), gx = min(S * xx + px, W + 1);
+            stg[u] = *(const v4i *)(src0 + ((size_t)gy * (W + 2) + gx) * p.in_pb + c * 16);
+        }
+    };
+    auto stage_store = [&](char *dst) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int it = min(tl + u * NTHR, ITEMS - 1);
+            const int pix = it / CPP, c = it % CPP;
+            *(v4i *)(dst + pix * STRIDE + c * 16) = stg[u];
+        }
+    };
+    constexpr size_t WSTEP = (size_t)WN * NT * 1024;
+    constexpr bool DEEP = true;                  // B fragments two k-steps ahead
+    v4i b0[NT], b1[NT];
+    auto load_b01 = [&](const char *wp) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            b0[t] = *(const v4i *)(wp + t * 1024);
+            if constexpr (DEEP) b1[t] = *(const v4i *)(wp + (size_t)min(1, KS - 1) * WSTEP + t * 1024);
+            else b1[t] = b0[t];
+        }
+    };
+
+    stage_load(b, y0, x0, 0);
+    const char *wp = p.w + ((size_t)(nb * KS) * WN + wn) * NT * 1024 + lane * 16;
+    load_b01(wp);
+    stage_store(smem);
+    __syncthreads();
+    int cur = 0;                                 // slab holding the chunk about to be consumed
+    unsigned int nsat = 0;
+    const float slope = p.slope;
+    const RequantG rq = p.rq;
+    const int halo = p.out_halo;
+    const int Ho = POOL ? (H >> 1) : (S == 2 ? (H + 1) >> 1 : H), Wo = POOL ? (W >> 1) : (S == 2 ? (W + 1) >> 1 : W);
+
+    {
+        ACC acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (BF) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+                else acc[m][t] = (v4i){0, 0, 0, 0};
+            }
+        int ksg = 0;
+        const char *slab = smem;
+        auto kstep = [&](int ko) {
+            const int nx = min(ksg + (DEEP ? 2 : 1), KS - 1);
+            v4i bn[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bn[t] = *(const v4i *)(wp + (size_t)nx * WSTEP + t * 1024);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const v4i a = *(const v4i *)(slab + abase[m] + ko);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if constexpr (BF)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b0[t]),
+                                                                            acc[m][t], 0, 0, 0);
+                    else
+                        acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b0[t], acc[m][t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (DEEP) { b0[t] = b1[t]; b1[t] = bn[t]; }
+                else b0[t] = bn[t];
+            }
+            ++ksg;
+        };
+
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const bool more = ch + 1 < p.nchunks;
+            slab = smem + cur * SLAB;
+            if (more) stage_load(b, y0, x0, ch + 1);       // in flight under this chunk's k-steps
+            if constexpr (THIN) {
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) kstep(kofs[ks]);
+            } else {
+#pragma unroll 1
+                for (int sub = 0; sub < SUB; ++sub) {
+                    if (taps == 9) {
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) kstep(((tap / 3) * PW + tap % 3) * STRIDE + sub * 64);
+                    } else {
+                        kstep((PW + 1) * STRIDE + sub * 64);
+                    }
+                }
+            }
+            if (more) {
+                stage_store(smem + (cur ^ 1) * SLAB);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        // ---- epilogue
+        const int nlane = nb * BN + wn * (NT * 16) + li * NT;       // first of this lane's NT channels
+        char *outb = p.out + (size_t)b * (Ho + 2 * halo) * (Wo + 2 * halo) * p.out_pb + p.out_off;
+        const char *resb = p.res ? p.res + (size_t)b * (Ho + 2) * (Wo + 2) * p.res_pb + p.res_off : nullptr;
+
+        float biasf[NT];
+        long long biasw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (BF) { biasf[t] = p.bias_f[nlane + t]; biasw[t] = 0; }
+            else { biasw[t] = p.bias_w[nlane + t]; biasf[t] = 0.f; }
+        }
+
+        auto finish = [&](const float (&vf)[NT], const int (&vi)[NT], bool valid, int oy, int ox) {
+            char *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.out_pb;
+            if constexpr (BF) {
+                float y[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float x = vf[t] + biasf[t];
+                    y[t] = x >= 0.f ? x : x * slope;
+                }
+                if (resb && valid) {                        // the residual is a bf16 activation: exact in fp32
+                    const unsigned short *r = (const unsigned short *)(resb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * p.res_pb) + nlane;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) y[t] += __uint_as_float((unsigned int)r[t] << 16);
+                }
+                if (valid) {
+                    if (p.out_f32) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) ((float *)dst)[nlane + t] = y[t];
+                    } else {
+                        store_bf16<NT>(dst + (size_t)nlane * 2, y);
+                    }
+                }
+            } else {
+                int q[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const long long qq = requant_g(vi[t], biasw[t], rq);
+                    q[t] = y355_clamp8<long long>(qq);
+                    nsat += (valid && (long long)q[t] != qq) ? 1u : 0u;
+                }
+                if (valid) store_i8<NT>(dst + nlane, q);
+            }
+        };
+
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if constexpr (POOL) {
+                // monotone epilogue: pool the raw accumulators first
+                const int w = (wm * MT + m) * 4 + g;
+                const int wy = w / (TW / 2), wx = w % (TW / 2);
+                const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                const bool valid = (w * 4 < BM) && oy < Ho && ox < Wo;
+                float vf[NT];
+                int vi[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const ACC a = acc[m][t];
+                    if constexpr (BF) { vf[t] = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])); vi[t] = 0; }
+                    else { vi[t] = max(max(a[0], a[1]), max(a[2], a[3])); vf[t] = 0.f; }
+                }
+                finish(vf, vi, valid, oy, ox);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (wm * MT + m) * 16 + 4 * g + r;
+                    const int oy = y0 + row / TW, ox = x0 + row % TW;
+                    const bool valid = row < BM && oy < Ho && ox < Wo;
+                    float vf[NT];
+                    int vi[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (BF) { vf[t] = acc[m][t][r]; vi[t] = 0; }
+                        else { vi[t] = acc[m][t][r]; vf[t] = 0.f; }
+                    }
+                    finish(vf, vi, valid, oy, ox);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    if constexpr (!BF) {
+        if (nsat && p.ctr) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S = 1>
 struct ConvGInst {
-    static constexpr size_t LDS = (size_t)(S * (TH - 1) + 3) * (S * (TW - 1) + 3) * (CHB + 16);
+    static constexpr size_t SLAB = ((size_t)(S * (TH - 1) + 3) * (S * (TW - 1) + 3) * (CHB + 16) + 15) / 16 * 16;
+    static constexpr bool EIGHT = (WM * WN == 8);
+    static constexpr size_t LDS = EIGHT ? 2 * SLAB : SLAB;
     static void launch(const ConvGParams &p, int nblocks, hipStream_t s) {
-        hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(256), LDS, s, p);
+        if constexpr (EIGHT) {
+            // one tile per workgroup (persistent workgroups measured slower: slim fp32, B = 64, 58.2 k vs 63.8 k img/s)
+            hipLaunchKernelGGL((convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(512),
+                               p.nchunks > 1 ? 2 * SLAB : SLAB, s, p, nblocks);
+        } else {
+            hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(256), SLAB, s, p);
+        }
     }
     static int prepare() {
-        return (int)hipFuncSetAttribute((const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        const void *fn;
+        if constexpr (EIGHT) fn = (const void *)convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>;
+        else fn = (const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>;
+        return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     static constexpr ConvGInfo info() {
         return ConvGInfo{BF ? 1 : 0, CHB, BN, TH, TW, POOL ? 1 : 0, WM, WN, BN / 16 / WN, S, LDS, &launch, &prepare};
@@ -321,14 +611,15 @@ struct ConvGInst {
 #define CONVG_SET(BF)                                                                                   \
     ConvGInst<BF, 32, 32, 16, 52, true, 4, 1>::info(),     /* 0 thin, pooled     (conv2)            */ \
     ConvGInst<BF, 32, 64, 13, 26, false, 2, 2>::info(),    /* 1 thin                                */ \
-    ConvGInst<BF, 64, 64, 13, 26, false, 2, 2>::info(),    /* 2 64 B chunks      (conv3_1)          */ \
-    ConvGInst<BF, 64, 64, 26, 26, true, 4, 1>::info(),     /* 3 64 B, pooled     (conv3_2, conv4_2) */ \
-    ConvGInst<BF, 128, 128, 13, 26, false, 2, 2>::info(),  /* 4 128 B chunks     (conv4_1)          */ \
-    ConvGInst<BF, 256, 256, 13, 13, false, 1, 4>::info(),  /* 5 256 B chunks     (conv5..7)         */ \
+    ConvGInst<BF, 64, 64, 13, 26, false, 4, 2>::info(),    /* 2 64 B chunks      (conv3_1)          */ \
+    ConvGInst<BF, 64, 64, 26, 26, true, 8, 1>::info(),     /* 3 64 B, pooled     (conv3_2, conv4_2) */ \
+    ConvGInst<BF, 128, 128, 13, 26, false, 4, 2>::info(),  /* 4 128 B chunks     (conv4_1)          */ \
+    ConvGInst<BF, 256, 256, 13, 13, false, 2, 4>::info(),  /* 5 256 B chunks     (conv5..7)         */ \
     ConvGInst<BF, 256, 64, 13, 13, false, 4, 1>::info(),   /* 6 256 B, few couts (pred)             */ \
     ConvGInst<BF, 64, 64, 8, 16, false, 4, 1>::info(),     /* 7 small tiles, any shape              */ \
     ConvGInst<BF, 64, 64, 8, 16, true, 4, 1>::info(),      /* 8 small tiles, pooled                 */ \
-    ConvGInst<BF, 64, 64, 8, 16, false, 4, 1, 2>::info()   /* 9 stride 2 (darknet53 down-sampling)  */
+    ConvGInst<BF, 64, 64, 8, 16, false, 4, 1, 2>::info(),  /* 9 stride 2 (darknet53 down-sampling)  */ \
+    ConvGInst<BF, 128, 64, 13, 13, false, 4, 2>::info()    /* 10 13x13 maps, 64 couts per workgroup: fills the chip at small batches */
 
 static const ConvGInfo g_convg[2][Y355_G_COUNT] = {{CONVG_SET(false)}, {CONVG_SET(true)}};
 
@@ -345,7 +636,7 @@ int y355_prepare_convg(void) {
 
 // Pick the instantiation for a layer: `in_pb` bytes per input pixel (multiple of 32), real output
 // channels `cout`, pooled or not, on an H x W map.
-int y355_convg_select(int in_pb, int cout, int pool, int H, int W, int stride) {
+int y355_convg_select(int in_pb, int cout, int pool, int H, int W, int stride, int batch_hint) {
     if (stride == 2) return (in_pb % 64 == 0 && !pool) ? 9 : -1;
     const bool small = (H < 13 || W < 13);
     if (in_pb == 32) return pool ? 0 : 1;
@@ -353,7 +644,11 @@ int y355_convg_select(int in_pb, int cout, int pool, int H, int W, int stride) {
     if (small) return 7;
     if (cout <= 64) return (in_pb % 256 == 0) ? 6 : 2;
     if (cout <= 128) return (in_pb % 128 == 0) ? 4 : 2;
-    if (in_pb % 256 == 0) return 5;
+    if (in_pb % 256 == 0) {
+        // 256 output channels per workgroup on 13x13 tiles: too few workgroups for 256 CUs on small maps at small batches
+        const long wgs = (long)((H + 12) / 13) * ((W + 12) / 13) * ((cout + 255) / 256) * (batch_hint > 0 ? batch_hint : 1 << 20);
+        return wgs >= 192 ? 5 : 10;
+    }
     return (in_pb % 128 == 0) ? 4 : 2;
 }
 

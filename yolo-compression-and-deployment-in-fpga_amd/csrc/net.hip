@@ -491,7 +491,7 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
             rc = nmalloc(h, (void **)&h->w0_dev, 2048, true);
         } else {
             const Tensor &ti = h->T[o.in];
-            L.kid = y355_convg_select(in_kbytes(h, o), L.cout, o.pool, ti.H, ti.W, o.stride2 ? 2 : 1);
+            L.kid = y355_convg_select(in_kbytes(h, o), L.cout, o.pool, ti.H, ti.W, o.stride2 ? 2 : 1, h->cfg.max_batch);
             if (L.kid < 0) { rc = y355_fail(Y355_EINVAL, "no convolution kernel for a layer of this graph"); break; }
             const ConvGInfo &ki = *y355_convg_kernel(h->bf, L.kid);
             if (in_kbytes(h, o) % ki.chb) { rc = y355_fail(Y355_EINVAL, "input channels not a multiple of the kernel's chunk"); break; }

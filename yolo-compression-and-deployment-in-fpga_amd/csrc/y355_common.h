@@ -286,10 +286,10 @@ struct ConvGInfo {
     void (*launch)(const ConvGParams &p, int nblocks, hipStream_t s);
     int (*prepare)(void);
 };
-#define Y355_G_COUNT 10
+#define Y355_G_COUNT 11
 const ConvGInfo *y355_convg_kernel(int bf, int id);
 int y355_prepare_convg(void);
-int y355_convg_select(int in_pb, int cout, int pool, int H, int W, int stride = 1);
+int y355_convg_select(int in_pb, int cout, int pool, int H, int W, int stride = 1, int batch_hint = 0);
 int y355_convg_ksteps(const ConvGInfo &ki, int in_pb, int taps);
 size_t y355_convg_packed_bytes(const ConvGInfo &ki, int in_pb, int taps, int cout_pad);
 void y355_convg_pack(const ConvGInfo &ki, const float *w_f, const int8_t *w_q, int cout, int cin, int ksize,
