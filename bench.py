@@ -184,31 +184,62 @@ def measure_net(args):
             sc = g / np.sqrt(var + 1e-5)
             w, b = w * sc[:, None, None, None], (b - mu) * sc + be
         folded.append((w.astype(np.float32), b.astype(np.float32)))
-    fnet = Net(arch, [H, W], classes, anchors, 0.01, 0.5, max_batch=B, device=dev, dtype="bf16")
-    for i, (w, b) in enumerate(folded):
-        fnet.load_layer(i, w, b)
-    net = fnet
+    # `--streams` handles on as many HIP streams, steps alternating (as the headline): the head / NMS of batch i runs beside
+    # the convolutions of batch i + 1.  The one-stream figure (latency of a batch) is reported next to it.
+    ns = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    quant = prep.quantize_folded(folded) if dtype == "int8" else None
+    sa_in = sa = None
     if dtype == "int8":
+        fnet = Net(arch, [H, W], classes, anchors, 0.01, 0.5, max_batch=B, device=dev, dtype="bf16")
+        for i, (w, b) in enumerate(folded):
+            fnet.load_layer(i, w, b)
         sa_in, sa = fnet.calibration_exponents(synth.make_images(1, 1, H, W))
-        net = Net(arch, [H, W], classes, anchors, 0.01, 0.5, max_batch=B, device=dev, dtype="int8")
-        for i, q in enumerate(prep.quantize_folded(folded)):
-            net.load_layer_i8(i, q["q_w"], q["q_b"], q["e_w"], q["e_b"])
-        net.set_act_exponents(sa_in, sa)
+        del fnet
+    nets = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            net = Net(arch, [H, W], classes, anchors, 0.01, 0.5, max_batch=B, device=dev, dtype=dtype)
+            if dtype == "int8":
+                for i, q in enumerate(quant):
+                    net.load_layer_i8(i, q["q_w"], q["q_b"], q["e_w"], q["e_b"])
+                net.set_act_exponents(sa_in, sa)
+            else:
+                for i, (w, b) in enumerate(folded):
+                    net.load_layer(i, w, b)
+        nets.append(net)
+    net = nets[0]
     x = torch.from_numpy(synth.make_images(1000, B, H, W)).to(dev)
-    for _ in range(args.warmup):
-        net.forward_device(x)
+    bufs = [tuple(torch.empty_like(t) for t in net._buffers(B)) for _ in range(2 * ns)]
+    torch.cuda.synchronize()
+
+    def run(n, k=ns):
+        out = None
+        for i in range(n):
+            with torch.cuda.stream(streams[i % k]):
+                out = nets[i % k].forward_device(x, 0, bufs[i % (2 * k)])
+        return out
+
+    run(max(args.warmup, ns))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = net.forward_device(x)
+    out = run(args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    net.profile(True)
-    acc = None
-    for _ in range(5):
-        net.forward_device(x)
-        ms = np.array(net.profile_ms())
-        acc = ms if acc is None else acc + ms
+    run(2, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, 1)
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t0
+    with torch.cuda.stream(streams[0]):
+        net.profile(True)
+        acc = None
+        for _ in range(5):
+            net.forward_device(x)
+            ms = np.array(net.profile_ms())
+            acc = ms if acc is None else acc + ms
+        net.profile(False)
     ms = acc / 5
     mmac = sum(LAYER_MMAC) if arch == "slim_yolo_v2" else sum(TINY_MMAC)
     peak = PEAK_I8_DENSE if dtype == "int8" else PEAK_BF16_DENSE
@@ -220,7 +251,8 @@ def measure_net(args):
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%s %s, batch %d, 416x416, %d classes, conf 0.01" % (arch, dtype, B, classes),
-                   "detections_per_step": int(out[3][:B].sum().item())},
+                   "streams_per_gpu": ns, "detections_per_step": int(out[3][:B].sum().item())},
+        "one_stream": {"value": round(B * args.steps / dt1, 1), "unit": "images/sec", "ms_per_step": round(dt1 / args.steps * 1e3, 4)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                      "frac": round(achieved * 1e12 / peak, 4), "traffic": None,
                      "kernel": "convg_kernel, all conv launches of the graph (%.1f MMAC/image)" % mmac,
@@ -612,6 +644,7 @@ def main():
                 r = measure_net(a2)
                 oc[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "images/sec",
                           "ms_per_step": r["ms_per_step"], "steps": r["steps"], "dtype": r["dtype"],
+                          "streams_per_gpu": r["config"]["streams_per_gpu"], "one_stream": r["one_stream"],
                           "conv_roofline_frac": r["roofline"]["frac"], "conv_achieved_tflops": r["roofline"]["achieved"],
                           "peak_tflops": r["roofline"]["peak"]}
             res["other_configs"] = oc
