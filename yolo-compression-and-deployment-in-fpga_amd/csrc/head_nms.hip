@@ -428,6 +428,10 @@ __device__ __forceinline__ bool suppresses(const float4 a, float area_a, const f
 //     buffer (and every wave at its end) is flushed to the image's global list with one global atomic;
 //   * the next bin row's range is read while the current row is walked.
 #define WAVE_EDGE_CAP (WG_EDGE_CAP / 16)
+#ifndef Y355_PAIRS_G
+#define Y355_PAIRS_G 2             // workgroups per image: 4 finish a batch no sooner (the heavy waves set the time) but hold twice the CUs,
+                                   // which the convolutions of the other streams cannot use meanwhile (3-stream: 227 k -> 239 k img/s)
+#endif
 __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const HeadWork wk, float thr) {
     extern __shared__ __attribute__((aligned(16))) char plds[];
     float4 *sbox = (float4 *)plds;                                   // [CAP]
@@ -438,7 +442,13 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     const int b = blockIdx.y;
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 0);
     const int M = wk.count[b];
-    if ((int)blockIdx.x * 64 >= M) return;
+    // L lanes share a candidate (each takes every L-th group of four partners of a bin row) when the image has few
+    // candidates: 845 of them are 14 waves, 3-4 per workgroup, one per SIMD -- with L = 4 every SIMD gets four
+    const int G = (int)gridDim.x;
+    int L = 1;
+    while (L < 8 && M * 2 * L <= 16 * G * 64) L *= 2;
+    const int nruns = (M * L + 63) >> 6;                    // 64-lane runs of the image
+    if ((int)blockIdx.x >= nruns) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int A = p.group_by_area ? NGROUP : p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // candidate groups, bin grid
     {
@@ -475,20 +485,10 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     }
     __syncthreads();
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 1);
-    // 64-candidate runs are dealt round-robin to the image's workgroups: neighbours in (group, bin)
-    // order have windows of similar size, so a wave stays uniform while every workgroup gets the same
-    // mix of cheap and expensive waves
-    const int wave = tid >> 6;
-    const int i = ((wave * (int)gridDim.x + (int)blockIdx.x) << 6) + lane;
-    const bool vi = i < M;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fast = thr >= 1e-4f && thr < 1e4f;
     const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
     const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
-    const float4 bi = vi ? sbox[i] : make_float4(0, 0, 0, 0);
-    const int cti = vi ? scls[i] : -1;                     // class | group << 16: equal classes <=> equal low halves
-    const int ci = cti & 0xffff;
-    const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
-    const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
     bool lost = false;
     unsigned int *wedge = sedge + wave * WAVE_EDGE_CAP;
     unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
@@ -505,6 +505,17 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         }
         wcount = 0;
     };
+    // 64-lane runs are dealt round-robin to the image's workgroups and their waves: neighbours in (group, bin) order have
+    // windows of similar size, so a wave stays uniform while every workgroup gets the same mix of cheap and expensive runs
+    for (int run = wave * G + (int)blockIdx.x; run < nruns; run += 16 * G) {
+    const int slot = (run << 6) + lane;
+    const int i = slot / L, sub = slot % L;
+    const bool vi = i < M;
+    const float4 bi = vi ? sbox[i] : make_float4(0, 0, 0, 0);
+    const int cti = vi ? scls[i] : -1;                     // class | group << 16: equal classes <=> equal low halves
+    const int ci = cti & 0xffff;
+    const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
+    const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
     // the reference's predicate (slim_yolo_v2.py:159-171) for partner q of candidate i, branch-free; `ok` = q is a real
     // partner of this lane's trip
     auto test = [&](int q, bool ok, const float4 bj, const int ctj) {
@@ -537,8 +548,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     };
     // Every loop below is WAVE-UNIFORM (bounds through __any, lanes without work carry ok = false): the edge count of the
     // wave's buffer is a scalar only if all lanes see every update.
-    auto walk = [&](int q0, int q1) {                      // partners [q0, q1) of this lane (empty: q0 >= q1)
-        for (int q = q0; __any(q < q1); q += 4) {
+    auto walk = [&](int q0, int q1) {                      // partners [q0, q1) of this candidate (empty: q0 >= q1)
+        for (int q = q0 + 4 * sub; __any(q < q1); q += 4 * L) {
 #ifdef Y355_EXPERIMENTS
             ++dbg_trips;
 #endif
@@ -595,11 +606,12 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
                 for (int t0 = 0; t0 < nt; ++t0) {
                     if (wcount > WAVE_EDGE_CAP - 64) flush();
                     const int q = tl[t0];
-                    test(q, tiny_i, sbox[q], scls[q]);
+                    test(q, tiny_i && sub == 0, sbox[q], scls[q]);
                 }
             }
         }
     }
+    }   // runs
 #ifdef Y355_EXPERIMENTS
     if (wk.stamps) {                                   // per-wave end of the walk and the wave-wide trip count (max over lanes)
         int mt = dbg_trips;
@@ -876,6 +888,6 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     }
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);
-    hipLaunchKernelGGL(pairs_kernel, dim3(NMS_CAP / 1024, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
+    hipLaunchKernelGGL(pairs_kernel, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
     hipLaunchKernelGGL(resolve_emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk, p.nms_thresh);
 }
