@@ -428,10 +428,21 @@ __device__ __forceinline__ bool suppresses(const float4 a, float area_a, const f
 //     buffer (and every wave at its end) is flushed to the image's global list with one global atomic;
 //   * the next bin row's range is read while the current row is walked.
 #define WAVE_EDGE_CAP (WG_EDGE_CAP / 16)
+__device__ __forceinline__ float raw_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float raw_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 #ifndef Y355_PAIRS_G
 #define Y355_PAIRS_G 2             // workgroups per image: 4 finish a batch no sooner (the heavy waves set the time) but hold twice the CUs,
                                    // which the convolutions of the other streams cannot use meanwhile (3-stream: 227 k -> 239 k img/s)
 #endif
+template <bool FAST>
 __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const HeadWork wk, float thr) {
     extern __shared__ __attribute__((aligned(16))) char plds[];
     float4 *sbox = (float4 *)plds;                                   // [CAP]
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     __syncthreads();
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool fast = thr >= 1e-4f && thr < 1e4f;
+    constexpr bool fast = FAST;                            // 1e-4 <= thr < 1e4: the pruning bounds hold (host-checked)
     const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
     const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
     bool lost = false;
@@ -527,9 +538,11 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
                              (fminf(ai, aj) <= thr_lo * fmaxf(ai, aj));
             cand = cand & !(far & (ai + aj >= AREA_MIN));
         }
-        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-        const float iw = fmaxf(1e-28f, xx2 - xx1), ih = fmaxf(1e-28f, yy2 - yy1);
+        // v_max / v_min issued as they are: hipcc quiets BOTH operands of every fmaxf / fminf first (8 extra v_max per test);
+        // on numbers -- the coordinates are clamped to [0, 1] by the decode -- the bare instructions give the same result
+        const float xx1 = raw_max(bi.x, bj.x), yy1 = raw_max(bi.y, bj.y);
+        const float xx2 = raw_min(bi.z, bj.z), yy2 = raw_min(bi.w, bj.w);
+        const float iw = raw_max(1e-28f, xx2 - xx1), ih = raw_max(1e-28f, yy2 - yy1);
         const float inter = iw * ih, den = ai + aj - inter;
         const float qv = inter * __builtin_amdgcn_rcpf(den);
         const bool sure = fast & (den > 1e-30f) & (den < 1e30f) & ((qv > q_hi) | (qv < q_lo));
@@ -841,7 +854,8 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
 unsigned long long *y355_nms_stamps_dev = nullptr;
 
 int y355_prepare_head(void) {
-    return (int)hipFuncSetAttribute((const void *)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
+    if (int e = (int)hipFuncSetAttribute((const void *)pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS)) return e;
+    return (int)hipFuncSetAttribute((const void *)pairs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
 }
 
 void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid) {
@@ -888,6 +902,9 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
     }
     hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     if (mid) (void)hipEventRecord(mid, s);
-    hipLaunchKernelGGL(pairs_kernel, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
+    if (p.nms_thresh >= 1e-4f && p.nms_thresh < 1e4f)
+        hipLaunchKernelGGL(pairs_kernel<true>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
+    else
+        hipLaunchKernelGGL(pairs_kernel<false>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
     hipLaunchKernelGGL(resolve_emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk, p.nms_thresh);
 }
