@@ -446,9 +446,9 @@ template <bool FAST>
 __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const HeadWork wk, float thr) {
     extern __shared__ __attribute__((aligned(16))) char plds[];
     float4 *sbox = (float4 *)plds;                                   // [CAP]
-    int *scls = (int *)(plds + NMS_CAP * 16);                        // [CAP] class | group << 16
-    int *sbin = (int *)(plds + NMS_CAP * 20);                        // [CAP + 8]
-    unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 20 + (NMS_CAP + 8) * 4);   // [16][WAVE_EDGE_CAP]
+    int2 *scls = (int2 *)(plds + NMS_CAP * 16);                      // [CAP] (class | group << 16, area of the box as computed here)
+    int *sbin = (int *)(plds + NMS_CAP * 24);                        // [CAP + 8]
+    unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 24 + (NMS_CAP + 8) * 4);   // [16][WAVE_EDGE_CAP]
     __shared__ float as[MAXA * 4];                         // per-group extents
     const int b = blockIdx.y;
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 0);
@@ -485,7 +485,10 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
 #pragma unroll
         for (int u = 0; u < NMS_CAP / 1024; ++u) {
             const int q = tid + u * 1024;
-            if (q < M) { sbox[q] = vb[u]; scls[q] = (vc[u] & 0xffff) | (vt[u] << 16); }
+            if (q < M) {
+                sbox[q] = vb[u];
+                scls[q] = make_int2((vc[u] & 0xffff) | (vt[u] << 16), __float_as_int((vb[u].z - vb[u].x) * (vb[u].w - vb[u].y)));
+            }
         }
 #pragma unroll
         for (int u = 0; u <= NMS_CAP / 1024; ++u) {
@@ -518,26 +521,26 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     };
     // 64-lane runs are dealt round-robin to the image's workgroups and their waves: neighbours in (group, bin) order have
     // windows of similar size, so a wave stays uniform while every workgroup gets the same mix of cheap and expensive runs
+#if defined(Y355_ABL_NMS) && (Y355_ABL_NMS & 2)
+    if (false)                                      // timing ablation (WRONG RESULTS): no pair walk
+#endif
     for (int run = wave * G + (int)blockIdx.x; run < nruns; run += 16 * G) {
     const int slot = (run << 6) + lane;
     const int i = slot / L, sub = slot % L;
     const bool vi = i < M;
     const float4 bi = vi ? sbox[i] : make_float4(0, 0, 0, 0);
-    const int cti = vi ? scls[i] : -1;                     // class | group << 16: equal classes <=> equal low halves
+    const int cti = vi ? scls[i].x : -1;                   // class | group << 16: equal classes <=> equal low halves
     const int ci = cti & 0xffff;
     const float wi = bi.z - bi.x, hi = bi.w - bi.y, ai = wi * hi;
     const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
     // the reference's predicate (slim_yolo_v2.py:159-171) for partner q of candidate i, branch-free; `ok` = q is a real
     // partner of this lane's trip
-    auto test = [&](int q, bool ok, const float4 bj, const int ctj) {
-        const float wj = bj.z - bj.x, hj = bj.w - bj.y, aj = wj * hj;
-        bool cand = ok && (q > i) && ((ctj & 0xffff) == ci);
-        if (fast) {
-            const float dx = fabsf(cxi - 0.5f * (bj.x + bj.z)), dy = fabsf(cyi - 0.5f * (bj.y + bj.w));
-            const bool far = (dx >= kr * (wi + wj) + PRUNE_EPS) | (dy >= kr * (hi + hj) + PRUNE_EPS) |
-                             (fminf(ai, aj) <= thr_lo * fmaxf(ai, aj));
-            cand = cand & !(far & (ai + aj >= AREA_MIN));
-        }
+    auto test = [&](int q, bool ok, const float4 bj, const int2 ctj) {
+        // No pruning test here: the window already holds only bins a suppressor can sit in, and a pair the bounds would rule
+        // out evaluates to ovr <= thr in the formula below as well (that is what the bounds prove) -- in branch-free code the
+        // extra test was 25 instructions that saved none.  The partner's area comes from LDS (computed once per candidate).
+        const float aj = __int_as_float(ctj.y);
+        const bool cand = ok && (q > i) && ((ctj.x & 0xffff) == ci);
         // v_max / v_min issued as they are: hipcc quiets BOTH operands of every fmaxf / fminf first (8 extra v_max per test);
         // on numbers -- the coordinates are clamped to [0, 1] by the decode -- the bare instructions give the same result
         const float xx1 = raw_max(bi.x, bj.x), yy1 = raw_max(bi.y, bj.y);
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
             ++dbg_trips;
 #endif
             float4 bj[4];
-            int cj[4];
+            int2 cj[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int qq = max(min(q + u, q1 - 1), 0);
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     if (lost) wk.nedges[b * 2 + 1] = 1;
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 7);
 }
-#define PAIRS_LDS (NMS_CAP * 20 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
+#define PAIRS_LDS (NMS_CAP * 24 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
 
 // ---- resolve_emit_kernel: one workgroup per image.
 // Greedy NMS = for every candidate, "kept unless an EARLIER (score desc, anchor index asc) kept
@@ -768,6 +771,9 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
             if (nround == 1) NSTAMP(2, blockIdx.x, 4);
             if (nround == 2) NSTAMP(2, blockIdx.x, 5);
             if (!again && wk.stamps && tid == 0 && blockIdx.x < 256) wk.stamps[((2 * 256 + blockIdx.x) * 8) + 6] = wk.stamps[((2 * 256 + blockIdx.x) * 8) + 5] + nround;
+#endif
+#if defined(Y355_ABL_NMS) && (Y355_ABL_NMS & 1)
+            break;                                  // timing ablation (WRONG RESULTS): one round only
 #endif
             if (!again) break;
         }
