@@ -586,13 +586,18 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         // own group and bin row (same formula as head_kernel); lanes past M walk nothing (a_i = A)
         const int a_i = vi ? (cti >> 16) : A;
         const int by_i = min(Hs - 1, max(0, (int)(cyi * (float)Hs)));
-        for (int a2 = 0; a2 < A; ++a2) {
-            const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1], amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
+        // candidates are sorted by group: lane 0 holds the run's lowest one, and lower groups only hold positions < i
+        const int a_lo = __builtin_amdgcn_readfirstlane(a_i);
+        for (int a2 = a_lo; a2 < A; ++a2) {
+            const float amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
             if (amax < amin) continue;                         // no candidate of this group (uniform)
-            bool act = a2 >= a_i;                              // lower groups only hold positions < i
+            const bool prune = fast && (ai + amin >= AREA_MIN);
+            bool act = a2 >= a_i;
+            if (prune && (ai <= thr_lo * amin || amax <= thr_lo * ai)) act = false;    // area ratio rules the group out
+            if (!__any(act)) continue;
             int bx0 = 0, bx1 = Ws - 1, by0 = 0, by1 = Hs - 1;
-            if (fast && (ai + amin >= AREA_MIN)) {
-                if (ai <= thr_lo * amin || amax <= thr_lo * ai) act = false;     // area ratio rules the group out
+            if (prune) {
+                const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1];
                 const float rx = kr * (wi + wmax) + PRUNE_EPS, ry = kr * (hi + hmax) + PRUNE_EPS;
                 bx0 = max(0, (int)floorf((cxi - rx) * (float)Ws));
                 bx1 = min(Ws - 1, (int)floorf((cxi + rx) * (float)Ws));
