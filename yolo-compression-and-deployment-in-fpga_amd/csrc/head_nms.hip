@@ -674,6 +674,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     __shared__ __attribute__((aligned(16))) unsigned char blocked[NMS_CAP];
     __shared__ unsigned int skey[2 * NMS_CAP];        // NMS order key of a candidate: (score bits, ~anchor index); later the emit scratch
     __shared__ unsigned long long keepn[64];          // survivors by anchor index
+    __shared__ int pend[2];
     __shared__ int wbase[64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     NSTAMP(2, blockIdx.x, 0);
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
         skey[2 * pos + 1] = pos < M ? (unsigned int)co[pos] : 0u;
     }
     if (tid < 64) keepn[tid] = 0ull;
+    if (tid < 2) pend[tid] = 0;
     __syncthreads();
     if (!brute) {
         // The first RE_REG entries of a thread's edge slots (slot k of thread tid = list entry tid + 1024 k) live in registers,
@@ -729,8 +731,10 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
         __syncthreads();
         NSTAMP(2, blockIdx.x, 1);
         // one step of A for an edge whose endpoint states were read as (sa, sc): returns the edge, or RE_NONE once it retires
-        auto settle = [&](unsigned int e, int sa, int sc) {
-            if (e == RE_NONE || sc == 2 || sa == 2) return RE_NONE;             // settled without this edge
+        // (the later endpoint's state is not read: an edge whose later endpoint already died only marks it blocked a few more
+        // times, which nobody looks at -- half the LDS gathers of a round)
+        auto settle = [&](unsigned int e, int sa) {
+            if (e == RE_NONE || sa == 2) return RE_NONE;                           // the earlier endpoint died: the edge is void
             const int c = (int)(e & 0xfffu);
             if (sa == 1) { state[c] = 2; return RE_NONE; }                        // earlier endpoint kept: the later one dies
             blocked[c] = 1;                                                        // earlier endpoint undecided
@@ -741,18 +745,15 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
         for (;;) {
             ++nround;
             {
-                int sa[RE_REG], sc[RE_REG];
+                int sa[RE_REG];
 #pragma unroll
-                for (int k = 0; k < RE_REG; ++k) {                                  // RE_NONE reads candidate 4095: harmless
-                    sa[k] = state[ed[k] >> 12];
-                    sc[k] = state[ed[k] & 0xfffu];
-                }
+                for (int k = 0; k < RE_REG; ++k) sa[k] = state[ed[k] >> 12];      // RE_NONE reads candidate 4095: harmless
 #pragma unroll
-                for (int k = 0; k < RE_REG; ++k) ed[k] = settle(ed[k], sa[k], sc[k]);
+                for (int k = 0; k < RE_REG; ++k) ed[k] = settle(ed[k], sa[k]);
             }
             for (int k = RE_REG; k < kmax; ++k) {                                   // rare: the LDS-resident tail
                 const unsigned int e = sedge[tid + (k - RE_REG) * 1024];
-                if (e != RE_NONE) sedge[tid + (k - RE_REG) * 1024] = settle(e, state[e >> 12], state[e & 0xfffu]);
+                if (e != RE_NONE) sedge[tid + (k - RE_REG) * 1024] = settle(e, state[e >> 12]);
             }
             __syncthreads();
 #ifdef Y355_EXPERIMENTS
@@ -771,7 +772,11 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
                 *(unsigned int *)&state[4 * tid] = st;
             }
             if (bl) *(unsigned int *)&blocked[4 * tid] = 0u;
-            const int again = __syncthreads_or(pending);
+            // "anybody still undecided?" through one LDS word per round parity and ONE barrier (was __syncthreads_or)
+            if (pending) pend[nround & 1] = 1;
+            __syncthreads();
+            const int again = pend[nround & 1];
+            if (tid == 0) pend[(nround + 1) & 1] = 0;      // written again only after the next round's first barrier
 #ifdef Y355_EXPERIMENTS
             if (nround == 1) NSTAMP(2, blockIdx.x, 4);
             if (nround == 2) NSTAMP(2, blockIdx.x, 5);
