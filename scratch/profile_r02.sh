@@ -13,3 +13,7 @@ cp gpurun_out/pmc_traffic.json gpurun_out/r02_pmc_traffic.json
 bash scratch/pmc_sq.sh r02 > gpurun_out/r02_sq.log 2>&1
 head -16 gpurun_out/r02_kernel_stats_one_stream.csv | cut -c1-150
 tail -2 gpurun_out/r02_pmc_traffic.log
+for w in slim_fp32 tiny_int8; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_stats_$w -- python3 bench.py --workload $w --steps 10 --warmup 3 --streams 1 > gpurun_out/r02_bench_$w.json 2> gpurun_out/r02_stats_$w.log
+  cp gpurun_out/r02_stats_$w/*/*_kernel_stats.csv gpurun_out/r02_kernel_stats_$w.csv
+done
