@@ -422,3 +422,35 @@ def test_resize_stage_matches_oracle(src, dst):
         for s, t in zip(u, v):
             assert np.array_equal(s, t)
     eng.close()
+
+
+# ---------------------------------------------------------------- NMS kernels in isolation (pairs + rounds), round-2 rewrite
+@pytest.mark.gpu
+@pytest.mark.parametrize("nms_thr", [0.5, 0.3, 0.75, 5e-5])
+def test_nms_sweep_on_the_engines_own_candidates(nms_thr):
+    """The round-2 pair walk (two workgroups per image, 64-lane runs in passes, L lanes per candidate on small images,
+    branch-free test, per-wave edge buffers) and the register-resident rounds, against the oracle's greedy NMS
+    (models/slim_yolo_v2.py:145-210, tie order (score desc, anchor index asc)) run on the SAME decoded candidates: exact
+    equality.  Densities: every anchor a candidate (3380: two passes of runs), about a third, a handful (L = 8);
+    nms_thresh 5e-5 is outside the range the pruning bounds hold for (the un-pruned kernel instantiation)."""
+    from yolo355.engine import Engine
+    B, C = 3, 2
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=C))
+    eng = Engine([416, 416], C, synth.ANCHOR_SIZE_MASK, conf_thresh=0.01, nms_thresh=nms_thr, max_batch=B)
+    eng.load_quantized(ql)
+    eng.calibrate(synth.make_images(1, 1, 416, 416), [prep.RangeTracker() for _ in range(11)])
+    x = synth.make_images(1000, B, 416, 416)
+    seen = []
+    for conf in (0.01, 0.45, 0.62):
+        eng.set_thresholds(conf, nms_thr)
+        dets = eng.forward(x, tap=True)
+        cb, cs, cc = eng.candidates(B)
+        for i in range(B):
+            prob = np.zeros((cb.shape[1], C), np.float32)
+            prob[np.arange(cb.shape[1]), cc[i]] = cs[i]
+            ref = O.postprocess(cb[i], prob, conf, nms_thr, C)[:3]
+            seen.append(int((cs[i] >= np.float32(conf)).sum()))
+            assert len(ref[1]) == len(dets[i][1]), (conf, i, len(ref[1]), len(dets[i][1]))
+            assert np.array_equal(ref[0], dets[i][0]) and np.array_equal(ref[1], dets[i][1]) and np.array_equal(ref[2], dets[i][2]), (conf, i)
+    assert max(seen) == 3380 and min(seen) < 400, seen          # the sweep really covers dense and sparse images
+    eng.close()

@@ -86,8 +86,8 @@ __device__ __forceinline__ void store_bytes2(int8_t *dst, const int (&q)[NT]) {
     }
 }
 
-template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvParams p, const int total_tiles) {
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES, int MINB = 1>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void conv3x3_i8_v2_kernel(const ConvParams p, const int total_tiles) {
     constexpr int NW = WM * WN;                                    // waves per workgroup (4 or 8)
     constexpr int NTHR = NW * 64;
     using G = KGeom2<CIN>;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_i8_v2_kernel(const ConvP
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES>
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, bool WRES, int MINB = 1>
 struct ConvInst2 {
     using G = KGeom2<CIN>;
     static constexpr int PWL = y355_lds_pitch(G::CC, TW + 2);
@@ -514,7 +514,7 @@ struct ConvInst2 {
 #endif
     }
     static int prepare() {
-        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>,
+        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES, MINB>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch());
     }
     static bool launch(const ConvParams &p, hipStream_t s) {
@@ -524,17 +524,20 @@ struct ConvInst2 {
         // only one fits a CU whatever its LDS (a 512-workgroup grid would run as two sequential rounds)
         int per_cu = (int)((160 * 1024) / LDS);
         per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-        if (WM * WN == 8) per_cu = 1;
+        if (WM * WN == 8 && MINB < 4) per_cu = 1;          // (MINB = waves per SIMD the kernel was compiled for: 4 = two 8-wave workgroups per CU)
         int grid = 256 * per_cu;
         if (grid > total) grid = total;
-        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES>), dim3(grid), dim3(WM * WN * 64), lds_launch(), s, p, total);
+        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES, MINB>), dim3(grid), dim3(WM * WN * 64), lds_launch(), s, p, total);
         return true;
     }
 };
 
 // must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
 using V2_CONV2 = ConvInst2<16, 32, 16, 52, true, 4, 1, true>;
-using V2_CONV3_1 = ConvInst2<32, 64, Y355_C31_TH, Y355_C31_TW, false, Y355_C31_WM, Y355_C31_WN, true>;
+#ifndef Y355_C31_OCC
+#define Y355_C31_OCC 1
+#endif
+using V2_CONV3_1 = ConvInst2<32, 64, Y355_C31_TH, Y355_C31_TW, false, Y355_C31_WM, Y355_C31_WN, true, Y355_C31_OCC>;
 #if Y355_C32_WRES
 using V2_CONV3_2 = ConvInst2<64, 64, 26, 26, true, 8, 1, true>;      // weights (36 KiB) resident: no per-step barrier, no weight re-streaming
 #else
