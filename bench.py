@@ -92,12 +92,15 @@ def sparse_fixture(args, dev, streams, x):
             return engines[i % len(engines)].forward_device(x, 0, bufs[i % len(bufs)])
     for i in range(args.warmup):
         out = run(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = run(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(max(1, min(args.repeats, 5))):       # median of a few regions of exactly `steps` steps, like `value`
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = run(i)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     return {"value": round(B * args.steps / dt, 1), "unit": "images/sec", "conf_thresh": 0.1,
             "weights": "make_weights(2, pred_gain=400, obj_bias=-4)", "detections_per_step": int(out[3][:B].sum().item())}
 
