@@ -454,3 +454,40 @@ def test_nms_sweep_on_the_engines_own_candidates(nms_thr):
             assert np.array_equal(ref[0], dets[i][0]) and np.array_equal(ref[1], dets[i][1]) and np.array_equal(ref[2], dets[i][2]), (conf, i)
     assert max(seen) == 3380 and min(seen) < 400, seen          # the sweep really covers dense and sparse images
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tail", "lds_overflow", "list_overflow"])
+def test_nms_edge_list_limits(case):
+    """The suppressing-pair lists past their fast paths: more than 7168 pairs per image (the rounds keep the rest in LDS),
+    more than 28 672 (the sorted walk takes over), more than the global list holds (pairs_kernel flags the image).  Crafted
+    int8 prediction maps: huge tw / th make every chosen anchor's box the whole image, so all chosen anchors of a class
+    suppress each other; expected = the oracle's greedy NMS (one survivor per class, ties to the lower anchor index)."""
+    from yolo355.engine import Engine
+    C, A, sa_pred = 2, 5, 2
+    size = 416 if case == "list_overflow" else 208
+    hs = size // 16
+    rng = np.random.RandomState(7)
+    pq = np.zeros((2, A * (5 + C), hs, hs), np.int8)
+    pq[:, :A] = -120                                                  # objectness: sigmoid(-30) -> below any threshold
+    n_on = {"tail": 220, "lds_overflow": 845, "list_overflow": 3380}[case]
+    for b in range(2):
+        flat = rng.permutation(hs * hs * A)[:n_on]                    # anchors switched on
+        cell, a = flat // A, flat % A
+        y, x = cell // hs, cell % hs
+        pq[b, a, y, x] = rng.randint(20, 127, size=n_on)              # objectness in (0.99.., 1): many equal scores
+        cls1 = rng.rand(n_on) < (0.0 if case == "tail" else 0.5)      # "tail": one class -> 220^2 / 2 = 24 k pairs
+        pq[b, A + a * C + 0, y, x] = np.where(cls1, -100, 100)
+        pq[b, A + a * C + 1, y, x] = np.where(cls1, 100, -100)
+        pq[b, (1 + C) * A + a * 4 + 2, y, x] = 127                    # tw, th: exp(31.75) x anchor -> clipped to the image
+        pq[b, (1 + C) * A + a * 4 + 3, y, x] = 127
+    eng = Engine([size, size], C, synth.ANCHOR_SIZE_MASK, conf_thresh=0.5, nms_thresh=0.5, max_batch=2)
+    dets = eng.head_nms(pq, sa_pred)
+    box, sc = O.head_decode(pq.astype(np.float32) * np.float32(2.0 ** -sa_pred), [size, size], synth.ANCHOR_SIZE_MASK, C)
+    for b in range(2):
+        ref = O.postprocess(box[b], sc[b], 0.5, 0.5, C)[:3]
+        assert 1 <= len(ref[1]) <= C
+        assert len(dets[b][1]) == len(ref[1]), (case, b, len(dets[b][1]), len(ref[1]))
+        assert np.array_equal(dets[b][2], ref[2])
+        assert np.allclose(dets[b][0], ref[0], atol=2e-5, rtol=0) and np.allclose(dets[b][1], ref[1], atol=2e-6, rtol=1e-5)
+    eng.close()
