@@ -567,7 +567,7 @@ def main():
 
     # per-kernel device time with HIP events on the engine's stream (separate profiled steps)
     eng.profile(True)
-    acc = np.zeros(12)
+    acc, kacc = [], []
     nprof = max(5, min(args.steps, 20))
     with torch.cuda.stream(streams[0]):
         for i in range(nprof):
@@ -575,9 +575,17 @@ def main():
                 eng.forward_frames_device(frames, 0, bufs[0])
             else:
                 eng.forward_device(x, 0, bufs[0])
-            acc += np.array(eng.profile_ms())
+            acc.append(eng.profile_ms())
+        eng.profile(2)              # second pass: the launches' own timestamps (widens the intervals, hence separate)
+        for i in range(nprof):
+            if frames is not None:
+                eng.forward_frames_device(frames, 0, bufs[0])
+            else:
+                eng.forward_device(x, 0, bufs[0])
+            kacc.append(eng.profile_kernel_ms())
     eng.profile(False)
-    layer_ms = acc / nprof
+    layer_ms = np.median(np.array(acc), axis=0)
+    kernel_ms = np.median(np.array(kacc), axis=0)    # the launches' own start / end timestamps (0 where a layer's launcher records none)
     ndet = int(out[3][:B].sum().item())
 
     if rank == 0:
@@ -585,7 +593,11 @@ def main():
         value = world * B * args.steps / dt
         conv_ms = float(layer_ms[:10].sum())
         achieved = B * OPS_PER_IMAGE / (conv_ms * 1e-3) / 1e12
-        dom_ms = float(layer_ms[7] + layer_ms[8]) / 2
+        # dominant kernel: its own duration (start / end timestamps of the launch, hipExtLaunchKernelGGL: what rocprofv3
+        # reports); the interval between the events before and after it also holds the gap to the neighbouring launches
+        dom_between = float(layer_ms[7] + layer_ms[8]) / 2
+        have_k = kernel_ms[7] > 0 and kernel_ms[8] > 0
+        dom_ms = float(kernel_ms[7] + kernel_ms[8]) / 2 if have_k else dom_between
         dom_tops = B * 2e6 * LAYER_MMAC[7] / (dom_ms * 1e-3) / 1e12
         fused = not args.no_fuse_front and layer_ms[1] < 0.2 * layer_ms[0]     # slot 0 then holds conv1 + conv2 (one launch)
         layers = {}
@@ -620,6 +632,12 @@ def main():
                          "kernel": DOMINANT_KERNEL + " (conv6 and conv7: 2 launches/step, the largest share of "
                                    "the step of any kernel; int8 ops = 2 x 398.72e6 MAC x %d images per launch)" % B,
                          "launch_ms": round(dom_ms, 4),
+                         "launch_ms_source": ("kernel start/end timestamps of the launch (hipExtLaunchKernelGGL events), mean of "
+                                              "conv6 and conv7, median of %d profiled steps on the engine's stream" % nprof) if have_k
+                         else "interval between hipEventRecord before / after the launch",
+                         "launch_ms_between_events": round(dom_between, 4),
+                         "frac_between_events": round(B * 2e6 * LAYER_MMAC[7] / (dom_between * 1e-3) / PEAK_I8_DENSE, 4),
+                         "kernel_ms": {n: round(float(kernel_ms[i]), 4) for i, n in enumerate(LAYER_NAMES) if kernel_ms[i] > 0},
                          # MFMA-only microbenchmark on this part (scratch/ubench/mfma_peak.hip, profiles/r01_g_ablation.txt):
                          # v_mfma_i32_16x16x64_i8 at two waves per SIMD sustains 4588 Tops/s (the clock drops to ~2.2 GHz)
                          "peak_measured": PEAK_I8_MEASURED / 1e12,

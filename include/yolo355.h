@@ -243,6 +243,11 @@ int y355_sync(y355_engine *h);
 #define Y355_NUM_TIMERS 12
 int y355_profile(y355_engine *h, int enable);
 int y355_profile_get(y355_engine *h, float *ms /*[Y355_NUM_TIMERS]*/);
+/* y355_profile(h, 2): additionally the layers' own kernel durations (ms, start / end timestamps of the launch itself, what
+ * rocprofv3 reports), without the gaps between launches that the slots above include -- and which this mode widens, so take
+ * the slots above from a run with y355_profile(h, 1).  0 for layers whose launch does not record them (today: recorded by
+ * the six ring-kernel layers conv3_2 .. pred) */
+int y355_profile_kernel_get(y355_engine *h, float *ms /*[10]*/);
 /* diagnostic builds (-DY355_DIAG=1): arm / read the s_memtime stamps of one conv layer */
 int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *out_host, int nwg);
 /* diagnostics (env Y355_NMS_STAMPS=1): s_memtime stamps [4 kernels][256 workgroups][8 slots] of the head / NMS kernels */

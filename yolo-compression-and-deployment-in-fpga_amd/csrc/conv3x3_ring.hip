@@ -16,6 +16,7 @@
 //     slot that just died (in two passes where it is larger than a slot), not in its own buffer.
 // Same math, tile geometry, weight packing and epilogue arithmetic as conv3x3_v2.hip / conv3x3.hip.
 #include "y355_common.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #ifndef Y355_DIAG
 #define Y355_DIAG 0
@@ -663,7 +664,14 @@ struct ConvInstR {
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
         int grid = grid_max;                                   // one persistent workgroup per CU (two for the half tiles)
         if (grid > total) grid = total;
-        hipLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
+        if (p.ev_start && p.ev_stop) {
+            hipEvent_t e0 = (hipEvent_t)p.ev_start, e1 = (hipEvent_t)p.ev_stop;
+            p.ev_start = p.ev_stop = nullptr;
+            hipExtLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s,
+                                  e0, e1, 0, p, total);
+        } else {
+            hipLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
+        }
         return true;
     }
 };

@@ -175,6 +175,8 @@ struct y355_engine {
     int profile = 0;
     int fuse_front = 1;             // conv1 + pool1 + conv2 + pool2 as one launch (front.hip) where eligible
     hipEvent_t ev[Y355_NUM_TIMERS + 1];
+    hipEvent_t kev[10][2];      // per-layer kernel start / stop timestamps (ring kernels, profile mode)
+    bool kev_set[10] = {};
     bool ev_ok = false;
     std::vector<void *> allocs;
 };
@@ -191,8 +193,10 @@ extern "C" void y355_destroy(y355_engine *h) {
     (void)hipSetDevice(h->cfg.device_id);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) (void)hipFree(p);
-    if (h->ev_ok)
+    if (h->ev_ok) {
         for (auto &e : h->ev) (void)hipEventDestroy(e);
+        for (auto &e : h->kev) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
+    }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -289,6 +293,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) {
         bool ok = true;
         for (auto &e : h->ev) ok = ok && (hipEventCreate(&e) == hipSuccess);
+        for (auto &e : h->kev) ok = ok && (hipEventCreate(&e[0]) == hipSuccess) && (hipEventCreate(&e[1]) == hipSuccess);
         h->ev_ok = ok;
         if (!ok) rc = fail(Y355_EHIP, "hipEventCreate failed");
     }
@@ -435,6 +440,8 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.ctr = h->ctr_dev + k;
         p.sink = h->sink_dev;
         p.stamps = (h->stamp_layer == k) ? h->stamps_dev : nullptr;
+        h->kev_set[k] = false;
+        if (h->profile == 2 && mode == 0) { p.ev_start = h->kev[k][0]; p.ev_stop = h->kev[k][1]; }
         p.B = B;
         p.H = L.Hin;
         p.W = L.Win;
@@ -467,6 +474,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         }
         if (!no_v2 && !((no_ring_mask >> k) & 1) && y355_launch_conv_ring(L.kid, p, h->stream)) {
             HIPCHK(hipGetLastError());
+            h->kev_set[k] = p.ev_start != nullptr;
             return 0;
         }
         if (no_v2 || ((no_v2_mask >> k) & 1) || !y355_launch_conv_v2(L.kid, p, h->stream))
@@ -931,6 +939,17 @@ extern "C" int y355_profile_get(y355_engine *h, float *ms) {
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipEventSynchronize(h->ev[12]));
     for (int i = 0; i < Y355_NUM_TIMERS; ++i) HIPCHK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return 0;
+}
+
+extern "C" int y355_profile_kernel_get(y355_engine *h, float *ms) {
+    if (!h || !ms) return fail(Y355_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipEventSynchronize(h->ev[12]));
+    for (int k = 0; k < 10; ++k) {
+        ms[k] = 0.f;
+        if (h->kev_set[k]) HIPCHK(hipEventElapsedTime(&ms[k], h->kev[k][0], h->kev[k][1]));
+    }
     return 0;
 }
 

@@ -60,6 +60,9 @@ struct ConvParams {
     int stagger;          // ring kernel, two workgroups per CU: the second half of the grid starts 64*stagger cycles late
     int mode;             // 0 run, 1 statistics only
     int guard;            // evaluate the head-room guard
+    // host side only (ring launcher): when set, the launch records the kernel's own start / end timestamps into these
+    // events (hipExtLaunchKernelGGL) -- the duration rocprofv3 reports, without the gap to the neighbouring launches
+    void *ev_start, *ev_stop;
 };
 
 struct Conv1Params {

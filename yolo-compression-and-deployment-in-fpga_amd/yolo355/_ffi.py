@@ -112,6 +112,7 @@ _SIGS = {
     "y355_sync": (C.c_int, [C.c_void_p]),
     "y355_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "y355_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
+    "y355_profile_kernel_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
     "y355_net_create": (C.c_int, [P(NetConfig), P(C.c_void_p)]),
     "y355_net_destroy": (None, [C.c_void_p]),
     "y355_net_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),

@@ -325,11 +325,20 @@ class Engine:
         _ffi.check(self._lib.y355_sync(self._h))
 
     def profile(self, enable=True):
-        _ffi.check(self._lib.y355_profile(self._h, 1 if enable else 0))
+        """True / 1: intervals between HIP events around every launch (profile_ms); 2: also the launches' own start / end
+        timestamps (profile_kernel_ms; the intervals of such a run are wider)."""
+        _ffi.check(self._lib.y355_profile(self._h, int(enable)))
 
     def profile_ms(self):
         arr = (C.c_float * _ffi.NUM_TIMERS)()
         _ffi.check(self._lib.y355_profile_get(self._h, arr))
+        return list(arr)
+
+    def profile_kernel_ms(self):
+        """the layers' own kernel durations of the last profiled forward (ms; 0 where the launch records none):
+        start / end timestamps of the launch itself, i.e. what rocprofv3 reports, without the gaps between launches."""
+        arr = (C.c_float * 10)()
+        _ffi.check(self._lib.y355_profile_kernel_get(self._h, arr))
         return list(arr)
 
 
