@@ -491,3 +491,27 @@ def test_nms_edge_list_limits(case):
         assert np.array_equal(dets[b][2], ref[2])
         assert np.allclose(dets[b][0], ref[0], atol=2e-5, rtol=0) and np.allclose(dets[b][1], ref[1], atol=2e-6, rtol=1e-5)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_kernel_timestamps_of_the_ring_layers():
+    """y355_profile(h, 2) / y355_profile_kernel_get: the ring layers (conv3_2 .. pred) report their own kernel durations, positive
+    and no longer than the interval between the events around the launch; the other layers report 0; results are unchanged."""
+    from yolo355.engine import Engine
+    B = 4
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
+    eng = Engine([416, 416], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+    eng.load_quantized(ql)
+    eng.calibrate(synth.make_images(1, 1, 416, 416), [prep.RangeTracker() for _ in range(11)])
+    x = synth.make_images(3, B, 416, 416)
+    ref = eng.forward(x)
+    eng.profile(2)
+    got = eng.forward(x)
+    ms, kms = eng.profile_ms(), eng.profile_kernel_ms()
+    eng.profile(False)
+    for a, b in zip(ref, got):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    assert all(k == 0 for k in kms[:3]) and all(k > 0 for k in kms[3:]), kms
+    assert all(kms[i] <= ms[i] * 1.05 + 1e-3 for i in range(3, 10)), (kms, ms)
+    eng.close()
