@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Params p) {
 // U8: the input is the camera frame itself (uint8 HWC BGR); BaseTransform's (u/255 - mean)/std, the
 // BGR->RGB swap and the HWC->CHW permute (data/__init__.py:30-56, test.py:79) happen in the load, with
 // the reference's fp32 operations in the reference's order, so the quantised pixels are identical.
-template <int TW, bool U8>
+template <int TW, bool U8, bool GEN = false>
 __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
     constexpr int TH = 16;
     constexpr int PW = TW + 2, PH = TH + 2;
@@ -299,10 +299,14 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
     const int shl2 = rq.shl + rq.sh_l;
     const int bias2 = bias << rq.sh_l;
     auto requant = [&](int v) {
-        int x = (v << shl2) + bias2;
-        x = max(x, x << rq.lk);
-        const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
-        return (x + rq.hm1 + rb) >> rq.sh_r;
+        if constexpr (GEN) {
+            return y355_requant_gen32(v, bias, rq);        // slope neg_mul / 2^lk (y355_net: LeakyReLU(0.1) = 205 / 2048)
+        } else {
+            int x = (v << shl2) + bias2;
+            x = max(x, x << rq.lk);
+            const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
+            return (x + rq.hm1 + rb) >> rq.sh_r;
+        }
     };
     // lane geometry inside an m-tile: window li>>2, position li&3 -> pixel (r>>1, 2*(li>>2) + (r&1))
     const int r4 = li & 3;
@@ -348,12 +352,13 @@ __global__ __launch_bounds__(256) void conv1_fast_kernel(const Conv1Params p) {
         }
     }
     __syncthreads();
-    int8_t *outb = p.out + (size_t)b * (Ho + 2) * (Wo + 2) * 16;
+    const int opb = p.out_pb ? p.out_pb : 16;                // bytes per output pixel (wider buffers: the rest stays as it is)
+    int8_t *outb = p.out + (size_t)b * (Ho + 2) * (Wo + 2) * opb;
     for (int w = tid; w < NW; w += 256) {
         const int wy = w / WPR, wx = w % WPR;
         const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
         if (oy < Ho && ox < Wo)
-            *(v4i *)(outb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * 16) = *(const v4i *)(otile + w * 16);
+            *(v4i *)(outb + ((size_t)(oy + 1) * (Wo + 2) + ox + 1) * opb) = *(const v4i *)(otile + w * 16);
     }
     if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
     if (nsat_in) atomicAdd(&p.ctr->in_sat, (unsigned long long)nsat_in);
@@ -370,6 +375,11 @@ void y355_conv1_tiles(int H, int W, int *tx, int *ty) {
 void y355_launch_conv1(const Conv1Params &p, hipStream_t s) {
     const int n = p.tiles_x * p.tiles_y * p.B;
     const bool big = conv1_tw(p.W) == 104;
+    if (p.mode == 0 && !p.guard && p.rq.gen32 && p.x && p.bias_t) {       // y355_net's first layer, general slope in 32 bits
+        if (big) hipLaunchKernelGGL((conv1_fast_kernel<104, false, true>), dim3(n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv1_fast_kernel<32, false, true>), dim3(n), dim3(256), 0, s, p);
+        return;
+    }
     if (p.mode == 0 && !p.rq.wide && !p.guard && !p.out_pb) {
         if (p.x) {
             if (big) hipLaunchKernelGGL((conv1_fast_kernel<104, false>), dim3(n), dim3(256), 0, s, p);

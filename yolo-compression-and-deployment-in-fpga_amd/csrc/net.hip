@@ -716,6 +716,21 @@ static int refresh_i8(y355_net *h) {
         L.rq1.neg_mul = nm;
         L.rq1.guard_log2 = 63;
         L.rq1.wide = 1;
+        // the first layer runs conv1.hip's fast kernel when the general-slope epilogue fits 32 bits:
+        //   |t| * max(2^max(0, lk - sh), neg_mul * 2^max(0, -sh)) + rounding < 2^31          (y355_requant_gen32)
+        L.rq1.gen32 = 0;
+        std::vector<int32_t> bt(L.cout_pad, 0);
+        if (o.type == OP_CONV1) {
+            long double t32 = ((long double)127 * 127 * o.ksize * o.ksize * o.cin) * std::ldexp(1.0L, shl) + bmax;
+            const long double fpos = std::ldexp(1.0L, std::max(0, lk - sh)), fneg = (long double)nm * std::ldexp(1.0L, std::max(0, -sh));
+            t32 = t32 * std::max(fpos, fneg) + std::ldexp(1.0L, std::max(sh, 0));
+            if (t32 < std::ldexp(1.0L, 31) && bmax < std::ldexp(1.0L, 31)) {
+                L.rq1.gen32 = 1;
+                for (int c = 0; c < L.cout; ++c) bt[c] = (int32_t)bw[c];
+            }
+            // int8 nets have no float bias: the layer's bias_dev (4 bytes per channel) holds the 32-bit copy
+            HIPCHK(hipMemcpyAsync(L.bias_dev, bt.data(), sizeof(int32_t) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
+        }
         HIPCHK(hipMemcpyAsync(L.bias_w_dev, bw.data(), sizeof(long long) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         L.dirty = false;
@@ -825,6 +840,7 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
             p.out_pb = (int)h->T[o.out].pb;
             p.w = (const int8_t *)h->w0_dev;
             p.bias_w = L.bias_w_dev;
+            p.bias_t = L.rq1.gen32 ? (const int *)L.bias_dev : nullptr;
             p.ctr = h->ctr_dev + i;
             p.B = B;
             p.H = h->cfg.height;

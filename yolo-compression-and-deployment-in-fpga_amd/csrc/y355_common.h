@@ -25,7 +25,21 @@ struct Requant {
     // general LeakyReLU slope neg_mul / 2^lk (1 / 2^3 = the reference's 0.125); only the 64-bit
     // epilogues (y355_pre) honour neg_mul != 1
     int neg_mul;
+    // 1: the general slope fits 32 bits (host-checked: |t| * max(2^max(0, lk - sh), neg_mul * 2^max(0, -sh)) < 2^31):
+    //   q = t >= 0 ? rne(t * 2^(lk - sh)) : rne(t * neg_mul * 2^-sh)          (y355_requant_gen32; first layer of y355_net)
+    int gen32;
 };
+
+__device__ __forceinline__ int y355_rne_shift32(int x, int s) {            // s wave-uniform
+    if (s <= 0) return x << (-s);
+    return (x + (1 << (s - 1)) - 1 + ((x >> s) & 1)) >> s;
+}
+// q before clamping for a LeakyReLU slope neg_mul / 2^lk that is not a power of two, 32-bit (Requant::gen32)
+__device__ __forceinline__ int y355_requant_gen32(int acc, int bias, const Requant &rq) {
+    const int t = (acc << rq.shl) + bias;
+    const int qp = y355_rne_shift32(t, rq.sh - rq.lk), qn = y355_rne_shift32(t * rq.neg_mul, rq.sh);
+    return t >= 0 ? qp : qn;
+}
 
 // q before clamping, 32-bit, no branches (production kernels)
 __device__ __forceinline__ int y355_requant_fast(int acc, int bias, const Requant &rq) {
