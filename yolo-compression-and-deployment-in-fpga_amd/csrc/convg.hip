@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
 // (58.2 k / 49.2 k): the extra live state spills, and one 8-wave workgroup per CU has nothing to overlap its epilogue with.
 // What bounds this kernel now is the B path: 16-32 KB of fragments per k-step per CU through the vector-memory pipe
 // (profiles/r02_notes.md); the int8 ring kernels avoid exactly that with LDS-DMA weight rings.
-template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S>
+template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S, bool NARROW = false>
 __global__ __launch_bounds__(WM * WN * 64) void convg8_kernel(const ConvGParams p, const int total) {
     constexpr int NTHR = WM * WN * 64;
     constexpr bool THIN = (CHB == 32);           // 32 B per pixel: a k-step covers two taps
@@ -505,6 +505,11 @@ __global__ __launch_bounds__(WM * WN * 64) void convg8_kernel(const ConvGParams 
             if constexpr (BF) { biasf[t] = p.bias_f[nlane + t]; biasw[t] = 0; }
             else { biasw[t] = p.bias_w[nlane + t]; biasf[t] = 0.f; }
         }
+        int biasn[NT];                                     // NARROW: the biases fit 32 bits too
+#pragma unroll
+        for (int t = 0; t < NT; ++t) biasn[t] = (int)biasw[t];
+        Requant rqn{};
+        rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul;
 
         auto finish = [&](const float (&vf)[NT], const int (&vi)[NT], bool valid, int oy, int ox) {
             char *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.out_pb;
@@ -532,9 +537,15 @@ __global__ __launch_bounds__(WM * WN * 64) void convg8_kernel(const ConvGParams 
                 int q[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const long long qq = requant_g(vi[t], biasw[t], rq);
-                    q[t] = y355_clamp8<long long>(qq);
-                    nsat += (valid && (long long)q[t] != qq) ? 1u : 0u;
+                    if constexpr (NARROW) {
+                        const int qq = y355_requant_gen32(vi[t], biasn[t], rqn);
+                        q[t] = y355_clamp8<int>(qq);
+                        nsat += (valid && q[t] != qq) ? 1u : 0u;
+                    } else {
+                        const long long qq = requant_g(vi[t], biasw[t], rq);
+                        q[t] = y355_clamp8<long long>(qq);
+                        nsat += (valid && (long long)q[t] != qq) ? 1u : 0u;
+                    }
                 }
                 if (valid) store_i8<NT>(dst + nlane, q);
             }
@@ -591,16 +602,27 @@ struct ConvGInst {
     static void launch(const ConvGParams &p, int nblocks, hipStream_t s) {
         if constexpr (EIGHT) {
             // one tile per workgroup (persistent workgroups measured slower: slim fp32, B = 64, 58.2 k vs 63.8 k img/s)
-            hipLaunchKernelGGL((convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(512),
-                               p.nchunks > 1 ? 2 * SLAB : SLAB, s, p, nblocks);
+            if (!BF && p.rq.narrow)
+                hipLaunchKernelGGL((convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S, !BF>), dim3(nblocks), dim3(512),
+                                   p.nchunks > 1 ? 2 * SLAB : SLAB, s, p, nblocks);
+            else
+                hipLaunchKernelGGL((convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(512),
+                                   p.nchunks > 1 ? 2 * SLAB : SLAB, s, p, nblocks);
         } else {
             hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(256), SLAB, s, p);
         }
     }
     static int prepare() {
         const void *fn;
-        if constexpr (EIGHT) fn = (const void *)convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>;
-        else fn = (const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>;
+        if constexpr (EIGHT) {
+            fn = (const void *)convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>;
+            if constexpr (!BF) {
+                if (int e = (int)hipFuncSetAttribute((const void *)convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S, !BF>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS)) return e;
+            }
+        } else {
+            fn = (const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>;
+        }
         return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     static constexpr ConvGInfo info() {

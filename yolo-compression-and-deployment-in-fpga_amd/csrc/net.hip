@@ -708,6 +708,13 @@ static int refresh_i8(y355_net *h) {
         L.rq.sh = sh;
         L.rq.lk = lk;
         L.rq.neg_mul = nm;
+        {
+            // 32-bit epilogue (y355_requant_gen32) when |t| * max(2^max(0, lk - sh), neg_mul * 2^max(0, -sh)) + rounding < 2^31
+            long double t32 = ((long double)127 * 127 * o.ksize * o.ksize * o.cin) * std::ldexp(1.0L, shl) + bmax;
+            const long double fpos = std::ldexp(1.0L, std::max(0, lk - sh)), fneg = (long double)nm * std::ldexp(1.0L, std::max(0, -sh));
+            t32 = t32 * std::max(fpos, fneg) + std::ldexp(1.0L, std::max(sh, 0));
+            L.rq.narrow = (t32 < std::ldexp(1.0L, 31) && bmax < std::ldexp(1.0L, 31)) ? 1 : 0;
+        }
         L.rq1 = Requant{};
         L.rq1.shl = shl;
         L.rq1.sh = sh;

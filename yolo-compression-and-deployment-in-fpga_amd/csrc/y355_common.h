@@ -264,6 +264,7 @@ struct RequantG {
     int sh;        // q = clamp(RNE(t' * 2^-sh))
     int lk;        // t' = t >= 0 ? t * 2^lk : t * neg_mul     (LeakyReLU slope neg_mul / 2^lk)
     int neg_mul;
+    int narrow;    // 1: the whole epilogue fits 32 bits (host-checked bound): the 8-wave kernels take their 32-bit instantiation
 };
 
 struct ConvGParams {
