@@ -67,7 +67,7 @@ __device__ __forceinline__ long long requant_g(int acc, long long bias, const Re
 
 // ---- four waves per workgroup (round 1): one tile per workgroup, stage -> barrier -> k-steps -> barrier per chunk.  Kept for
 // the thin layers and the small / stride-2 tiles, where its 2-3 workgroups per CU overlap each other's phases.
-template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S>
+template <bool BF, int CHB, int BN, int TH, int TW, bool POOL, int WM, int WN, int S, bool NARROW = false>
 __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
     constexpr bool THIN = (CHB == 32);           // 32 B per pixel: a k-step covers two taps
     // input patch of a TH x TW output tile: S*(T-1)+3 pixels a side (stride S, 3x3, pad 1)
@@ -226,8 +226,13 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
         if constexpr (BF) { biasf[t] = p.bias_f[nlane + t]; biasw[t] = 0; }
         else { biasw[t] = p.bias_w[nlane + t]; biasf[t] = 0.f; }
     }
+    int biasn[NT];                                         // NARROW: the biases fit 32 bits too
+#pragma unroll
+    for (int t = 0; t < NT; ++t) biasn[t] = (int)biasw[t];
     const float slope = p.slope;
     const RequantG rq = p.rq;
+    Requant rqn{};
+    rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul;
 
     auto finish = [&](const float (&vf)[NT], const int (&vi)[NT], bool valid, int oy, int ox) {
         char *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.out_pb;
@@ -255,9 +260,15 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
             int q[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const long long qq = requant_g(vi[t], biasw[t], rq);
-                q[t] = y355_clamp8<long long>(qq);
-                nsat += (valid && (long long)q[t] != qq) ? 1u : 0u;
+                if constexpr (NARROW) {
+                    const int qq = y355_requant_gen32(vi[t], biasn[t], rqn);
+                    q[t] = y355_clamp8<int>(qq);
+                    nsat += (valid && q[t] != qq) ? 1u : 0u;
+                } else {
+                    const long long qq = requant_g(vi[t], biasw[t], rq);
+                    q[t] = y355_clamp8<long long>(qq);
+                    nsat += (valid && (long long)q[t] != qq) ? 1u : 0u;
+                }
             }
             if (valid) store_i8<NT>(dst + nlane, q);
         }
@@ -609,7 +620,10 @@ struct ConvGInst {
                 hipLaunchKernelGGL((convg8_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(512),
                                    p.nchunks > 1 ? 2 * SLAB : SLAB, s, p, nblocks);
         } else {
-            hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(256), SLAB, s, p);
+            if (!BF && p.rq.narrow)
+                hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S, !BF>), dim3(nblocks), dim3(256), SLAB, s, p);
+            else
+                hipLaunchKernelGGL((convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>), dim3(nblocks), dim3(256), SLAB, s, p);
         }
     }
     static int prepare() {
@@ -622,6 +636,10 @@ struct ConvGInst {
             }
         } else {
             fn = (const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S>;
+            if constexpr (!BF) {
+                if (int e = (int)hipFuncSetAttribute((const void *)convg_kernel<BF, CHB, BN, TH, TW, POOL, WM, WN, S, !BF>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS)) return e;
+            }
         }
         return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
