@@ -598,8 +598,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                         *(unsigned int *)(stg + lrow * SSTR + ncol) = w;
                     }
                 }
+                if (Y355_DIAG && first) stamp();                   // requantised and staged (this wave)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                if (Y355_DIAG && first) stamp();                   // everybody's rows are staged
 #pragma unroll
                 for (int j = 0; j < NITP; ++j) {
                     const int it = min(tid + j * NTHR, RP * CG - 1);      // tail clamps: duplicates rewrite the same bytes
