@@ -79,6 +79,8 @@ def sparse_fixture(args, dev, streams, x):
         with torch.cuda.stream(st):
             e = Engine([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.1, nms_thresh=0.5, max_batch=B, device=dev)
             e.load_quantized(quantized_layers(2, pred_gain=400.0, obj_bias=-4.0))
+            if len(streams) > 1:
+                e.set_option(2, args.ring_workgroups)    # Y355_OPT_RING_WORKGROUPS, as the headline's timed region
         engines.append(e)
     sa = engines[0].calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
     for e in engines:
@@ -442,6 +444,9 @@ def main():
     ap.add_argument("--no-fuse-front", action="store_true",
                     help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
+    ap.add_argument("--ring-workgroups", type=int, default=192,
+                    help="persistent workgroups per launch of the deep convolutions while several handles share the GPU "
+                         "(Y355_OPT_RING_WORKGROUPS; 0 = one per CU; a handle running alone always gets one per CU)")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32 = the headline configuration (fp32 NCHW tensor resident in HBM); u8 = uint8 HWC BGR "
                          "frames with BaseTransform fused into the first layer (SURVEY 8f-1), same detections")
@@ -558,8 +563,15 @@ def main():
         return times, out
 
     reps = max(1, args.repeats)
+    # throughput mode: handles that share the GPU run their deep convolutions on fewer persistent workgroups, each walking
+    # more tiles (include/yolo355.h, Y355_OPT_RING_WORKGROUPS); the one-stream and the profiling passes below use all CUs
+    ring_wgs = args.ring_workgroups if nstreams > 1 else 0
+    for e in engines:
+        e.set_option(2, ring_wgs)                        # Y355_OPT_RING_WORKGROUPS
     times, out = timed(nstreams, args.steps, args.warmup, reps)
     dt = float(np.median(times))
+    for e in engines:
+        e.set_option(2, 0)
     one = None
     if nstreams > 1:
         t1, _ = timed(1, args.steps, min(args.warmup, 5), max(3, reps // 3))
@@ -618,7 +630,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "slim_yolo_v2_q_bf int8, batch %d per GPU, 416x416, 2 classes, conf 0.01" % B,
                        "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
-                       "streams_per_gpu": nstreams, "input": args.input,
+                       "streams_per_gpu": nstreams, "ring_workgroups_per_launch": ring_wgs if ring_wgs else "one per CU",
+                       "input": args.input,
                        "detections_per_step_rank0": ndet},
             # the timed region (exactly `steps` steps between barrier + synchronize) was run `repeats` times: value and
             # ms_per_step are the MEDIAN region; with 3 engine handles ms_per_step is a throughput period, not a latency

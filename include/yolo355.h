@@ -76,6 +76,11 @@ int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
  * 16-channel intermediate map stays on chip; 0 = one launch per layer (then y355_get_feature(0) is current after a forward).
  * Results are identical bit for bit either way. */
 #define Y355_OPT_FUSE_FRONT 1
+/* Y355_OPT_RING_WORKGROUPS (default 0 = one per CU): persistent workgroups per launch of the deep convolutions.  A handle that
+ * has the GPU to itself wants them all; when several handles share it (bench.py: three), fewer workgroups that each walk more
+ * tiles let launches of different handles run side by side and pay a workgroup's start-up once per several tiles
+ * (192 of 256: +2.6 % images/s with three handles, -25 % for a handle running alone) */
+#define Y355_OPT_RING_WORKGROUPS 2
 int y355_set_option(y355_engine *h, int option, int value);
 
 /* replaces load_state_dict of the quantized checkpoint: integer weights as produced by

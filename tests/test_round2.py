@@ -515,3 +515,30 @@ def test_kernel_timestamps_of_the_ring_layers():
     assert all(k == 0 for k in kms[:3]) and all(k > 0 for k in kms[3:]), kms
     assert all(kms[i] <= ms[i] * 1.05 + 1e-3 for i in range(3, 10)), (kms, ms)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_ring_workgroups_option_changes_nothing_but_the_schedule():
+    """Y355_OPT_RING_WORKGROUPS: fewer persistent workgroups per launch of the deep convolutions walk more tiles each -- same maps,
+    same detections (B = 6 at 416 x 416: 24-48 tiles per layer on 7 workgroups)."""
+    from yolo355 import _ffi
+    from yolo355.engine import Engine
+    B = 6
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
+    eng = Engine([416, 416], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+    eng.load_quantized(ql)
+    eng.calibrate(synth.make_images(1, 1, 416, 416), [prep.RangeTracker() for _ in range(11)])
+    x = synth.make_images(11, B, 416, 416)
+    ref = eng.forward(x)
+    maps = [eng.get_feature(k, B).copy() for k in range(10)]
+    for n in (7, 192):
+        eng.set_option(_ffi.OPT_RING_WORKGROUPS, n)
+        got = eng.forward(x)
+        for k in range(10):
+            assert np.array_equal(eng.get_feature(k, B), maps[k]), (n, k)
+        for a, b in zip(ref, got):
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v)
+    with pytest.raises(_ffi.Y355Error):
+        eng.set_option(_ffi.OPT_RING_WORKGROUPS, -1)
+    eng.close()

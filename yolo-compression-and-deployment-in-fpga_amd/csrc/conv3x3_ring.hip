@@ -665,6 +665,7 @@ struct ConvInstR {
         p.stagger = stagger;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
         int grid = grid_max;                                   // one persistent workgroup per CU (two for the half tiles)
+        if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;   // fewer, each walking more tiles (throughput mode)
         if (grid > total) grid = total;
         if (p.ev_start && p.ev_stop) {
             hipEvent_t e0 = (hipEvent_t)p.ev_start, e1 = (hipEvent_t)p.ev_stop;

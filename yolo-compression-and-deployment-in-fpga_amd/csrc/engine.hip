@@ -174,6 +174,7 @@ struct y355_engine {
     int stamp_layer = -1;
     int profile = 0;
     int fuse_front = 1;             // conv1 + pool1 + conv2 + pool2 as one launch (front.hip) where eligible
+    int ring_wgs = 0;               // persistent workgroups per ring launch (0 = one per CU)
     hipEvent_t ev[Y355_NUM_TIMERS + 1];
     hipEvent_t kev[10][2];      // per-layer kernel start / stop timestamps (ring kernels, profile mode)
     bool kev_set[10] = {};
@@ -311,6 +312,10 @@ extern "C" int y355_set_option(y355_engine *h, int option, int value) {
     if (!h) return fail(Y355_EINVAL, "null engine");
     switch (option) {
     case Y355_OPT_FUSE_FRONT: h->fuse_front = value ? 1 : 0; return 0;
+    case Y355_OPT_RING_WORKGROUPS:
+        if (value < 0 || value > 4096) return fail(Y355_EINVAL, "workgroups per launch out of range");
+        h->ring_wgs = value;
+        return 0;
     default: return fail(Y355_EINVAL, "unknown option");
     }
 }
@@ -442,6 +447,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.stamps = (h->stamp_layer == k) ? h->stamps_dev : nullptr;
         h->kev_set[k] = false;
         if (h->profile == 2 && mode == 0) { p.ev_start = h->kev[k][0]; p.ev_stop = h->kev[k][1]; }
+        p.grid_limit = h->ring_wgs;
         p.B = B;
         p.H = L.Hin;
         p.W = L.Win;

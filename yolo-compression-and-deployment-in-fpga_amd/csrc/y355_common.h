@@ -77,6 +77,7 @@ struct ConvParams {
     // host side only (ring launcher): when set, the launch records the kernel's own start / end timestamps into these
     // events (hipExtLaunchKernelGGL) -- the duration rocprofv3 reports, without the gap to the neighbouring launches
     void *ev_start, *ev_stop;
+    int grid_limit;       // host side only: persistent workgroups of a ring launch (0 = one per CU), Y355_OPT_RING_WORKGROUPS
 };
 
 struct Conv1Params {

@@ -16,6 +16,7 @@ NUM_TIMERS = 12
 F_GUARD, F_TAP = 1, 2
 OP_LEAKY, OP_POOL, OP_RELU = 1, 2, 4
 OPT_FUSE_FRONT = 1
+OPT_RING_WORKGROUPS = 2
 
 
 class Config(C.Structure):
