@@ -542,3 +542,44 @@ def test_ring_workgroups_option_changes_nothing_but_the_schedule():
     with pytest.raises(_ffi.Y355Error):
         eng.set_option(_ffi.OPT_RING_WORKGROUPS, -1)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_three_handles_throughput_mode_is_exact():
+    """bench.py's default configuration -- three engine handles on three HIP streams, deep convolutions on 192 persistent
+    workgroups per launch (Y355_OPT_RING_WORKGROUPS), steps alternating without a synchronisation in between: every output
+    equals the stand-alone result of a handle that has the GPU to itself (extends test_two_engines_concurrent to the
+    round-2 scheduling knob and NMS kernels)."""
+    from yolo355 import _ffi
+    from yolo355.engine import Engine
+    B = 64
+    dev = torch.device("cuda", 0)
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    engs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            e = Engine([416, 416], 2, synth.ANCHOR_SIZE_MASK, max_batch=B, device=dev)
+            e.load_quantized(ql)
+        engs.append(e)
+    sa = engs[0].calibrate(synth.make_images(1, 1, 416, 416), [prep.RangeTracker() for _ in range(11)])
+    for e in engs:
+        e.set_act_exponents(sa)
+    x = torch.from_numpy(synth.make_images(1000, B, 416, 416)).to(dev)
+    bufs = [tuple(torch.zeros_like(t) for t in engs[0]._buffers(B)) for _ in range(7)]
+    torch.cuda.synchronize()
+    engs[0].forward_device(x, 0, bufs[6])
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in bufs[6]]
+    assert int(ref[3].sum()) > 0
+    for e in engs:
+        e.set_option(_ffi.OPT_RING_WORKGROUPS, 192)
+    for it in range(40):
+        for i in range(6):
+            with torch.cuda.stream(streams[i % 3]):
+                engs[i % 3].forward_device(x, 0, bufs[i])
+        torch.cuda.synchronize()
+        for i in range(6):
+            assert all(torch.equal(u, v) for u, v in zip(ref, bufs[i])), (it, i)
+    for e in engs:
+        e.close()
