@@ -444,6 +444,12 @@ def main():
     ap.add_argument("--no-fuse-front", action="store_true",
                     help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
+    ap.add_argument("--gather-max-det", type=int, default=256,
+                    help="multi-GPU: detections per image in the all-gather records (SURVEY.md 8e: fixed-cap records, 6.1 KB per image "
+                         "at 256); the per-GPU forward and its outputs are unchanged")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="self-test: run the multi-GPU code path (process group, exponent broadcast, packed all-gather per step, "
+                         "barriers, max over ranks) with a world of ONE rank -- the build boxes have one GPU each")
     ap.add_argument("--ring-workgroups", type=int, default=192,
                     help="persistent workgroups per launch of the deep convolutions while several handles share the GPU "
                          "(Y355_OPT_RING_WORKGROUPS; 0 = one per CU; a handle running alone always gets one per CU)")
@@ -466,10 +472,16 @@ def main():
         sys.exit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     B = args.batch
 
@@ -506,28 +518,29 @@ def main():
     nbuf = 2 * nstreams
     bufs = [tuple(torch.empty_like(t) for t in eng._buffers(B)) for _ in range(nbuf)]
     gsend = grecv = None
-    if world > 1:
-        rb = shard.record_bytes(eng.max_det)
+    gather_md = max(1, min(args.gather_max_det, eng.max_det))
+    if dist_on:
+        rb = shard.record_bytes(gather_md)
         gsend = [torch.empty((B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         grecv = [torch.empty((world * B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     torch.cuda.synchronize()
 
     def step(i, pending, ns):
         k = i % nbuf
-        if world > 1 and pending[k] is not None:     # buffer reuse: its gather must be done
-            for w in pending[k]:
-                w.wait()
-            streams[i % ns].wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(streams[i % ns]):      # the engine's own stream: no cross-stream waits are inserted
+            if dist_on and pending[k] is not None:    # buffer reuse: its gather (2 x streams steps ago) must be done
+                for w in pending[k]:
+                    w.wait()
             if frames is not None:
                 out = engines[i % ns].forward_frames_device(frames, 0, bufs[k])
             else:
                 out = engines[i % ns].forward_device(x, 0, bufs[k])
-        if world > 1:
-            # one packed all-gather per batch, asynchronous: it overlaps the next batches' kernels
-            torch.cuda.current_stream().wait_stream(streams[i % ns])
-            _finish, works = shard.allgather_detections(*[t[:B] for t in out], async_op=True, send=gsend[k], recv=grecv[k])
-            pending[k] = works
+            if dist_on:
+                # ONE packed all-gather per batch: one pack launch on the engine's stream, then the collective,
+                # which orders itself after that stream and runs on RCCL's own -- asynchronous, no other stream involved
+                # (packing with torch ops on the default stream and waiting across streams halved the per-GPU rate)
+                shard.pack_detections_kernel(*[t[:B] for t in out], B, gsend[k], gather_md)
+                pending[k] = [dist.all_gather_into_tensor(grecv[k], gsend[k], async_op=True)]
         return out
 
     def timed(ns, steps, warmup, repeats):
@@ -540,7 +553,7 @@ def main():
         times = []
         for _ in range(repeats):
             torch.cuda.synchronize()
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -551,11 +564,11 @@ def main():
                     for w in p:
                         w.wait()
             torch.cuda.synchronize()
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
@@ -631,6 +644,8 @@ def main():
             "config": {"workload": "slim_yolo_v2_q_bf int8, batch %d per GPU, 416x416, 2 classes, conf 0.01" % B,
                        "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
                        "streams_per_gpu": nstreams, "ring_workgroups_per_launch": ring_wgs if ring_wgs else "one per CU",
+                       **({"gather": "one all_gather_into_tensor per batch, %d detections per image (%d bytes per record)"
+                                     % (gather_md, shard.record_bytes(gather_md))} if dist_on else {}),
                        "input": args.input,
                        "detections_per_step_rank0": ndet},
             # the timed region (exactly `steps` steps between barrier + synchronize) was run `repeats` times: value and
@@ -687,8 +702,13 @@ def main():
             res["cpu_baseline_pytorch"], grid2 = cpu_baseline_torch()
             grid.update(grid2)
             res["cpu_baseline_grid"] = grid
-        print(json.dumps(res))
-    if world > 1:
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)            # RCCL prints a version banner through C stdio: out before our line
+        except OSError:
+            pass
+        print(json.dumps(res), flush=True)
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -238,6 +238,11 @@ int y355_comm_rank(y355_comm *c);
 int y355_pack_dets(const float *boxes_dev, const float *scores_dev, const int32_t *cls_dev, const int32_t *count_dev,
                    int batch, int records, int max_det, void *packed_dev, void *stream);
 int y355_allgather_dets(y355_comm *c, const void *packed_send_dev, void *packed_recv_dev, int records, int max_det, void *stream);
+/* the same with a record cap below the arrays' own: the arrays hold src_max_det entries per image, the records max_det
+ * (the first max_det detections of an image in anchor order; count = min(count, max_det)) -- a gather that ships a fixed
+ * 256 detections per image whatever the engine's own cap */
+int y355_pack_dets_capped(const float *boxes_dev, const float *scores_dev, const int32_t *cls_dev, const int32_t *count_dev,
+                          int batch, int records, int src_max_det, int max_det, void *packed_dev, void *stream);
 int y355_unpack_dets(const void *packed_dev, const int32_t *slot_dev, int records, int max_det, float *boxes_dev,
                      float *scores_dev, int32_t *cls_dev, int32_t *count_dev, void *stream);
 

@@ -583,3 +583,24 @@ def test_three_handles_throughput_mode_is_exact():
             assert all(torch.equal(u, v) for u, v in zip(ref, bufs[i])), (it, i)
     for e in engs:
         e.close()
+
+
+@pytest.mark.gpu
+def test_capped_pack_kernel_equals_the_torch_packing():
+    """y355_pack_dets_capped (one launch, the per-step gather of bench.py) against shard.pack_detections (torch ops, the form the
+    gloo tests pin) on the first `cap` detections of every image: byte-identical records, also with padding records."""
+    from yolo355 import shard
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    n, md = 5, 300
+    boxes = torch.rand((n, md, 4), generator=g).to(dev)
+    scores = torch.rand((n, md), generator=g).to(dev)
+    cls = torch.randint(0, 20, (n, md), generator=g, dtype=torch.int32).to(dev)
+    count = torch.tensor([0, 7, 300, 255, 256], dtype=torch.int32, device=dev)
+    for cap, records in ((256, 5), (256, 8), (300, 6), (17, 5)):
+        got = torch.full((records, shard.record_bytes(cap)), 0xAB, dtype=torch.uint8, device=dev)
+        shard.pack_detections_kernel(boxes, scores, cls, count, records, got, cap)
+        want = shard.pack_detections(boxes[:, :cap].contiguous(), scores[:, :cap].contiguous(), cls[:, :cap].contiguous(),
+                                     count.clamp(max=cap), records)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (cap, records)

@@ -109,8 +109,9 @@ extern "C" int y355_comm_world(y355_comm *c) { return c ? c->world : Y355_EINVAL
 extern "C" int y355_comm_rank(y355_comm *c) { return c ? c->rank : Y355_EINVAL; }
 
 // one thread per 16 bytes of the record; grid (ceil(rec16 / 256), records)
+// `src_md`: detections per image the source arrays are laid out for (>= max_det, the record's cap: longer lists are cut there)
 __global__ __launch_bounds__(256) void pack_dets_kernel(const float4 *boxes, const float *scores, const int *cls, const int *count,
-                                                        int batch, int max_det, v4i *packed) {
+                                                        int batch, int src_md, int max_det, v4i *packed) {
     const int b = blockIdx.y;
     const int rec16 = 1 + max_det + (max_det * 2 + 3) / 4;            // 16-byte units: header, boxes, scores + cls (rounded up)
     const int u = blockIdx.x * 256 + threadIdx.x;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void pack_dets_kernel(const float4 *boxes, con
     } else if (u <= max_det) {
         const int i = u - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n) v = boxes[(size_t)b * max_det + i];
+        if (i < n) v = boxes[(size_t)b * src_md + i];
         *(float4 *)(rec + 16 + (size_t)i * 16) = v;
     } else {
         // scores [max_det] then cls [max_det], 4 dwords per thread (the tail of the record may be shorter)
@@ -134,22 +135,28 @@ __global__ __launch_bounds__(256) void pack_dets_kernel(const float4 *boxes, con
             const int d = d0 + k;
             if (d >= (2 * max_det + 3) / 4 * 4) break;   // includes the zeroed rounding pad of the record
             int v = 0;
-            if (d < max_det) { if (d < n) v = __float_as_int(scores[(size_t)b * max_det + d]); }
-            else if (d < 2 * max_det) { if (d - max_det < n) v = cls[(size_t)b * max_det + d - max_det]; }
+            if (d < max_det) { if (d < n) v = __float_as_int(scores[(size_t)b * src_md + d]); }
+            else if (d < 2 * max_det) { if (d - max_det < n) v = cls[(size_t)b * src_md + d - max_det]; }
             dst[d] = v;
         }
     }
 }
 
-extern "C" int y355_pack_dets(const float *boxes_dev, const float *scores_dev, const int32_t *cls_dev, const int32_t *count_dev,
-                              int batch, int records, int max_det, void *packed_dev, void *stream) {
+extern "C" int y355_pack_dets_capped(const float *boxes_dev, const float *scores_dev, const int32_t *cls_dev, const int32_t *count_dev,
+                                     int batch, int records, int src_max_det, int max_det, void *packed_dev, void *stream) {
     if (!boxes_dev || !scores_dev || !cls_dev || !count_dev || !packed_dev) return y355_fail(Y355_EINVAL, "null argument");
-    if (batch < 0 || records < batch || records < 1 || max_det < 1) return y355_fail(Y355_EINVAL, "bad batch / records / max_det");
+    if (batch < 0 || records < batch || records < 1 || max_det < 1 || src_max_det < max_det)
+        return y355_fail(Y355_EINVAL, "bad batch / records / max_det");
     const int rec16 = 1 + max_det + (max_det * 2 + 3) / 4;
     hipLaunchKernelGGL(pack_dets_kernel, dim3((rec16 + 255) / 256, records), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)boxes_dev, scores_dev, cls_dev, count_dev, batch, max_det, (v4i *)packed_dev);
+                       (const float4 *)boxes_dev, scores_dev, cls_dev, count_dev, batch, src_max_det, max_det, (v4i *)packed_dev);
     COMMCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int y355_pack_dets(const float *boxes_dev, const float *scores_dev, const int32_t *cls_dev, const int32_t *count_dev,
+                              int batch, int records, int max_det, void *packed_dev, void *stream) {
+    return y355_pack_dets_capped(boxes_dev, scores_dev, cls_dev, count_dev, batch, records, max_det, max_det, packed_dev, stream);
 }
 
 extern "C" int y355_allgather_dets(y355_comm *c, const void *packed_send_dev, void *packed_recv_dev, int records, int max_det,

@@ -108,6 +108,7 @@ _SIGS = {
     "y355_comm_world": (C.c_int, [C.c_void_p]),
     "y355_comm_rank": (C.c_int, [C.c_void_p]),
     "y355_pack_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "y355_pack_dets_capped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y355_allgather_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y355_unpack_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y355_sync": (C.c_int, [C.c_void_p]),

@@ -66,6 +66,19 @@ def pack_detections(boxes, scores, cls, count, records=None, out=None):
     return rec
 
 
+def pack_detections_kernel(boxes, scores, cls, count, records, out, max_det=None):
+    """the same packing in ONE launch on the caller's current HIP stream (C ABI y355_pack_dets_capped): no torch ops, no stream
+    but the current one -- what a per-step gather beside running engines wants (bench.py).  `max_det` below the arrays' own
+    cap ships the first max_det detections of every image (anchor order) in records of record_bytes(max_det)."""
+    from . import _ffi
+    n, md = scores.shape[0], scores.shape[1]
+    cap = md if max_det is None else min(int(max_det), md)
+    st = C.c_void_p(torch.cuda.current_stream(scores.device).cuda_stream)
+    _ffi.check(_ffi.lib().y355_pack_dets_capped(boxes.data_ptr(), scores.data_ptr(), cls.data_ptr(), count.data_ptr(), n, int(records),
+                                                md, cap, out.data_ptr(), st))
+    return out
+
+
 def unpack_records(rec, max_det, global_batch=None):
     """uint8 [R, record_bytes] -> (boxes [G,md,4], scores [G,md], cls [G,md], count [G]) dropping padding records
     (count -1); rank-major records of contiguous shards are already in global image order."""
