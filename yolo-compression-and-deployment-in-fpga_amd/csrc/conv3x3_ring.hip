@@ -30,6 +30,9 @@
 #ifndef Y355_RING_YSWZ
 #define Y355_RING_YSWZ 0         // 1: row-dependent chunk swizzle for the pooled (window-ordered) tiles: measured, no gain (profiles/r02_notes.md)
 #endif
+#ifndef Y355_RING_PF
+#define Y355_RING_PF 5            // k-steps of weights in flight (ring of PF + 2 slots)
+#endif
 #ifndef Y355_RING_DMA_AT2
 #define Y355_RING_DMA_AT2 -2     // >= 0: the younger half of the workgroup (waves NW/2..) refills after this m-tile instead
 #endif
@@ -682,12 +685,12 @@ struct ConvInstR {
 // must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
 template <bool ROLL, bool DIRECT>
 struct RSet {
-    using C3_2 = ConvInstR<64, 64, 26, 26, true, 8, 1, 5, ROLL, DIRECT>;
-    using C4_1 = ConvInstR<64, 128, 13, 26, false, 4, 2, 5, ROLL, DIRECT>;
-    using C4_2 = ConvInstR<128, 64, 26, 26, true, 8, 1, 5, ROLL, DIRECT>;
-    using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, 5, ROLL, DIRECT>;
-    using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, 5, ROLL, DIRECT>;
-    using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, 5, ROLL, DIRECT>;
+    using C3_2 = ConvInstR<64, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
+    using C4_1 = ConvInstR<64, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
+    using C4_2 = ConvInstR<128, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
+    using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
+    using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
+    using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
     // experiment (Y355_RING_HALF): half-size tiles, two 4-wave workgroups per CU, staggered start
     using C67H = ConvInstR<256, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
     using C5H = ConvInstR<128, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
