@@ -73,7 +73,8 @@ void y355_destroy(y355_engine *h);
 int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
 /* engine options.  Y355_OPT_FUSE_FRONT (default 1): run input quantisation, conv1, pool1, conv2 and pool2
  * (models/slim_yolo_v2.py:218-244; first_conv + second_conv of c_embedding/yolo_forward.c:269-572) as one launch whose
- * 16-channel intermediate map stays on chip; 0 = one launch per layer (then y355_get_feature(0) is current after a forward).
+ * 16-channel intermediate map stays on chip (y355_get_feature(h, 0, ...) returns Y355_ENOTREADY after such a forward);
+ * 0 = one launch per layer (then y355_get_feature(0) is current after a forward).
  * Results are identical bit for bit either way. */
 #define Y355_OPT_FUSE_FRONT 1
 /* Y355_OPT_RING_WORKGROUPS (default 0 = one per CU): persistent workgroups per launch of the deep convolutions.  A handle that
@@ -218,8 +219,10 @@ int y355_head_nms(y355_engine *h, const int8_t *pred_q, int batch, int sa_pred,
 /* --- multi-GPU exchange: the batch is sharded over the GPUs of one node (one process per GPU, rank r owns a
  * contiguous range of images, weights replicated, no collective on the data path).  The only exchange is ONE RCCL
  * all-gather per batch of the padded detections, packed into one buffer of fixed-size records:
- *   record = i32 count (-1: padding record of a ragged shard), i32 pad[3], f32 boxes[max_det][4], f32 scores[max_det],
- *            i32 cls[max_det], rounded up to 16 bytes = y355_packed_det_bytes(max_det); entries past `count` are zero.
+ *   record = i32 count (-1: padding record of a ragged shard), i32 total (detections the image had; > count when
+ *            y355_pack_dets_capped cut the record at max_det; -1 in a padding record), i32 pad[2], f32 boxes[max_det][4],
+ *            f32 scores[max_det], i32 cls[max_det], rounded up to 16 bytes = y355_packed_det_bytes(max_det); entries past
+ *            `count` are zero.
  * The reference has no multi-GPU code; these are the entry points a multi-process host binds.  RCCL is bound at run time
  * (the copy already loaded in the process, e.g. PyTorch's, is reused).
  *   y355_comm_unique_id   rank 0 makes the 128-byte id and ships it to the other ranks by any host channel
@@ -258,6 +261,10 @@ int y355_profile_get(y355_engine *h, float *ms /*[Y355_NUM_TIMERS]*/);
  * the slots above from a run with y355_profile(h, 1).  0 for layers whose launch does not record them (today: recorded by
  * the six ring-kernel layers conv3_2 .. pred) */
 int y355_profile_kernel_get(y355_engine *h, float *ms /*[10]*/);
+/* host-only: the 16 KiB of MFMA weight fragments the fused front end (csrc/front.hip: conv1 + pool1 + conv2 + pool2,
+ * models/slim_yolo_v2.py:218-244) streams; q_w1 int8 [16][3][3][3], q_w2 int8 [32][16][3][3] (either may be null: its part
+ * stays zero).  y355_load_layer does this itself; exported so that the layout can be checked without a GPU. */
+int y355_pack_front_weights(const int8_t *q_w1, const int8_t *q_w2, int8_t *dst /*[16384]*/);
 /* diagnostic builds (-DY355_DIAG=1): arm / read the s_memtime stamps of one conv layer */
 int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *out_host, int nwg);
 /* diagnostics (env Y355_NMS_STAMPS=1): s_memtime stamps [4 kernels][256 workgroups][8 slots] of the head / NMS kernels */

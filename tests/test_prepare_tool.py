@@ -78,8 +78,9 @@ def _model(sd, H, W):
 
 @pytest.mark.gpu
 def test_prepare_multi_batch_calibration():
-    """--calib-batch N: the calibration loop of retune_bias_quantize.py:357-369 (EMA trackers over batches, stop after
-    more than `calib_images` images) == the oracle's trackers driven the same way on the same quantized weights."""
+    """--calib-batch N: the calibration loop of retune_bias_quantize.py:357-369 (EMA trackers over batches, stop after the
+    batch in front of which more than `calib_images` images had been seen) == the oracle's trackers driven over the batch
+    count the reference's own condition gives."""
     from yolo355.tools import prepare as P
     H, W = 96, 160
     layers, sd = _fp32_sd(2)
@@ -89,10 +90,31 @@ def test_prepare_multi_batch_calibration():
     ql = O.quantize_layers([("l%d" % i, w, b) for i, (w, b) in enumerate(folded)])
     x = synth.normalize_frames(frames)
     tr = [O.RangeTracker() for _ in range(11)]
-    for i0 in (0, 2, 4):                                    # the third batch takes the count past 4: the loop stops after it
+    assert P.calib_batches(7, 2, 4) == 4
+    for i0 in (0, 2, 4, 6):          # reference condition `batch_size * iter_i > 4`, checked after batch iter_i (0-based): 4 batches
         O.forward_backbone_int(x[i0:i0 + 2], ql, tr, quant_freeze=False, saturate=True, keep=False)
     assert [int(v) for v in package["sa"]] == [t.exponent() for t in tr]
     got = [float(getattr(qm, n).scale.item()) for n in ("a_tracker_in", "a_tracker3_2", "a_tracker_pred")]
     ref = [float(tr[i].scale.item()) for i in (0, 4, 10)]
     assert np.allclose(got, ref, rtol=1e-6, atol=0)
     assert all(int(getattr(qm, "a_tracker%s" % s).first_a.item()) == 1 for s in ("_in", "1", "_pred"))
+
+
+def test_calibration_loop_batch_count_is_the_references():
+    """retune_bias_quantize.py:324,365-367: `for iter_i, batch in enumerate(loader): forward(batch); if batch_size * iter_i >
+    1000: break` -- restated literally here and compared with tools.prepare.calib_batches (the loop used to stop
+    one batch early)."""
+    from yolo355.tools.prepare import calib_batches
+
+    def reference_loop(n_images, bs, limit):
+        done = 0
+        for iter_i in range(-(-n_images // bs)):
+            done += 1
+            if bs * iter_i > limit:
+                break
+        return done
+
+    assert calib_batches(5000, 32) == 33 == reference_loop(5000, 32, 1000)      # 1056 images
+    for n, bs, lim in [(7, 2, 4), (5000, 16, 1000), (5000, 64, 1000), (100, 32, 1000), (1001, 1, 1000), (3000, 1000, 1000),
+                       (10, 3, 0), (64, 64, 1000)]:
+        assert calib_batches(n, bs, lim) == reference_loop(n, bs, lim), (n, bs, lim)

@@ -46,7 +46,10 @@ int load_rccl() {
     for (const char *n : names)
         if (!h) h = dlopen(n, RTLD_LAZY | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_LAZY | RTLD_GLOBAL);
-    if (!h) return y355_fail(Y355_ENOTREADY, std::string("RCCL is not loadable: ") + (dlerror() ? dlerror() : "?"));
+    if (!h) {
+        const char *de = dlerror();                   // one call: dlerror() clears the message it returns
+        return y355_fail(Y355_ENOTREADY, std::string("RCCL is not loadable: ") + (de ? de : "?"));
+    }
     g_rccl.GetUniqueId = (int (*)(nccl_uid *))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(nccl_comm *, int, nccl_uid, int))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(nccl_comm))dlsym(h, "ncclCommDestroy");
@@ -118,9 +121,11 @@ __global__ __launch_bounds__(256) void pack_dets_kernel(const float4 *boxes, con
     if (u >= rec16) return;
     const size_t rec_bytes = rec_bytes_of(max_det);
     char *rec = (char *)packed + (size_t)b * rec_bytes;
-    const int n = b < batch ? min(max(count[b], 0), max_det) : 0;
+    const int full = b < batch ? max(count[b], 0) : 0;
+    const int n = min(full, max_det);
     if (u == 0) {
-        *(v4i *)rec = (v4i){b < batch ? n : -1, 0, 0, 0};
+        // header: detections kept, detections the image had (> kept: the record was cut at max_det), 0, 0
+        *(v4i *)rec = (v4i){b < batch ? n : -1, b < batch ? full : -1, 0, 0};
     } else if (u <= max_det) {
         const int i = u - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

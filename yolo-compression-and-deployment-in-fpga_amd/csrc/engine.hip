@@ -115,6 +115,12 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     if (sh < 0) lim = std::ldexp((long double)tmax, -sh);
     if (lim >= std::ldexp(1.0L, 62)) return fail(Y355_ERANGE, "fixed-point epilogue exceeds 62 bits");
     rq->wide = lim >= std::ldexp(1.0L, 30) ? 1 : 0;
+    {
+        const long long t0 = ((long long)127 * 127 * 9 * cin_real) * (1ll << shl) + bmax;
+        int n = 0;
+        while (n < 62 && t0 >= (1ll << n)) ++n;
+        rq->tmax_log2 = n;
+    }
     if (!rq->wide && sh > 31) sh = 31;
     rq->shl = shl;
     rq->sh = sh;
@@ -157,6 +163,7 @@ struct y355_engine {
     int *rs_tab = nullptr;          // [xofs W | xa 2W | yofs H | yb 2H]
     int rs_src_h = 0, rs_src_w = 0;
     int8_t *w0_dev = nullptr;       // conv1 fragment
+    int8_t *wf_dev = nullptr;       // weight fragments of the fused front end (y355_pack_front)
     Counters *ctr_dev = nullptr;    // [10]
     unsigned int *absmax_dev = nullptr;
     int8_t *sink_dev = nullptr;
@@ -174,6 +181,8 @@ struct y355_engine {
     int stamp_layer = -1;
     int profile = 0;
     int fuse_front = 1;             // conv1 + pool1 + conv2 + pool2 as one launch (front.hip) where eligible
+    int l0_batch = 0;               // images of conv1's pooled map that the last launches left valid in L[0].out_dev (the fused
+                                    // front end keeps that map on chip: 0 after a fused forward)
     int ring_wgs = 0;               // persistent workgroups per ring launch (0 = one per CU)
     hipEvent_t ev[Y355_NUM_TIMERS + 1];
     hipEvent_t kev[10][2];      // per-layer kernel start / stop timestamps (ring kernels, profile mode)
@@ -266,6 +275,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     }
     const size_t cap = Y355_NMS_CAP;
     if (!rc) rc = dmalloc(h, (void **)&h->w0_dev, 1024, true);
+    if (!rc) rc = dmalloc(h, (void **)&h->wf_dev, 16384, true);
     if (!rc) rc = dmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * 10, true);
     if (!rc) rc = dmalloc(h, (void **)&h->absmax_dev, 16, true);
     if (!rc) rc = dmalloc(h, (void **)&h->sink_dev, 16384, true);
@@ -343,11 +353,19 @@ extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const
         int8_t frag[1024];
         y355_pack_conv1(q_w, frag);
         HIPCHK(hipMemcpy(h->w0_dev, frag, 1024, hipMemcpyHostToDevice));
+        std::vector<int8_t> ff(16384);
+        y355_pack_front(q_w, nullptr, ff.data());
+        HIPCHK(hipMemcpy(h->wf_dev, ff.data(), 4096, hipMemcpyHostToDevice));
     } else {
         const ConvKernelInfo &ki = *y355_conv_kernel(L.kid);
         std::vector<int8_t> packed(y355_packed_bytes(ki, L.cout_pad));
         y355_pack_weights(ki, q_w, cout, cin, L.cout_pad, packed.data());
         HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        if (idx == 1) {
+            std::vector<int8_t> ff(16384);
+            y355_pack_front(nullptr, q_w, ff.data());
+            HIPCHK(hipMemcpy(h->wf_dev + 4096, ff.data() + 4096, 12288, hipMemcpyHostToDevice));
+        }
     }
     L.q_b.assign(q_b, q_b + cout);
     L.e_w = e_w;
@@ -434,6 +452,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.mode = mode;
         p.guard = guard;
         y355_launch_conv1(p, h->stream);
+        if (mode == 0) h->l0_batch = B;
     } else {
         const ConvKernelInfo &ki = *y355_conv_kernel(L.kid);
         ConvParams p{};
@@ -533,6 +552,9 @@ extern "C" int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst)
     if (!h || !dst || idx < 0 || idx >= 10) return fail(Y355_EINVAL, "bad argument");
     if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    if (idx == 0 && batch > h->l0_batch)
+        return fail(Y355_ENOTREADY, "conv1's map of the last forward was not written (fused front end): "
+                                    "run with y355_set_option(h, Y355_OPT_FUSE_FRONT, 0) to tap it");
     const Layer &L = h->L[idx];
     const int Hp = L.Hout + 2 * L.halo, Wp = L.Wout + 2 * L.halo, CS = L.cout_pad;
     std::vector<int8_t> tmp((size_t)batch * Hp * Wp * CS);
@@ -591,8 +613,7 @@ static int launch_front(y355_engine *h, int B, const float *x_dev) {
     p.x_u8 = x_dev ? nullptr : h->x_u8;
     for (int c = 0; c < 3; ++c) { p.nmean[c] = h->nmean[c]; p.nstd[c] = h->nstd[c]; }
     p.out = L1.out_dev;
-    p.w1 = h->w0_dev;
-    p.w2 = L1.w_dev;
+    p.wf = h->wf_dev;
     p.bias1 = L0.bias_dev;
     p.bias2 = L1.bias_dev;
     p.ctr = h->ctr_dev;
@@ -616,10 +637,11 @@ static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int fl
     const int guard = (flags & Y355_F_GUARD) ? 1 : 0;
     // the fused front end covers the 32-bit epilogue without the head-room guard; conv2's packed weights must be the
     // resident-weight layout (one n-block of 32 channels), which they are for this network
-    const bool fused = h->fuse_front && !guard && !h->L[0].rq.wide && !h->L[1].rq.wide && h->L[1].cout_pad == 32;
+    const bool fused = h->fuse_front && !guard && y355_front_eligible(h->L[0].rq, h->L[1].rq) && h->L[1].cout_pad == 32;
     for (int k = 0; k < 10; ++k) {
         if (prof) HIPCHK(hipEventRecord(h->ev[k], h->stream));
         if (fused && k == 0) {
+            h->l0_batch = 0;
             if (int rc = launch_front(h, batch, x_dev)) return rc;
             continue;
         }
@@ -734,14 +756,18 @@ extern "C" int y355_forward_u8(y355_engine *h, const uint8_t *frames_dev, int ba
 // fixed-point bilinear (imgproc/resize.cpp: 11-bit coefficients, horizontal pass in int32, vertical pass
 // (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2).  The coefficient tables are computed on the host with
 // OpenCV's own float / double expressions, so the kernel only gathers and does integer arithmetic.
-static void linear_tables(int src, int dst, int *ofs, int *coef) {
+// Horizontal axis: OpenCV clamps the offset AND zeroes the fraction at both borders.  Vertical axis (`vertical`): it keeps
+// floor(f) and the coefficient pair as they are and clips the two ROW INDICES instead (resizeGeneric_Invoker:
+// `sy = clip(sy0 - ksize2 + 1 + k, 0, ssize.height)`), so a border row is blended with itself through two separately
+// truncated products -- up to 1 LSB below the single-product form; the kernel does the same clipping.
+static void linear_tables(int src, int dst, int *ofs, int *coef, bool vertical) {
     const double scale = (double)src / (double)dst;
     for (int d = 0; d < dst; ++d) {
         float f = (float)((d + 0.5) * scale - 0.5);
         int sx = (int)std::floor(f);
         f -= (float)sx;
-        if (sx < 0) { sx = 0; f = 0.f; }
-        if (sx >= src - 1) { sx = src - 1; f = 0.f; }
+        if (!vertical && sx < 0) { sx = 0; f = 0.f; }
+        if (!vertical && sx >= src - 1) { sx = src - 1; f = 0.f; }
         ofs[d] = sx;
         const long c0 = std::lrintf((1.f - f) * 2048.f), c1 = std::lrintf(f * 2048.f);     // saturate_cast<short>: round half to even
         coef[2 * d] = (int)std::min(32767l, std::max(-32768l, c0));
@@ -756,7 +782,7 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t *src, uint
     const int dy = i / dw, dx = i % dw;
     const int *xofs = tab, *xa = tab + dw, *yofs = tab + 3 * dw, *yb = tab + 3 * dw + dh;
     const int sx0 = xofs[dx], sx1 = min(sx0 + 1, sw - 1), a0 = xa[2 * dx], a1 = xa[2 * dx + 1];
-    const int sy0 = yofs[dy], sy1 = min(sy0 + 1, sh - 1), b0 = yb[2 * dy], b1 = yb[2 * dy + 1];
+    const int sy0 = min(max(yofs[dy], 0), sh - 1), sy1 = min(max(yofs[dy] + 1, 0), sh - 1), b0 = yb[2 * dy], b1 = yb[2 * dy + 1];
     const uint8_t *s = src + (size_t)b * sh * sw * 3;
     uint8_t *d = dst + ((size_t)b * dh * dw + i) * 3;
 #pragma unroll
@@ -784,8 +810,8 @@ extern "C" int y355_forward_u8_resized(y355_engine *h, const uint8_t *frames_dev
     }
     if (h->rs_src_h != src_h || h->rs_src_w != src_w) {
         std::vector<int> tab(3 * (size_t)(H + W));
-        linear_tables(src_w, W, tab.data(), tab.data() + W);
-        linear_tables(src_h, H, tab.data() + 3 * W, tab.data() + 3 * W + H);
+        linear_tables(src_w, W, tab.data(), tab.data() + W, false);
+        linear_tables(src_h, H, tab.data() + 3 * W, tab.data() + 3 * W + H, true);
         HIPCHK(hipStreamSynchronize(h->stream));          // a previous forward may still read the old tables
         HIPCHK(hipMemcpy(h->rs_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
         h->rs_src_h = src_h;
@@ -899,6 +925,12 @@ extern "C" int y355_scale_boxes(y355_engine *h, float *boxes_dev, const int32_t 
     const int md = y355_max_det(h);
     hipLaunchKernelGGL(scale_boxes_kernel, dim3((md + 255) / 256, batch), dim3(256), 0, h->stream, boxes_dev, count_dev, wh_dev, md);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int y355_pack_front_weights(const int8_t *q_w1, const int8_t *q_w2, int8_t *dst) {
+    if (!dst) return fail(Y355_EINVAL, "null argument");
+    y355_pack_front(q_w1, q_w2, dst);
     return 0;
 }
 

@@ -5,74 +5,124 @@
 // and the FPGA driver's first_conv + second_conv (c_embedding/yolo_forward.c:269-572: the same fusion
 // boundary -- the camera frame goes in, the 32-channel quarter-resolution map comes out).
 //
-// Why: as three launches the 16- and 32-channel maps round-trip through HBM (45 MB + 23 MB written and read
-// back per 64-image batch) and each launch exposes its own load latency.  Here a persistent workgroup walks
-// tiles of TOY x TOX pooled conv2 outputs:
-//   Q   the fp32 (or uint8) input patch of the tile, prefetched into registers during the previous tile's
-//       MFMA phases, is quantised into an LDS patch of 4-byte pixels (r, g, b, 0);
-//   C1  conv1 on the matrix cores (one v_mfma_i32_16x16x64_i8 per 16 pixels x 16 channels, K = 3 filter rows
-//       x 4 pixels x 4 bytes, rows ordered as 2x2 pooling windows so the pool is a max over the lane's four
-//       accumulators) -> int8 pooled tile WITH its one-pixel halo in LDS (halo pixels are recomputed, pixels
-//       outside the image are zero: conv2's padding);
-//   C2  conv2 from that LDS tile (K = 9 taps x 16 channels in three 64-deep steps, weights resident in
-//       registers) -> pooled int8 tile staged in LDS;
-//   OUT 16-byte coalesced stores of the NHWC32 tile.
-// Integer semantics are those of conv1.hip / conv3x3_v2.hip, bit for bit; saturation is
-// detected with one op per output and counted exactly (own pixels only) in a cold second pass.
+// Round 3 rewrite.  The round-2 kernel was instruction-issue-bound (profiles/r02_notes.md: 1 940 instructions per
+// wave and tile, 17 VALU per conv1 MFMA); this one spends about 0.6 of that:
+//   * the 2x2 pooling window is the unit of work.  A window of a 3x3 / pad-1 convolution followed by a 2x2 pool reads
+//     a 4x4 input neighbourhood; the FOUR conv outputs of the window are four MFMAs over the SAME neighbourhood
+//     operand with four weight fragments (the 3x3 filter placed at the four offsets inside the 4x4 neighbourhood,
+//     zeros elsewhere).  conv1: 4x4 px x 4 B = exactly one 64-deep k-step; conv2: four k-steps (neighbourhood rows)
+//     of 4 px x 16 ch.  One set of LDS reads feeds all four pool partners;
+//   * weights are the MFMA's A operand (rows = output channels), pixels the B operand (columns = 16 windows): a lane
+//     then holds FOUR CHANNELS of ONE window in an accumulator, the pool is an element-wise max over the four MFMA
+//     results (no cross-lane step), and the int8 results leave as one packed ds_write_b32 / b64 per lane;
+//   * the biases ride in as the MFMAs' C operand (when the layer's accumulator shift is zero: template FOLD);
+//   * the requantisation runs in fp32 on exact integers: t < 2^24 (host-checked, Requant::tmax_log2), so
+//         q = low byte of med3(max(fma(t, 2^(lk-sh), M), fma(t, 2^-sh, M)), M - 127, M + 127),   M = 1.5 * 2^23
+//     is RNE(t' * 2^-sh) clamped, bit for bit the integer pipeline of DESIGN.md section 2: the fma rounds the exact
+//     product once, to the integer grid of [2^23, 2^24), ties to even; five VALU operations instead of eight;
+//   * the input quantisation uses the same fma: q = low byte of fma(x, 2^sa0, M); three values are packed with two
+//     v_perm_b32; clamped inputs are detected from max |x| and handled (and counted exactly) in a cold pass.
+// Integer semantics are those of conv1.hip / conv3x3_v2.hip, bit for bit; saturation is detected with one op per output
+// and counted exactly (own pixels only) in a cold second pass.
 #include "y355_common.h"
 #include <type_traits>
-#ifndef FRONT_PREFETCH
-#define FRONT_PREFETCH 0
-#endif
+#include <cstring>
 #ifndef FRONT_OCC
 #define FRONT_OCC 3
 #endif
-#ifndef FRONT_P0_PAD
-#define FRONT_P0_PAD 1           // 1: conflict-free patch pitch (72 pixels); 0: dense pitch (60): 2.8 KiB less LDS per workgroup
-#endif
+#ifndef FRONT_P0
+#define FRONT_P0 64              // patch pitch in pixels (dwords): 32 mod 64 keeps the two filter rows of a half-wave's
+#endif                           // ds_read_b64 on disjoint banks
 #ifndef FRONT_DIAG
 #define FRONT_DIAG 0             // 1: s_memtime stamps at the phase boundaries of each workgroup's first tiles (y355_debug_stamps)
 #endif
 
-// 16-byte pixels: the LDS pitch (in pixels) that makes the A-fragment ds_read_b128 of 2x2-window-ordered
-// rows conflict-free under gfx950's 4 x 16 lane grouping (conv3x3_v2.hip: pitch = 8 mod 16)
-constexpr int front_pitch32(int pw) { int p = pw; while (p % 32 != 8) ++p; return p; }
-constexpr int front_pitch16(int pw) { int p = pw; while (p % 16 != 8) ++p; return p; }
+namespace {
+constexpr int TOY = 13, TOX = 13;                    // pooled conv2 outputs per tile
+constexpr int P1H = 2 * TOY + 2, P1W = 2 * TOX + 2;  // pooled conv1 tile with its halo (windows of conv1)
+constexpr int PH0 = 2 * P1H + 2;                     // input patch rows (= columns used)
+constexpr int P0 = FRONT_P0;
+constexpr int P1P = P1W;                             // p1 pitch in 16-byte pixels (28: rows two apart differ by 8 mod 16 slots)
+constexpr int P1ROWS = P1H + 2;                      // slack rows: the clamped padding windows of C2 stay inside
+constexpr int NW1 = P1H * P1W;                       // 784 conv1 windows = 49 groups of 16
+constexpr int NG1 = NW1 / 16;
+constexpr int NW2 = TOY * TOX;                       // 169 conv2 windows = 11 groups of 16 (7 padding slots)
+constexpr int NG2 = (NW2 + 15) / 16;
+constexpr int QITEMS = 4;                            // input items (row, 4-pixel group) per thread: 16 wave-items of 4 rows
+constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23
+constexpr float QLO = 12582785.0f, QHI = 12583039.0f;   // MAGIC -+ 127
+static_assert(NW1 % 16 == 0 && PH0 <= 4 * 4 * QITEMS && P0 % 4 == 0 && P0 >= PH0 + 2, "front geometry");
 
 __device__ __forceinline__ void front_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// bare instructions: hipcc canonicalises (quiets) both operands of fmaxf / fabsf chains
+__device__ __forceinline__ float vmax(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float vmax3abs(float a, float b, float c) {      // max(a, |b|, |c|)
+    float d;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmaxabs(float a, float b) {               // max(a, |b|)
+    float d;
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// lane i of each row of 16 lanes receives lane i + 1's value (lane 15: zero)
+__device__ __forceinline__ unsigned int row_next(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+}
+// bytes 0 of four registers -> one dword
+__device__ __forceinline__ unsigned int pack4(float a, float b, float c, float d) {
+    const unsigned int ab = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x0c0c0400u);
+    const unsigned int cd = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x04000c0cu);
+    return ab | cd;
+}
+// (r, g, b) bytes 0 -> pixel word (r, g, b, 0)
+__device__ __forceinline__ unsigned int pack3(float r, float g, float b) {
+    const unsigned int rg = __builtin_amdgcn_perm(__float_as_uint(g), __float_as_uint(r), 0x0c0c0400u);
+    return __builtin_amdgcn_perm(__float_as_uint(b), rg, 0x0c040100u);
+}
 
-template <int TOY, int TOX>
-struct FrontGeom {
-    static constexpr int P1H = 2 * TOY + 2, P1W = 2 * TOX + 2;     // pooled conv1 tile (windows), with halo
-    static constexpr int PH0 = 2 * P1H + 2;                        // input patch rows
-    static constexpr int NG = (2 * P1W + 4) / 4;                   // 4-pixel groups per patch row (16-byte aligned in x)
-    // patch pitch in pixels (= dwords): 8 mod 32, so that the three patch rows an A fragment's half-wave touches (eight
-    // consecutive dwords each) fall into disjoint LDS banks (pitch 60 made every ds_read_b32 a 2-way conflict)
-    static constexpr int P0 = FRONT_P0_PAD ? front_pitch32(NG * 4) : NG * 4;
-    static constexpr int NITEM = PH0 * NG;
-    static constexpr int IPT = (NITEM + 255) / 256;
-    static constexpr int P1P = front_pitch16(P1W);
-    static constexpr int MT1 = P1W / 4;                            // conv1 m-tiles (4 windows) per window row
-    static constexpr int NWIN = TOY * TOX;
-    static constexpr int MT2_TOT = (NWIN + 3) / 4;
-    static constexpr int MT2 = (MT2_TOT + 3) / 4;                  // conv2 m-tiles per wave
-    static_assert(P1W % 4 == 0, "window rows split into whole m-tiles (TOX odd)");
+// fp32 form of the epilogue of one layer (see the header): q = low byte of yc
+// FOLD (accumulator shift 0, |t| < 2^22, |sh| small: y355_launch_front): the MFMAs' C operand is bias + 0x4B400000, so the
+// int32 accumulator IS the bit pattern of the float M + t (no v_cvt), and M + t * s = fma(M + t, s, M * (1 - s)) exactly
+// (M * (1 - s) is representable for 2^-22 <= s <= 2^8).
+struct RqF {
+    float s_pos, s_neg;      // 2^(lk - sh), neg_mul * 2^-sh
+    float c_pos, c_neg;      // FOLD: M * (1 - s); else M
+    float scl;               // !FOLD: 2^shl
 };
+template <bool FOLD>
+__device__ __forceinline__ RqF make_rqf(const Requant &rq) {
+    RqF r;
+    r.s_pos = ldexpf(1.0f, rq.lk - rq.sh);
+    r.s_neg = (float)rq.neg_mul * ldexpf(1.0f, -rq.sh);
+    r.c_pos = FOLD ? MAGIC - MAGIC * r.s_pos : MAGIC;
+    r.c_neg = FOLD ? MAGIC - MAGIC * r.s_neg : MAGIC;
+    r.scl = ldexpf(1.0f, rq.shl);
+    return r;
+}
+// pooled accumulator -> M + rne(t' * 2^-sh), unclamped
+template <bool FOLD>
+__device__ __forceinline__ float rq_round(int m, float biasf, const RqF &r) {
+    const float tf = FOLD ? __int_as_float(m) : fmaf((float)m, r.scl, biasf);   // (float)m exact: |t| < 2^24
+    return vmax(fmaf(tf, r.s_pos, r.c_pos), fmaf(tf, r.s_neg, r.c_neg));         // RNE is monotone: round(max) = max(round)
+}
+}  // namespace
 
-template <int TOY, int TOX, bool U8>
+template <bool U8, bool FOLD>
 __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams p, const int total_tiles) {
-    using G = FrontGeom<TOY, TOX>;
-    constexpr int P1H = G::P1H, P1W = G::P1W, NG = G::NG, P0 = G::P0, NITEM = G::NITEM, IPT = G::IPT;
-    constexpr int P1P = G::P1P, MT1 = G::MT1, NWIN = G::NWIN, MT2 = G::MT2;
     // separate LDS objects: the compiler then knows that the writes of one phase do not alias the reads of the same phase
-    // (with one array every ds_write of an m-tile fenced the next m-tile's ds_reads and the phases ran as serial chains)
-    __shared__ __attribute__((aligned(16))) unsigned int patch[G::PH0 * P0 + 4];
-    __shared__ __attribute__((aligned(16))) char p1[(P1H + 3) * P1P * 16];   // + slack: padding windows of C2 read past the tile
-    __shared__ __attribute__((aligned(16))) char stg[MT2 * 4 * 4 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned int patch[PH0 * P0];
+    __shared__ __attribute__((aligned(16))) char p1[P1ROWS * P1P * 16];
+    __shared__ __attribute__((aligned(16))) char stg[NG2 * 16 * 32];
     __shared__ __attribute__((aligned(16))) unsigned int lut[U8 ? 3 * 256 : 4];
 
     const int tid = threadIdx.x;
@@ -83,62 +133,27 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     const int Hp = H >> 1, Wp = W >> 1, Ho = H >> 2, Wo = W >> 2;
     const size_t plane = (size_t)H * W;
     const float sc = p.in_scale;
+    const float in_thr = 127.5f / sc;                  // |x| >= thr  <=>  rne(|x| * 2^sa0) > 127 (sc is a power of two)
 
-    // ---- tile-independent per-thread geometry
-    // patch item k of this thread = tid + 256 k: row r, 4-pixel group j (256 = 17 rows + 1 group when NG = 15)
-    int r0 = tid / NG, j0 = tid % NG;
-    auto item_rj = [&](int k, int &r, int &j, bool &ok) {
-        const int jj = j0 + (256 % NG) * k;
-        const int wrap = jj / NG;                          // k * (256 % NG) + j0 < 4 * NG: a couple of compares
-        j = jj - wrap * NG;
-        r = r0 + (256 / NG) * k + wrap;
-        ok = tid + 256 * k < NITEM;
-    };
-    const int r4 = li & 3;
-    int lbase1 = ((r4 >> 1) + min(g, 2)) * P0 + 2 * (li >> 2) + (r4 & 1) + 1;
-    // conv2 A-fragment base of this lane's row in the wave's first m-tile; later m-tiles step 4 windows to the right
-    // with wrap-around (windows past the tile's last one read and write padding that is never copied out)
-    const int w2_0 = wave * MT2 * 4 + (li >> 2);
-    int wx2_0 = w2_0 % TOX;
-    int ab2_0 = ((2 * (w2_0 / TOX) + (r4 >> 1)) * P1P + 2 * wx2_0 + (r4 & 1)) * 16;
-    int kofs2[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int tap = min(4 * t + g, 8);
-        kofs2[t] = ((tap / 3) * P1P + tap % 3) * 16;
-    }
-    int oofs[2], orc[2];                                  // OUT: relative output offset, (row << 8) | col or -1
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int item = tid + 256 * k;
-        const int px = item >> 1, half = item & 1;
-        const int row = px / TOX, col = px % TOX;
-        orc[k] = item < NWIN * 2 ? ((row << 8) | col) : -1;
-        oofs[k] = (row * (Wo + 2) + col) * 32 + half * 16;
-    }
-    // weights and biases stay in registers for the whole launch
-    const v4i bw1 = *(const v4i *)(p.w1 + lane * 16);
-    v4i bw2[3][2];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bw2[t][n] = *(const v4i *)(p.w2 + (t * 2 + n) * 1024 + lane * 16);
+    // ---- biases stay in registers for the whole launch; the weight fragments (16 KiB, L2-resident) are re-read per tile
+    // just ahead of the phase that uses them, so that they are not live across the other phases (168 / 128 registers)
     const Requant rq1 = p.rq1, rq2 = p.rq2;
-    const int shl1 = rq1.shl + rq1.sh_l, shl2 = rq2.shl + rq2.sh_l;
-    const int bias1 = p.bias1[li] << rq1.sh_l;
-    const int bias2a = p.bias2[2 * li] << rq2.sh_l, bias2b = p.bias2[2 * li + 1] << rq2.sh_l;
-    auto requant1 = [&](int v) {
-        int x = (v << shl1) + bias1;
-        x = max(x, x << rq1.lk);
-        const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq1.sh_r, (unsigned int)rq1.bw);
-        return (x + rq1.hm1 + rb) >> rq1.sh_r;
-    };
-    auto requant2 = [&](int v, int bias) {
-        int x = (v << shl2) + bias;
-        x = max(x, x << rq2.lk);
-        const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq2.sh_r, (unsigned int)rq2.bw);
-        return (x + rq2.hm1 + rb) >> rq2.sh_r;
-    };
+    const RqF f1 = make_rqf<FOLD>(rq1), f2 = make_rqf<FOLD>(rq2);
+    // accumulator register r of lane (li, g): conv1 channel 4 g + r; conv2 n-tile n: channel 8 g + 4 n + r
+    v4i cin1, cin2[2];
+    float bf1[4], bf2[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b1 = p.bias1[4 * g + r];
+        cin1[r] = FOLD ? b1 + 0x4B400000 : 0;
+        bf1[r] = (float)b1;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int b2 = p.bias2[8 * g + 4 * n + r];
+            cin2[n][r] = FOLD ? b2 + 0x4B400000 : 0;
+            bf2[n][r] = (float)b2;
+        }
+    }
     if constexpr (U8) {
         // normalise + quantise is a function of the byte: per channel a 256-entry table built with the reference's
         // fp32 operations in the reference's order ((u/255 - mean)/std, data/__init__.py:43-45; round(x * 2^sa),
@@ -156,26 +171,57 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
         }
     }
 
-    const int G_ = gridDim.x;
-    const int vb = y355_xcd_remap(blockIdx.x, G_);
-    auto decode = [&](int t, int &b, int &ty, int &tx) {
-        tx = t % p.tiles_x;
-        t /= p.tiles_x;
-        ty = t % p.tiles_y;
-        b = t / p.tiles_y;
-    };
-    // prefetch registers: IPT items x 3 channels x 4 pixels (fp32), or IPT x 12 bytes (uint8 HWC BGR)
-    float4 vf[U8 ? 1 : IPT][3];
-    uint3 vu[U8 ? IPT : 1];
-    auto load_tile = [&](int b, int ty, int tx) {
-        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+    // ---- tile-independent per-thread geometry
+    // Q: wave-item q = wave + 4 k covers patch rows 4 q .. 4 q + 3; lane = 16 * (row in the item) + 4-pixel group j
+    // (j = 15 is an idle slot: 15 groups = 60 pixels per row are loaded)
+    int qr0 = 4 * wave + g;                            // row of item k: qr0 + 16 k
+    const int qj = li;
+    // OUT: relative output offset, (row << 8) | col or -1
+    int oofs[2], orc[2];
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            int r, j;
-            bool ok;
-            item_rj(k, r, j, ok);
-            const int gy = min(max(y0p + r, 0), H - 1);       // items past the patch re-read valid rows
-            const int gx = min(max(x0p + 4 * j, 0), W - 4);
+    for (int k = 0; k < 2; ++k) {
+        const int item = tid + 256 * k;
+        const int px = item >> 1, half = item & 1;
+        const int row = px / TOX, col = px % TOX;
+        orc[k] = item < NW2 * 2 ? ((row << 8) | col) : -1;
+        oofs[k] = (row * (Wo + 2) + col) * 32 + half * 16;
+    }
+
+    const int G_ = gridDim.x;
+    int tile = y355_xcd_remap(blockIdx.x, G_);
+    if (tile >= total_tiles) return;
+    int nstamp = 0;
+    auto stamp = [&]() {
+#if FRONT_DIAG
+        if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
+#endif
+    };
+    (void)nstamp;
+    if constexpr (U8) front_lds_barrier();              // the table is complete
+    unsigned int nsat_in = 0, nsat1 = 0, nsat2 = 0;
+
+    for (;; tile += G_) {
+        // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
+        // out of the tile loop as a loop invariant and held in registers
+        int li_ = li, g_ = g, lane_ = lane;
+        asm volatile("" : "+v"(qr0), "+v"(li_), "+v"(g_), "+v"(lane_));
+        int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+        const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
+        stamp();
+
+        v4i w1[4];                                         // conv1: variant (dy, dx) = v >> 1, v & 1
+#pragma unroll
+        for (int v = 0; v < 4; ++v) w1[v] = *(const v4i *)(p.wf + v * 1024 + lane_ * 16);
+        // ---- load the tile's input patch: QITEMS x (3 x float4 | 12 bytes) per thread, all in flight together
+        float4 vf[U8 ? 1 : QITEMS][3];
+        uint3 vu[U8 ? QITEMS : 1];
+#pragma unroll
+        for (int k = 0; k < QITEMS; ++k) {
+            const int r = qr0 + 16 * k;
+            const int gy = min(max(y0p + r, 0), H - 1);           // rows / groups past the patch or the image re-read valid data
+            const int gx = min(max(x0p + 4 * qj, 0), W - 4);
             const size_t o = (size_t)gy * W + gx;
             if constexpr (U8) {
                 vu[k] = *(const uint3 *)(p.x_u8 + ((size_t)b * plane + o) * 3);
@@ -185,54 +231,22 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                 for (int c = 0; c < 3; ++c) vf[k][c] = *(const float4 *)(xb + c * plane);
             }
         }
-    };
-
-    int tile = vb;
-    if (tile >= total_tiles) return;
-    int nstamp = 0;
-    auto stamp = [&]() {
-#if FRONT_DIAG
-        if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
-#endif
-    };
-    (void)nstamp;
-    int b, ty, tx;
-    decode(tile, b, ty, tx);
-#if FRONT_PREFETCH
-    load_tile(b, ty, tx);
-#endif
-    if constexpr (U8) front_lds_barrier();              // the table is complete
-    unsigned int nsat_in = 0, nsat1 = 0, nsat2 = 0;
-
-    for (;;) {
-        // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
-        // out of the tile loop as a loop invariant and the kernel spills ~100 registers of precomputed addresses
-        asm volatile("" : "+v"(r0), "+v"(j0), "+v"(lbase1), "+v"(wx2_0), "+v"(ab2_0));
-        const int ntile = tile + G_;
-        const bool more = ntile < total_tiles;
-        int b2 = b, ty2 = ty, tx2 = tx;
-        if (more) decode(ntile, b2, ty2, tx2);
-        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
-        stamp();
-#if !FRONT_PREFETCH
-        load_tile(b, ty, tx);
 #if FRONT_DIAG
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp();
 #endif
-#endif
 
-        // ---- Q: quantise the prefetched patch into LDS: q = clamp(rne(x * 2^sa0))  (slim_yolo_v2.py:33-35)
-        {
-            float satm = 0.f;
+        // ---- Q: quantise into the LDS patch of 4-byte pixels (r, g, b, 0): q = clamp(rne(x * 2^sa0))  (slim_yolo_v2.py:33-35).
+        // Patch column L holds global column x0p + 1 + L: the 4x4 neighbourhood of every conv1 window then starts on an
+        // 8-byte boundary (one pixel to the left of the aligned 4-pixel groups the loads use: the fourth word of an
+        // LDS group comes from the next lane).
+        auto quantise = [&](auto clampc) {
+            constexpr bool CLAMP = decltype(clampc)::value;      // cold: clamp (and count the tile's own clamped values)
+            float am = 0.f;
             unsigned int sato = 0;
 #pragma unroll
-            for (int k = 0; k < IPT; ++k) {
-                int r, j;
-                bool ok;
-                item_rj(k, r, j, ok);
-                const int gy = y0p + r, gx = x0p + 4 * j;
-                const bool inside = ok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            for (int k = 0; k < QITEMS; ++k) {
+                const int r = qr0 + 16 * k;
                 unsigned int w[4];
                 if constexpr (U8) {
                     const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
@@ -247,47 +261,41 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                             e |= lut[c * 256 + u];
                         }
                         sato |= e;
-                        w[px] = e;
+                        w[px] = e & 0x00ffffffu;
                     }
                 } else {
 #pragma unroll
                     for (int px = 0; px < 4; ++px) {
-                        w[px] = 0;
-                        float sat0 = 0.f, sat1 = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float xv = px == 0 ? vf[k][c].x : px == 1 ? vf[k][c].y : px == 2 ? vf[k][c].z : vf[k][c].w;
-                            const float rr = rintf(xv * sc);
-                            const float rc = __builtin_amdgcn_fmed3f(rr, -127.f, 127.f);
-                            if (c == 0) sat0 = fabsf(rr);          // detection may see neighbours' pixels; the count below is exact
-                            else if (c == 1) sat1 = fabsf(rr);
-                            else satm = fmaxf(fmaxf(satm, sat0), fmaxf(sat1, fabsf(rr)));
-                            if (c == 0) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w[px]) : "v"(rc));
-                            else if (c == 1) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w[px]) : "v"(rc));
-                            else asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w[px]) : "v"(rc));
+                        const float xr = px == 0 ? vf[k][0].x : px == 1 ? vf[k][0].y : px == 2 ? vf[k][0].z : vf[k][0].w;
+                        const float xg = px == 0 ? vf[k][1].x : px == 1 ? vf[k][1].y : px == 2 ? vf[k][1].z : vf[k][1].w;
+                        const float xb = px == 0 ? vf[k][2].x : px == 1 ? vf[k][2].y : px == 2 ? vf[k][2].z : vf[k][2].w;
+                        float yr = fmaf(xr, sc, MAGIC), yg = fmaf(xg, sc, MAGIC), yb = fmaf(xb, sc, MAGIC);
+                        if constexpr (CLAMP) {
+                            yr = __builtin_amdgcn_fmed3f(yr, QLO, QHI);
+                            yg = __builtin_amdgcn_fmed3f(yg, QLO, QHI);
+                            yb = __builtin_amdgcn_fmed3f(yb, QLO, QHI);
+                        } else {
+                            am = vmax3abs(am, xr, xg);
+                            am = vmaxabs(am, xb);
                         }
+                        w[px] = pack3(yr, yg, yb);
                     }
                 }
-                if (ok) {
-                    v4i wv;
-                    wv[0] = inside ? (int)w[0] : 0;
-                    wv[1] = inside ? (int)w[1] : 0;
-                    wv[2] = inside ? (int)w[2] : 0;
-                    wv[3] = inside ? (int)w[3] : 0;
-                    *(v4i *)(patch + r * P0 + 4 * j) = wv;
-                }
-            }
-            // cold (also taken for NaN): exact count of clamped input values over the pixels this tile OWNS
-            // (rows [3, 3 + 4 TOY), groups [1, TOX] of the patch: the tiles' exclusive input areas partition the image)
-            if (U8 ? (sato & (1u << 24)) != 0 : !(satm <= 127.f)) {
+                const int gy = y0p + r, gx = x0p + 4 * qj;
+                const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const bool zero = border && !inside;              // pixels outside the image are conv1's zero padding
 #pragma unroll
-                for (int k = 0; k < IPT; ++k) {
-                    int r, j;
-                    bool ok;
-                    item_rj(k, r, j, ok);
-                    const int gy = y0p + r, gx = x0p + 4 * j;
-                    const bool own = ok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W &&
-                                     r >= 3 && r < 3 + 4 * TOY && j >= 1 && j <= TOX;
+                for (int px = 0; px < 4; ++px) w[px] = zero ? 0u : w[px];
+                v4i wv;
+                wv[0] = (int)w[1];
+                wv[1] = (int)w[2];
+                wv[2] = (int)w[3];
+                wv[3] = (int)row_next(w[0]);
+                if (r < PH0 && qj < 15) *(v4i *)(patch + r * P0 + 4 * qj) = wv;
+                if constexpr (CLAMP) {
+                    // exact count over the pixels this tile OWNS (rows [3, 3 + 4 TOY), load groups [1, TOX] of the
+                    // patch: the tiles' exclusive input areas partition the image)
+                    const bool own = inside && r >= 3 && r < 3 + 4 * TOY && qj >= 1 && qj <= TOX;
                     if constexpr (U8) {
                         const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
 #pragma unroll
@@ -300,105 +308,141 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                         for (int c = 0; c < 3; ++c) {
                             const float xs[4] = {vf[k][c].x, vf[k][c].y, vf[k][c].z, vf[k][c].w};
 #pragma unroll
-                            for (int px = 0; px < 4; ++px) {
-                                const float rr = rintf(xs[px] * sc);
-                                nsat_in += (own && fminf(fmaxf(rr, -127.f), 127.f) != rr) ? 1u : 0u;
-                            }
+                            for (int px = 0; px < 4; ++px) nsat_in += (own && !(fabsf(xs[px]) < in_thr)) ? 1u : 0u;
                         }
                     }
                 }
             }
+            return U8 ? (sato >> 24) != 0u : !(am < in_thr);          // also true for NaN / Inf inputs
+        };
+        if constexpr (U8) {
+            if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{})) != 0ull) (void)quantise(std::true_type{});
+        } else {
+            if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{})) != 0ull) (void)quantise(std::true_type{});
         }
         stamp();
         front_lds_barrier();                              // B1: patch complete
         stamp();
 
-        // ---- C1: conv1 + pool1 -> p1 (wave w owns window rows w, w + 4, ...)
+        v4i w2[2][3][2];                                   // conv2: [n-tile][filter row][dx]; in flight during C1
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) w2[n][ky][dx] = *(const v4i *)(p.wf + 4096 + ((n * 3 + ky) * 2 + dx) * 1024 + lane_ * 16);
+        // ---- C1: conv1 + pool1 -> p1.  Group = 16 consecutive windows of the 28 x 28 window grid (row-major);
+        // wave w owns groups w, w + 4, ...  Lane (li, g): window li of the group, neighbourhood row g.
         const int gyp0 = 2 * TOY * ty - 1, gxp0 = 2 * TOX * tx - 1;     // pooled coordinates of window (0, 0)
-        const bool xborder = gxp0 < 0 || gxp0 + P1W > Wp;
-        auto c1 = [&](auto countc) {
-            constexpr bool COUNT = decltype(countc)::value;
+        auto c1 = [&](auto countc, auto borderc) {
+            constexpr bool COUNT = decltype(countc)::value, BORDER = decltype(borderc)::value;
             unsigned int satx = 0;
+            auto body = [&](int grp) {
+                const int w = grp * 16 + li_;
+                const int py = (w * 2341) >> 16;                  // w / 28 for w < 784
+                const int px = w - py * P1W;
+                const unsigned int *src = patch + (2 * py + g_) * P0 + 2 * px;
+                const uint2 lo = *(const uint2 *)src, hi = *(const uint2 *)(src + 2);
+                const v4i bq = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+                v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[0], bq, cin1, 0, 0, 0);
+                v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[1], bq, cin1, 0, 0, 0);
+                v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[2], bq, cin1, 0, 0, 0);
+                v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[3], bq, cin1, 0, 0, 0);
+                float y[4], yc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = max(max(a0[r], a1[r]), max(a2[r], a3[r]));
+                    y[r] = rq_round<FOLD>(m, bf1[r], f1);
+                    yc[r] = __builtin_amdgcn_fmed3f(y[r], QLO, QHI);
+                }
+                const bool inimg = !(BORDER || COUNT) || ((unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp);
+                if constexpr (!COUNT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
+                    unsigned int word = pack4(yc[0], yc[1], yc[2], yc[3]);
+                    if constexpr (BORDER) word = inimg ? word : 0u;   // windows outside the image: conv2's zero padding
+                    *(unsigned int *)(p1 + (py * P1P + px) * 16 + 4 * g_) = word;
+                } else {
+                    const bool own = inimg && py >= 1 && py < P1H - 1 && px >= 1 && px < P1W - 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                }
+            };
+            // wave w owns groups w, w + 4, ..., two per trip so that one group's epilogue runs under the other's MFMAs
 #pragma unroll 1
-            for (int wy = wave; wy < P1H; wy += 4) {
-                if ((unsigned)(gyp0 + wy) >= (unsigned)Hp) {          // row outside the image: conv2's zero padding
-                    if (!COUNT && lane < P1W) *(v4i *)(p1 + (wy * P1P + lane) * 16) = (v4i){0, 0, 0, 0};
-                    continue;
-                }
-                const unsigned int *src = patch + lbase1 + wy * 2 * P0;
-                char *dst = p1 + (wy * P1P + g) * 16 + li;
-                // the row's seven A fragments first, then seven independent MFMAs, then the epilogues: written in this
-                // order so that the LDS latency and the MFMA pipeline latency are paid once per row, not once per m-tile
-                v4i a[MT1], acc[MT1];
-#pragma unroll
-                for (int mt = 0; mt < MT1; ++mt) {
-                    a[mt][0] = (int)src[mt * 8 + 0];
-                    a[mt][1] = (int)src[mt * 8 + 1];
-                    a[mt][2] = (int)src[mt * 8 + 2];
-                    a[mt][3] = (int)src[mt * 8 + 3];
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT1; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mt], bw1, (v4i){0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT1; ++mt) {
-                    const int vmax = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
-                    const int qq = requant1(vmax);
-                    const int q = y355_clamp8<int>(qq);
-                    if constexpr (!COUNT) {
-                        satx += (unsigned int)(q ^ qq);
-                        dst[mt * 64] = (char)q;
-                    } else {
-                        int gl = g;
-                        asm volatile("" : "+v"(gl));              // cold path: nothing of it may be hoisted out of the tile loop
-                        const int wx = 4 * mt + gl;
-                        const bool own = wy >= 1 && wy < P1H - 1 && wx >= 1 && wx < P1W - 1 && gxp0 + wx < Wp;
-                        satx += (own && q != qq) ? 1u : 0u;
-                    }
-                }
-                if (!COUNT && xborder && lane < P1W && (unsigned)(gxp0 + lane) >= (unsigned)Wp)
-                    *(v4i *)(p1 + (wy * P1P + lane) * 16) = (v4i){0, 0, 0, 0};
+            for (int i = 0; i < NG1 / 8; ++i) {
+                body(wave + 8 * i);
+                body(wave + 8 * i + 4);
             }
+            if (wave < NG1 % 8) body(wave + 8 * (NG1 / 8));
+            static_assert(NG1 % 8 <= 4, "tail groups: at most one per wave");
             return satx;
         };
-        if (__builtin_amdgcn_ballot_w64(c1(std::false_type{}) != 0) != 0ull) nsat1 += c1(std::true_type{});
+        unsigned int s1 = border ? c1(std::false_type{}, std::true_type{}) : c1(std::false_type{}, std::false_type{});
+        if (__builtin_amdgcn_ballot_w64(s1 != 0) != 0ull) nsat1 += c1(std::true_type{}, std::true_type{});
         stamp();
         front_lds_barrier();                              // B2: p1 complete
         stamp();
-#if FRONT_PREFETCH
-        if (more) load_tile(b2, ty2, tx2);                // the next tile's input: in flight during C2 and OUT
-#endif
 
-        // ---- C2: conv2 + pool2 -> staged int8 tile (wave w owns m-tiles w * MT2 ..)
+        // ---- C2: conv2 + pool2 -> staged int8 tile.  Group = 16 consecutive windows of the 13 x 13 grid (the last
+        // group's padding slots repeat window 168); k-step t = neighbourhood row t, lane group g = neighbourhood column.
         auto c2 = [&](auto countc) {
             constexpr bool COUNT = decltype(countc)::value;
             unsigned int satx = 0;
-            int ab = ab2_0, wx = wx2_0;
-#pragma unroll 2
-            for (int m = 0; m < MT2; ++m) {
-                v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll 1
+            for (int grp = wave; grp < NG2; grp += 4) {
+                const int wraw = grp * 16 + li_;
+                const int w = min(wraw, NW2 - 1);
+                const int wy = (w * 5042) >> 16;                  // w / 13 for w < 169
+                const int wx = w - wy * TOX;
+                const char *src = p1 + ((2 * wy) * P1P + 2 * wx + g_) * 16;
+                v4i acc[2][2][2];                                 // [dy][dx][n]
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const v4i a = *(const v4i *)(p1 + ab + kofs2[t]);
-                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw2[t][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bw2[t][1], acc1, 0, 0, 0);
-                }
-                const int qq0 = requant2(max(max(acc0[0], acc0[1]), max(acc0[2], acc0[3])), bias2a);
-                const int qq1 = requant2(max(max(acc1[0], acc1[1]), max(acc1[2], acc1[3])), bias2b);
-                const int q0 = y355_clamp8<int>(qq0), q1 = y355_clamp8<int>(qq1);
-                int gl = g;
-                if constexpr (COUNT) asm volatile("" : "+v"(gl));  // cold path: nothing of it may be hoisted out of the tile loop
-                const int w = (wave * MT2 + m) * 4 + gl;
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[dy][dx][n] = cin2[n];
+                v4i bq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bq[t] = *(const v4i *)(src + t * P1P * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int ky = t - dy;
+                        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n)
+                                acc[dy][dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2[n][ky][dx], bq[t], acc[dy][dx][n], 0, 0, 0);
+                    }
+                float y[2][4], yc[2][4];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = max(max(acc[0][0][n][r], acc[0][1][n][r]), max(acc[1][0][n][r], acc[1][1][n][r]));
+                        y[n][r] = rq_round<FOLD>(m, bf2[n][r], f2);
+                        yc[n][r] = __builtin_amdgcn_fmed3f(y[n][r], QLO, QHI);
+                    }
                 if constexpr (!COUNT) {
-                    satx += (unsigned int)(q0 ^ qq0) + (unsigned int)(q1 ^ qq1);
-                    *(unsigned short *)(stg + w * 32 + 2 * li) = (unsigned short)((q0 & 0xff) | ((q1 & 0xff) << 8));
+                    uint2 word;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[n][r]) ^ __float_as_uint(yc[n][r]);
+                    word.x = pack4(yc[0][0], yc[0][1], yc[0][2], yc[0][3]);
+                    word.y = pack4(yc[1][0], yc[1][1], yc[1][2], yc[1][3]);
+                    *(uint2 *)(stg + wraw * 32 + 8 * g_) = word;
                 } else {
-                    const bool own = w < NWIN && TOY * ty + w / TOX < Ho && TOX * tx + w % TOX < Wo;
-                    satx += (own && q0 != qq0 ? 1u : 0u) + (own && q1 != qq1 ? 1u : 0u);
+                    const bool own = wraw < NW2 && TOY * ty + wy < Ho && TOX * tx + wx < Wo;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) satx += (own && y[n][r] != yc[n][r]) ? 1u : 0u;
                 }
-                wx += 4;
-                const bool wrap = wx >= TOX;
-                wx -= wrap ? TOX : 0;
-                ab += wrap ? (8 + 2 * P1P - 2 * TOX) * 16 : 8 * 16;
             }
             return satx;
         };
@@ -417,9 +461,9 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                     *(v4i *)(outb + oofs[k]) = *(const v4i *)(stg + (tid + 256 * k) * 16);
             }
         }
-        if (!more) break;
-        tile = ntile;
-        b = b2; ty = ty2; tx = tx2;
+        if (tile + G_ >= total_tiles) break;
+        // the next tile's Q phase writes `patch` (last read before B2) and its C1 writes `p1` (last read before B3):
+        // both are behind a barrier every wave has passed; `stg` is rewritten only after B2 of the next tile
     }
     if (nsat_in) atomicAdd(&p.ctr[0].in_sat, (unsigned long long)nsat_in);
     if (nsat1) atomicAdd(&p.ctr[0].sat, (unsigned long long)nsat1);
@@ -427,14 +471,58 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
 }
 
 void y355_front_tiles(int H, int W, int *tx, int *ty) {
-    *tx = (W / 4 + 12) / 13;
-    *ty = (H / 4 + 12) / 13;
+    *tx = (W / 4 + TOX - 1) / TOX;
+    *ty = (H / 4 + TOY - 1) / TOY;
+}
+
+// Weight fragments of the fused front end (16 KiB): MFMA A operands, lane (i = l & 15: accumulator row, g = l >> 4), 16 bytes.
+//   conv1, variant v = 2 dy + dx (offset of the conv output inside the pooling window), at v * 1024:
+//     row i = output channel i; g = neighbourhood row; byte 4 nc + c = w[i][c][g - dy][nc - dx] (zero outside the 3x3 filter)
+//   conv2, fragment ((n * 3 + ky) * 2 + dx) at 4096 + ... * 1024:
+//     row i = output channel 8 (i >> 2) + 4 n + (i & 3); g = neighbourhood column; byte ci = w[ch][ci][ky][g - dx]
+void y355_pack_front(const int8_t *q_w1 /*[16][3][3][3]*/, const int8_t *q_w2 /*[32][16][3][3]*/, int8_t *dst /*16384*/) {
+    memset(dst, 0, 16384);
+    if (q_w1) {
+        for (int v = 0; v < 4; ++v)
+            for (int l = 0; l < 64; ++l) {
+                const int i = l & 15, g = l >> 4, ky = g - (v >> 1);
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int kx = (kk >> 2) - (v & 1), c = kk & 3;
+                    if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3 && c < 3)
+                        dst[v * 1024 + l * 16 + kk] = q_w1[((i * 3 + c) * 3 + ky) * 3 + kx];
+                }
+            }
+    }
+    if (q_w2) {
+        for (int n = 0; n < 2; ++n)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int dx = 0; dx < 2; ++dx)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = l & 15, g = l >> 4, kx = g - dx;
+                        const int ch = 8 * (i >> 2) + 4 * n + (i & 3);
+                        if (kx < 0 || kx > 2) continue;
+                        for (int ci = 0; ci < 16; ++ci)
+                            dst[4096 + ((n * 3 + ky) * 2 + dx) * 1024 + l * 16 + ci] = q_w2[((ch * 16 + ci) * 3 + ky) * 3 + kx];
+                    }
+    }
+}
+
+// true when the fused launch covers these two layers: 32-bit epilogues whose t stays below 2^24 (exact in fp32)
+bool y355_front_eligible(const Requant &rq1, const Requant &rq2) {
+    return !rq1.wide && !rq2.wide && rq1.tmax_log2 <= 24 && rq2.tmax_log2 <= 24;
 }
 
 void y355_launch_front(const FrontParams &p, hipStream_t s) {
     const int total = p.tiles_x * p.tiles_y * p.B;
     int grid = 256 * FRONT_OCC;
     if (grid > total) grid = total;
-    if (p.x) hipLaunchKernelGGL((front_kernel<13, 13, false>), dim3(grid), dim3(256), 0, s, p, total);
-    else hipLaunchKernelGGL((front_kernel<13, 13, true>), dim3(grid), dim3(256), 0, s, p, total);
+    auto foldable = [](const Requant &rq) { return rq.shl == 0 && rq.tmax_log2 <= 22 && rq.sh <= 22 && rq.sh - rq.lk >= -8; };
+    const bool fold = foldable(p.rq1) && foldable(p.rq2);
+    if (p.x) {
+        if (fold) hipLaunchKernelGGL((front_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, total);
+        else hipLaunchKernelGGL((front_kernel<false, false>), dim3(grid), dim3(256), 0, s, p, total);
+    } else {
+        if (fold) hipLaunchKernelGGL((front_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, total);
+        else hipLaunchKernelGGL((front_kernel<true, false>), dim3(grid), dim3(256), 0, s, p, total);
+    }
 }

@@ -28,6 +28,8 @@ struct Requant {
     // 1: the general slope fits 32 bits (host-checked: |t| * max(2^max(0, lk - sh), neg_mul * 2^max(0, -sh)) < 2^31):
     //   q = t >= 0 ? rne(t * 2^(lk - sh)) : rne(t * neg_mul * 2^-sh)          (y355_requant_gen32; first layer of y355_net)
     int gen32;
+    // |t| = |(acc << shl) + bias_t| < 2^tmax_log2 for worst-case operands (<= 24: t is exact in fp32, front.hip's epilogue)
+    int tmax_log2;
 };
 
 __device__ __forceinline__ int y355_rne_shift32(int x, int s) {            // s wave-uniform
@@ -104,8 +106,7 @@ struct FrontParams {
     const uint8_t *x_u8;  // or (x == nullptr) uint8 HWC BGR frames [B][H][W][3]
     float nmean[3], nstd[3];
     int8_t *out;          // conv2's pooled output: int8 NHWC32 with halo [B][H/4+2][W/4+2][32]
-    const int8_t *w1;     // conv1 fragment (y355_pack_conv1)
-    const int8_t *w2;     // conv2 fragments (y355_pack_weights of Y355_K_CONV2: 3 k-steps x 2 n-tiles x 1 KiB)
+    const int8_t *wf;     // 16 KiB of weight fragments (y355_pack_front)
     const int *bias1;     // [16]
     const int *bias2;     // [32]
     Counters *ctr;        // [0] conv1, [1] conv2
@@ -116,6 +117,8 @@ struct FrontParams {
     unsigned long long *stamps;   // diagnostic builds only (-DFRONT_DIAG=1)
 };
 void y355_front_tiles(int H, int W, int *tx, int *ty);
+void y355_pack_front(const int8_t *q_w1, const int8_t *q_w2, int8_t *dst /*16384; a null tensor leaves its part zero*/);
+bool y355_front_eligible(const Requant &rq1, const Requant &rq2);
 void y355_launch_front(const FrontParams &p, hipStream_t s);
 
 template <typename T>

@@ -61,6 +61,7 @@ _SIGS = {
     "y355_create": (C.c_int, [P(Config), P(C.c_void_p)]),
     "y355_destroy": (None, [C.c_void_p]),
     "y355_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "y355_pack_front_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "y355_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y355_load_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "y355_set_act_exponents": (C.c_int, [C.c_void_p, P(C.c_int32)]),

@@ -5,7 +5,8 @@ Images are independent once the activation exponents are frozen (models/slim_yol
 shard_range(global_batch, world, r) through its own engine.  The only exchange is ONE all-gather per batch
 (RCCL over xGMI on GPUs; gloo in the CPU tests) of the padded detections packed into one buffer of
 fixed-size records (include/yolo355.h, "multi-GPU exchange"):
-    record = i32 count (-1: padding record of a ragged shard), i32 pad[3], f32 boxes[max_det][4],
+    record = i32 count (-1: padding record of a ragged shard), i32 total (detections the image had: > count when the
+             record was cut at max_det; -1 in a padding record), i32 pad[2], f32 boxes[max_det][4],
              f32 scores[max_det], i32 cls[max_det], rounded up to 16 bytes
 Every rank sends ceil(global_batch / world) records; result order = global image index.  Calibration happens
 once (rank 0) and the 11 exponents (44 bytes) are broadcast -- never per rank on different data.
@@ -56,8 +57,10 @@ def pack_detections(boxes, scores, cls, count, records=None, out=None):
     rec.zero_()
     r32 = rec.view(torch.int32)                                   # [records, rb / 4]
     r32[:, 0] = -1
+    r32[:, 1] = -1
     if n:
         cnt = count[:n].to(torch.int32).clamp(0, md)
+        r32[:n, 1] = count[:n].to(torch.int32).clamp(min=0)
         keep = torch.arange(md, device=scores.device)[None, :] < cnt[:, None]          # [n, md]
         r32[:n, 0] = cnt
         r32[:n, 4:4 + 4 * md] = (boxes[:n].contiguous().view(torch.int32).reshape(n, md, 4) * keep[:, :, None]).reshape(n, 4 * md)
@@ -94,6 +97,12 @@ def unpack_records(rec, max_det, global_batch=None):
     scores = r32[:, 4 + 4 * md:4 + 5 * md].contiguous().view(torch.float32)
     cls = r32[:, 4 + 5 * md:4 + 6 * md].contiguous()
     return boxes, scores, cls, r32[:, 0].contiguous()
+
+
+def truncated_images(rec):
+    """number of image records of a gathered buffer that were cut at the record's cap (header word 1 > word 0)."""
+    r32 = rec.view(torch.int32)
+    return int(((r32[:, 0] >= 0) & (r32[:, 1] > r32[:, 0])).sum().item())
 
 
 def allgather_detections(boxes, scores, cls, count, global_batch=None, async_op=False, send=None, recv=None):

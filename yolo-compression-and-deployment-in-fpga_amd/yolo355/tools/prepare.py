@@ -37,13 +37,22 @@ def fold_model(fp32_model, corrected=False):
     return out
 
 
+def calib_batches(n_images, calib_batch, calib_images=1000):
+    """Number of batches the reference's calibration loop runs over a set of n_images (retune_bias_quantize.py:324,365-367:
+    `for iter_i, ... : forward; if batch_size * iter_i > 1000: break`, iter_i 0-based, checked after the batch)."""
+    total = -(-n_images // calib_batch)
+    first_break = calib_images // calib_batch + 1          # smallest iter_i with calib_batch * iter_i > calib_images
+    return min(total, first_break + 1)
+
+
 def prepare(state_dict, num_classes, anchor_size, input_size, calib, device="cuda:0", corrected_fold=False,
             conf_thresh=0.01, nms_thresh=0.5, calib_batch=0, calib_images=1000):
     """Returns (q_model, package dict, report list).  calib: fp32 NCHW tensor/array (already normalised) or
     uint8 [B,H,W,3] BGR frames (normalised like BaseTransform).  calib_batch = 0: its FIRST image calibrates the
     trackers (first-call rule of an eval-mode model, models/slim_yolo_v2.py:25-27).  calib_batch = N > 0: the reference's
     calibration loop (retune_bias_quantize.py:357-369): batches of N images, first batch sets every scale, every
-    further batch moves it by the EMA of :30-31, stop once more than `calib_images` images were seen (:365-367)."""
+    further batch moves it by the EMA of :30-31, stop after the batch in front of which more than `calib_images` images
+    had been seen (:365-367; `calib_batches`)."""
     fp = SlimYOLOv2(device, input_size=input_size, num_classes=num_classes, anchor_size=anchor_size)
     fp.load_state_dict(state_dict, strict=False)
     fp.eval()
@@ -64,12 +73,12 @@ def prepare(state_dict, num_classes, anchor_size, input_size, calib, device="cud
     if x.dtype == np.uint8:
         x = synth.normalize_frames(x)
     if calib_batch > 0:
-        seen = 0
-        for i0 in range(0, x.shape[0], calib_batch):
+        for iter_i, i0 in enumerate(range(0, x.shape[0], calib_batch)):
             xb = torch.from_numpy(np.ascontiguousarray(x[i0:i0 + calib_batch], dtype=np.float32))
             qm.calibrate(xb, freeze=False)
-            seen += xb.shape[0]
-            if seen > calib_images:                         # retune_bias_quantize.py:365-367
+            # retune_bias_quantize.py:324,365-367: `if args.batch_size * iter_i > 1000: break` AFTER the batch, iter_i 0-based:
+            # the images seen BEFORE this batch are compared (batch 32 -> 33 batches = 1056 images), see calib_batches()
+            if calib_batch * iter_i > calib_images:
                 break
     else:
         x = torch.from_numpy(np.ascontiguousarray(x[:1], dtype=np.float32))
