@@ -41,7 +41,8 @@ LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "co
 DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, false, false>"
 
 
-TRAFFIC_FILES = ["r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
+TRAFFIC_FILES = ["r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
+N_INPUTS = 4          # distinct input batches rotated through the timed loop: 4 x 133 MB > the 256 MB Infinity Cache
 
 
 def pmc_traffic(kernel):
@@ -95,7 +96,7 @@ def sparse_fixture(args, dev, streams, x):
     for i in range(args.warmup):
         out = run(i)
     times = []
-    for _ in range(max(1, min(args.repeats, 5))):       # median of a few regions of exactly `steps` steps, like `value`
+    for _ in range(5 if args.repeats <= 0 else min(args.repeats, 5)):       # median of a few regions of exactly `steps` steps, like `value`
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -151,7 +152,6 @@ def cpu_baseline(n_images=128):
 TINY_MMAC = [74.760192, 199.360512, 199.360512, 199.360512, 199.360512, 199.360512, 797.442048, 398.721024,
              5.537792, 598.081536, 199.360512, 6.4896, 12.9792]
 PEAK_BF16_DENSE = 2.5e15
-PEAK_I8_MEASURED = 4.588e15      # scratch/ubench/mfma_peak.hip on an MI355X, 2 waves per SIMD (nominal 5.0e15 = PEAK_I8_DENSE)
 # myYOLOv2 on DarkNet-19 (models/yolo_v2.py, backbone/darknet.py:40-110), weight slots of csrc/net.hip kV2Ops:
 # (cin, cout, ksize, map side at 416x416 the convolution runs on); cout 0 = A * (5 + C)
 V2_LAYERS = [(3, 32, 3, 416), (32, 64, 3, 208), (64, 128, 3, 104), (128, 64, 1, 104), (64, 128, 3, 104),
@@ -435,8 +435,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--repeats", type=int, default=15,
-                    help="the timed region of EXACTLY --steps steps is run this many times; value = median (min / max reported)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="the timed region of EXACTLY --steps steps is run this many times; value = median (min / max reported). "
+                         "0 (default) = as many as it takes to time at least 2 s of GPU work, and at least 15")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the extra 'sparse fixture' measurement (SURVEY.md 8d)")
@@ -465,9 +466,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if torch.cuda.device_count() < args.gpus:           # device_count() does not initialise the GPU on this image
-            sys.exit("bench.py: --gpus %d but %d GPU(s) are visible" % (args.gpus, torch.cuda.device_count()))
-        sys.exit(_spawn_torchrun(args))
+        sys.exit(_spawn_torchrun(args))                     # the children fail loudly if a GPU is missing
     if args.gpus != world:
         sys.exit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
@@ -512,9 +511,23 @@ def main():
     for e in engines:
         e.set_act_exponents(sa)
 
-    # rank r owns global images [r*B, (r+1)*B)
-    x = torch.from_numpy(synth.make_images(1000 + rank, B, H, W)).to(dev)
-    frames = torch.from_numpy(synth.make_frames_u8(1000 + rank, B, H, W)).to(dev) if args.input == "u8" else None
+    # rank r owns global images [r*B, (r+1)*B): the seed-1000 batch rolled r pixels along W (every rank can rebuild any
+    # other rank's shard on its own GPU: the verification below).  The timed loop rotates N_INPUTS distinct batches (the shard
+    # and its three flips, 4 x 133 MB: more than the Infinity Cache holds), so no step finds its input on chip.
+    base_x = torch.from_numpy(synth.make_images(1000, B, H, W)).to(dev)
+    base_f = torch.from_numpy(synth.make_frames_u8(1000, B, H, W)).to(dev) if args.input == "u8" else None
+
+    def shard_inputs(r):
+        """(fp32 NCHW batches, uint8 NHWC batches or None) of rank r"""
+        x0 = torch.roll(base_x, r, 3)
+        xs = [x0, torch.flip(x0, (3,)), torch.flip(x0, (2,)), torch.flip(x0, (2, 3))][:N_INPUTS]
+        fs = None
+        if base_f is not None:
+            f0 = torch.roll(base_f, r, 2)
+            fs = [f0, torch.flip(f0, (2,)), torch.flip(f0, (1,)), torch.flip(f0, (1, 2))][:N_INPUTS]
+        return [t.contiguous() for t in xs], ([t.contiguous() for t in fs] if fs is not None else None)
+    xs, fs = shard_inputs(rank)
+    x, frames = xs[0], (fs[0] if fs is not None else None)
     nbuf = 2 * nstreams
     bufs = [tuple(torch.empty_like(t) for t in eng._buffers(B)) for _ in range(nbuf)]
     gsend = grecv = None
@@ -525,16 +538,17 @@ def main():
         grecv = [torch.empty((world * B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     torch.cuda.synchronize()
 
-    def step(i, pending, ns):
+    def step(i, pending, ns, rotate=True):
         k = i % nbuf
+        j = i % N_INPUTS if rotate else 0
         with torch.cuda.stream(streams[i % ns]):      # the engine's own stream: no cross-stream waits are inserted
             if dist_on and pending[k] is not None:    # buffer reuse: its gather (2 x streams steps ago) must be done
                 for w in pending[k]:
                     w.wait()
-            if frames is not None:
-                out = engines[i % ns].forward_frames_device(frames, 0, bufs[k])
+            if fs is not None:
+                out = engines[i % ns].forward_frames_device(fs[j], 0, bufs[k])
             else:
-                out = engines[i % ns].forward_device(x, 0, bufs[k])
+                out = engines[i % ns].forward_device(xs[j], 0, bufs[k])
             if dist_on:
                 # ONE packed all-gather per batch: one pack launch on the engine's stream, then the collective,
                 # which orders itself after that stream and runs on RCCL's own -- asynchronous, no other stream involved
@@ -543,22 +557,23 @@ def main():
                 pending[k] = [dist.all_gather_into_tensor(grecv[k], gsend[k], async_op=True)]
         return out
 
-    def timed(ns, steps, warmup, repeats):
-        """`repeats` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both
-        sides; per region the MAX over ranks.  Returns (list of seconds, last outputs)."""
+    def timed(ns, steps, warmup, repeats, rotate=True, min_seconds=0.0):
+        """`repeats` timed regions of EXACTLY `steps` steps each (repeats = 0: until `min_seconds` of timed work and 15 regions),
+        every one bracketed by barrier + synchronize on both sides; per region the MAX over ranks.
+        Returns (list of seconds, last outputs)."""
         pending = [None] * nbuf
         out = None
         for i in range(warmup):
-            out = step(i, pending, ns)
+            out = step(i, pending, ns, rotate)
         times = []
-        for _ in range(repeats):
+        while len(times) < (repeats if repeats > 0 else 15) or (repeats <= 0 and sum(times) < min_seconds and len(times) < 2000):
             torch.cuda.synchronize()
             if dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(steps):
-                out = step(i, pending, ns)
+                out = step(i, pending, ns, rotate)
             for p in pending:
                 if p is not None:
                     for w in p:
@@ -575,20 +590,59 @@ def main():
             times.append(dt)
         return times, out
 
-    reps = max(1, args.repeats)
     # throughput mode: handles that share the GPU run their deep convolutions on fewer persistent workgroups, each walking
     # more tiles (include/yolo355.h, Y355_OPT_RING_WORKGROUPS); the one-stream and the profiling passes below use all CUs
     ring_wgs = args.ring_workgroups if nstreams > 1 else 0
     for e in engines:
         e.set_option(2, ring_wgs)                        # Y355_OPT_RING_WORKGROUPS
-    times, out = timed(nstreams, args.steps, args.warmup, reps)
+    times, out = timed(nstreams, args.steps, args.warmup, args.repeats, True, 2.0)
+    reps = len(times)
     dt = float(np.median(times))
+    # the same with ONE input batch fed to every step (what rounds 1 and 2 reported: part of it stays in the Infinity Cache)
+    t_same, _ = timed(nstreams, args.steps, min(args.warmup, 5), 5, False)
+    dt_same = float(np.median(t_same))
     for e in engines:
         e.set_option(2, 0)
     one = None
     if nstreams > 1:
-        t1, _ = timed(1, args.steps, min(args.warmup, 5), max(3, reps // 3))
+        t1, _ = timed(1, args.steps, min(args.warmup, 5), 5)
         one = float(np.median(t1))
+
+    # ---- multi-GPU: verify what the gather delivers ("gathered detections equal the single-GPU run bit for
+    # bit").  Every rank runs one more step on its shard's first batch and gathers (torch.distributed, blocking, the timed
+    # path's records; then the C ABI route y355_pack_dets / y355_allgather_dets / y355_unpack_dets with full records);
+    # rank 0 rebuilds every rank's shard on its own GPU, runs it through its own engine and compares every byte.
+    gather_info = None
+    if dist_on:
+        with torch.cuda.stream(streams[0]):
+            inp0 = fs[0] if fs is not None else xs[0]
+            fwd = (lambda e, t, bf: e.forward_frames_device(t, 0, bf)) if fs is not None else (lambda e, t, bf: e.forward_device(t, 0, bf))
+            o_mine = fwd(eng, inp0, bufs[0])
+            shard.pack_detections_kernel(*[t[:B] for t in o_mine], B, gsend[0], gather_md)
+            dist.all_gather_into_tensor(grecv[0], gsend[0])
+            rg = shard.RcclGather(world, rank, dev)
+            comm_world = int(rg._lib.y355_comm_world(rg._h))
+            g_full = rg.allgather(*[t[:B] for t in o_mine])
+            torch.cuda.synchronize()
+            bad_records, bad_full = 0, 0
+            if rank == 0:
+                ref = torch.empty_like(gsend[0])
+                for r in range(world):
+                    xr, fr = shard_inputs(r)
+                    o_r = fwd(eng, (fr[0] if fr is not None else xr[0]), bufs[1])
+                    shard.pack_detections_kernel(*[t[:B] for t in o_r], B, ref, gather_md)
+                    torch.cuda.synchronize()
+                    bad_records += int((ref != grecv[0][r * B:(r + 1) * B]).any(dim=1).sum().item())
+                    for a, b_ in zip(o_r, g_full):
+                        bad_full += int((a[:B] != b_[r * B:(r + 1) * B]).sum().item())
+            rg.close()
+        gather_info = {"gather_verified": bad_records == 0 and bad_full == 0, "dist_world_size": dist.get_world_size(),
+                       "y355_comm_world": comm_world, "records_compared": world * B, "mismatching_records": bad_records,
+                       "mismatching_values_c_abi_route": bad_full,
+                       "truncated_images": shard.truncated_images(grecv[0]),
+                       "how": "rank 0 re-ran every rank's shard on its own GPU and compared the gathered bytes (torch.distributed "
+                              "records of the timed path, and full records through y355_pack_dets / y355_allgather_dets / y355_unpack_dets)"}
+        dist.barrier()
 
     # per-kernel device time with HIP events on the engine's stream (separate profiled steps)
     eng.profile(True)
@@ -607,10 +661,12 @@ def main():
                 eng.forward_frames_device(frames, 0, bufs[0])
             else:
                 eng.forward_device(x, 0, bufs[0])
-            kacc.append(eng.profile_kernel_ms())
+            kacc.append(eng.profile_kernels_ms())
     eng.profile(False)
     layer_ms = np.median(np.array(acc), axis=0)
-    kernel_ms = np.median(np.array(kacc), axis=0)    # the launches' own start / end timestamps (0 where a layer's launcher records none)
+    kernel_ms = np.median(np.array(kacc), axis=0)    # the launches' own start / end timestamps: 10 layers + the 4 head / NMS launches
+    from yolo355.engine import mfma_peak_i8
+    peak_tops, peak_clock = mfma_peak_i8(local_rank, 50.0) if rank == 0 else (0.0, 0.0)
     ndet = int(out[3][:B].sum().item())
 
     if rank == 0:
@@ -646,15 +702,18 @@ def main():
                        "streams_per_gpu": nstreams, "ring_workgroups_per_launch": ring_wgs if ring_wgs else "one per CU",
                        **({"gather": "one all_gather_into_tensor per batch, %d detections per image (%d bytes per record)"
                                      % (gather_md, shard.record_bytes(gather_md))} if dist_on else {}),
-                       "input": args.input,
+                       "input": args.input, "input_batches_rotated": N_INPUTS,
                        "detections_per_step_rank0": ndet},
             # the timed region (exactly `steps` steps between barrier + synchronize) was run `repeats` times: value and
             # ms_per_step are the MEDIAN region; with 3 engine handles ms_per_step is a throughput period, not a latency
-            "timing": {"repeats": reps, "ms_per_step_min": round(min(times) / args.steps * 1e3, 4),
+            "timing": {"repeats": reps, "timed_seconds": round(float(sum(times)), 3), "ms_per_step_min": round(min(times) / args.steps * 1e3, 4),
                        "ms_per_step_max": round(max(times) / args.steps * 1e3, 4),
                        "value_min": round(world * B * args.steps / max(times), 1),
                        "value_max": round(world * B * args.steps / min(times), 1)},
-            "roofline": {"bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
+            # whole_path_frac = the headline as a fraction of the int8-MFMA roofline (value x 5.0432 G int8-op / peak): the
+            # figure BASELINE.json's >= 50 % target is about; `frac` = the same for the dominant kernel alone (named below)
+            "roofline": {"whole_path_frac": round(value / world * OPS_PER_IMAGE / PEAK_I8_DENSE, 4),
+                         "bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": round(dom_tops * 1e12 / PEAK_I8_DENSE, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": DOMINANT_KERNEL + " (conv6 and conv7: 2 launches/step, the largest share of "
@@ -665,17 +724,27 @@ def main():
                          else "interval between hipEventRecord before / after the launch",
                          "launch_ms_between_events": round(dom_between, 4),
                          "frac_between_events": round(B * 2e6 * LAYER_MMAC[7] / (dom_between * 1e-3) / PEAK_I8_DENSE, 4),
-                         "kernel_ms": {n: round(float(kernel_ms[i]), 4) for i, n in enumerate(LAYER_NAMES) if kernel_ms[i] > 0},
-                         # MFMA-only microbenchmark on this part (scratch/ubench/mfma_peak.hip, profiles/r01_g_ablation.txt):
-                         # v_mfma_i32_16x16x64_i8 at two waves per SIMD sustains 4588 Tops/s (the clock drops to ~2.2 GHz)
-                         "peak_measured": PEAK_I8_MEASURED / 1e12,
-                         "frac_of_measured_peak": round(dom_tops * 1e12 / PEAK_I8_MEASURED, 4),
+                         # every launch's own duration (ms): layers (the fused front end under "conv1"), then the head / NMS kernels
+                         "kernel_ms": {n: round(float(kernel_ms[i]), 4) for i, n in
+                                       enumerate((["conv1+conv2 (fused front end)"] if fused else ["conv1"]) + LAYER_NAMES[1:] +
+                                                 ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
+                                       if kernel_ms[i] > 0},
+                         "kernel_ms_sum": round(float(kernel_ms.sum()), 4),
+                         # MFMA-only loop MEASURED IN THIS RUN (y355_mfma_peak_i8: v_mfma_i32_16x16x64_i8 back to back on register
+                         # operands, two waves per SIMD on every CU, ~50 ms) and the in-kernel clock it held
+                         "peak_measured": round(peak_tops, 1), "peak_measured_clock_ghz": round(peak_clock, 3),
+                         "frac_of_measured_peak": round(dom_tops / peak_tops, 4) if peak_tops else None,
                          "all_conv_achieved": round(achieved, 2),
                          "all_conv_frac": round(achieved * 1e12 / PEAK_I8_DENSE, 4),
-                         "whole_path_frac": round(value / world * OPS_PER_IMAGE / PEAK_I8_DENSE, 4),
                          "layers": layers,
                          "head_ms": round(float(layer_ms[10]), 4), "nms_ms": round(float(layer_ms[11]), 4)},
         }
+        res["same_input_every_step"] = {
+            "value": round(world * B * args.steps / dt_same, 1), "unit": "images/sec", "ms_per_step": round(dt_same / args.steps * 1e3, 4),
+            "note": "ONE input batch fed to every step (rounds 1 / 2): part of its 133 MB stays in the 256 MB Infinity Cache; "
+                    "`value` rotates %d distinct batches" % N_INPUTS}
+        if gather_info is not None:
+            res.update(gather_info)
         if one is not None:
             v1 = world * B * args.steps / one
             res["one_stream"] = {"value": round(v1, 1), "unit": "images/sec", "ms_per_step": round(one / args.steps * 1e3, 4),
@@ -708,8 +777,15 @@ def main():
         except OSError:
             pass
         print(json.dumps(res), flush=True)
+    failed = gather_info is not None and not gather_info["gather_verified"]
     if dist_on:
+        if world > 1:
+            flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+            dist.broadcast(flag, 0)
+            failed = bool(flag.item())
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: the gathered detections differ from the single-GPU run")
 
 
 if __name__ == "__main__":

@@ -261,6 +261,13 @@ int y355_profile_get(y355_engine *h, float *ms /*[Y355_NUM_TIMERS]*/);
  * the slots above from a run with y355_profile(h, 1).  0 for layers whose launch does not record them (today: recorded by
  * the six ring-kernel layers conv3_2 .. pred) */
 int y355_profile_kernel_get(y355_engine *h, float *ms /*[10]*/);
+/* the same for every launch of a forward: slots 0..9 = layers (the fused front end = slot 0, slot 1 then 0), 10 = head decode,
+ * 11 = candidate sort, 12 = NMS pair walk, 13 = NMS rounds + output */
+#define Y355_NUM_KERNEL_TIMERS 14
+int y355_profile_kernels_get(y355_engine *h, float *ms /*[Y355_NUM_KERNEL_TIMERS]*/);
+/* host utility: the int8 MFMA rate this GPU sustains (v_mfma_i32_16x16x64_i8 back to back on register operands, two waves per
+ * SIMD on every CU, about `ms_target` milliseconds): the measured counterpart of the nominal 5.0 Pop/s bench.py divides by */
+int y355_mfma_peak_i8(int device_id, float ms_target, float *tops_out, float *clock_ghz_out);
 /* host-only: the 16 KiB of MFMA weight fragments the fused front end (csrc/front.hip: conv1 + pool1 + conv2 + pool2,
  * models/slim_yolo_v2.py:218-244) streams; q_w1 int8 [16][3][3][3], q_w2 int8 [32][16][3][3] (either may be null: its part
  * stays zero).  y355_load_layer does this itself; exported so that the layout can be checked without a GPU. */

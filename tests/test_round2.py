@@ -612,6 +612,7 @@ def test_capped_pack_kernel_equals_the_torch_packing():
         got = torch.full((records, shard.record_bytes(cap)), 0xAB, dtype=torch.uint8, device=dev)
         shard.pack_detections_kernel(boxes, scores, cls, count, records, got, cap)
         want = shard.pack_detections(boxes[:, :cap].contiguous(), scores[:, :cap].contiguous(), cls[:, :cap].contiguous(),
-                                     count.clamp(max=cap), records)
+                                     count, records)              # header word 1 keeps the image's own count
         torch.cuda.synchronize()
         assert torch.equal(got, want), (cap, records)
+        assert shard.truncated_images(got) == int((count > cap).sum().item())

@@ -517,8 +517,10 @@ struct ConvInst2 {
         return (int)hipFuncSetAttribute((const void *)conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES, MINB>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch());
     }
-    static bool launch(const ConvParams &p, hipStream_t s) {
-        if (WRES && p.nblk != 1) return false;     // resident weights = one n-block
+    static bool launch(const ConvParams &p_in, hipStream_t s) {
+        if (WRES && p_in.nblk != 1) return false;  // resident weights = one n-block
+        ConvParams p = p_in;
+        p.ev_start = p.ev_stop = nullptr;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
         // persistent grid = what is actually co-resident: 8-wave workgroups take > 128 VGPRs per wave, so
         // only one fits a CU whatever its LDS (a 512-workgroup grid would run as two sequential rounds)
@@ -527,7 +529,8 @@ struct ConvInst2 {
         if (WM * WN == 8 && MINB < 4) per_cu = 1;          // (MINB = waves per SIMD the kernel was compiled for: 4 = two 8-wave workgroups per CU)
         int grid = 256 * per_cu;
         if (grid > total) grid = total;
-        hipLaunchKernelGGL((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES, MINB>), dim3(grid), dim3(WM * WN * 64), lds_launch(), s, p, total);
+        Y355_LAUNCH((conv3x3_i8_v2_kernel<CIN, BN, TH, TW, POOL, WM, WN, WRES, MINB>), dim3(grid), dim3(WM * WN * 64), lds_launch(), s,
+                    p_in.ev_start, p_in.ev_stop, p, total);
         return true;
     }
 };

@@ -185,8 +185,10 @@ struct y355_engine {
                                     // front end keeps that map on chip: 0 after a fused forward)
     int ring_wgs = 0;               // persistent workgroups per ring launch (0 = one per CU)
     hipEvent_t ev[Y355_NUM_TIMERS + 1];
-    hipEvent_t kev[10][2];      // per-layer kernel start / stop timestamps (ring kernels, profile mode)
-    bool kev_set[10] = {};
+    // kernel start / stop timestamps of the launches themselves (profile mode 2): 0..9 layers (the fused front end in slot 0),
+    // 10 decode, 11 candidate sort, 12 pair walk, 13 rounds + output
+    hipEvent_t kev[Y355_NUM_KERNEL_TIMERS][2];
+    bool kev_set[Y355_NUM_KERNEL_TIMERS] = {};
     bool ev_ok = false;
     std::vector<void *> allocs;
 };
@@ -495,6 +497,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         // layers whose whole weight tensor stays resident in LDS run conv3x3_v2.hip (no per-k-step barrier); the others the ring
         if (!no_v2 && y355_conv_v2_preferred(L.kid) && y355_launch_conv_v2(L.kid, p, h->stream)) {
             HIPCHK(hipGetLastError());
+            h->kev_set[k] = p.ev_start != nullptr;
             return 0;
         }
         if (!no_v2 && !((no_ring_mask >> k) & 1) && y355_launch_conv_ring(L.kid, p, h->stream)) {
@@ -625,6 +628,8 @@ static int launch_front(y355_engine *h, int B, const float *x_dev) {
     p.rq1 = L0.rq;
     p.rq2 = L1.rq;
     p.stamps = (h->stamp_layer == 0) ? h->stamps_dev : nullptr;
+    h->kev_set[0] = h->kev_set[1] = false;
+    if (h->profile == 2) { p.ev_start = h->kev[0][0]; p.ev_stop = h->kev[0][1]; h->kev_set[0] = true; }
     y355_launch_front(p, h->stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -651,7 +656,9 @@ static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int fl
     if (prof) HIPCHK(hipEventRecord(h->ev[10], h->stream));
     HeadParams hp = head_params(h, h->sa[10], boxes_dev, scores_dev, cls_dev, count_dev);
     if (!(flags & Y355_F_TAP)) { hp.cand_box = nullptr; hp.cand_score = nullptr; hp.cand_cls = nullptr; }
-    y355_launch_head_nms(hp, batch, h->ws, h->stream, prof ? h->ev[11] : nullptr);
+    const bool kprof = prof && h->profile == 2;
+    for (int i = 10; i < Y355_NUM_KERNEL_TIMERS; ++i) h->kev_set[i] = kprof;
+    y355_launch_head_nms(hp, batch, h->ws, h->stream, prof ? h->ev[11] : nullptr, kprof ? &h->kev[10] : nullptr);
     HIPCHK(hipGetLastError());
     if (prof) HIPCHK(hipEventRecord(h->ev[12], h->stream));
     return 0;
@@ -985,6 +992,17 @@ extern "C" int y355_profile_kernel_get(y355_engine *h, float *ms) {
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipEventSynchronize(h->ev[12]));
     for (int k = 0; k < 10; ++k) {
+        ms[k] = 0.f;
+        if (h->kev_set[k]) HIPCHK(hipEventElapsedTime(&ms[k], h->kev[k][0], h->kev[k][1]));
+    }
+    return 0;
+}
+
+extern "C" int y355_profile_kernels_get(y355_engine *h, float *ms) {
+    if (!h || !ms) return fail(Y355_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipEventSynchronize(h->ev[12]));
+    for (int k = 0; k < Y355_NUM_KERNEL_TIMERS; ++k) {
         ms[k] = 0.f;
         if (h->kev_set[k]) HIPCHK(hipEventElapsedTime(&ms[k], h->kev[k][0], h->kev[k][1]));
     }

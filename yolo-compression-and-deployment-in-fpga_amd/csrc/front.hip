@@ -28,11 +28,14 @@
 #include <type_traits>
 #include <cstring>
 #ifndef FRONT_OCC
-#define FRONT_OCC 3
+#define FRONT_OCC 4
 #endif
 #ifndef FRONT_P0
 #define FRONT_P0 64              // patch pitch in pixels (dwords): 32 mod 64 keeps the two filter rows of a half-wave's
 #endif                           // ds_read_b64 on disjoint banks
+#ifndef FRONT_HOTCOLD
+#define FRONT_HOTCOLD 1          // 1: the hot pass does not clamp (running max / min of the rounded values detect a clamp; a cold pass
+#endif                           //    then rewrites the wave's outputs clamped and counts); 0: clamp + detect per output in the hot pass
 #ifndef FRONT_DIAG
 #define FRONT_DIAG 0             // 1: s_memtime stamps at the phase boundaries of each workgroup's first tiles (y355_debug_stamps)
 #endif
@@ -74,6 +77,16 @@ __device__ __forceinline__ float vmaxabs(float a, float b) {               // ma
     asm("v_max_f32 %0, %1, |%2|" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // lane i of each row of 16 lanes receives lane i + 1's value (lane 15: zero)
 __device__ __forceinline__ unsigned int row_next(unsigned int v) {
     return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
@@ -102,8 +115,9 @@ struct RqF {
 template <bool FOLD>
 __device__ __forceinline__ RqF make_rqf(const Requant &rq) {
     RqF r;
-    r.s_pos = ldexpf(1.0f, rq.lk - rq.sh);
-    r.s_neg = (float)rq.neg_mul * ldexpf(1.0f, -rq.sh);
+    // wave-uniform: the two scales live in SGPRs (one constant-bus operand per fma), the addends in VGPRs
+    r.s_pos = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, rq.lk - rq.sh))));
+    r.s_neg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)rq.neg_mul * ldexpf(1.0f, -rq.sh))));
     r.c_pos = FOLD ? MAGIC - MAGIC * r.s_pos : MAGIC;
     r.c_neg = FOLD ? MAGIC - MAGIC * r.s_neg : MAGIC;
     r.scl = ldexpf(1.0f, rq.shl);
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     __shared__ __attribute__((aligned(16))) char p1[P1ROWS * P1P * 16];
     __shared__ __attribute__((aligned(16))) char stg[NG2 * 16 * 32];
     __shared__ __attribute__((aligned(16))) unsigned int lut[U8 ? 3 * 256 : 4];
+    __shared__ __attribute__((aligned(16))) char wl[U8 ? 16 : 4096 + 64];       // fp32 input: conv1's fragments and biases
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -135,25 +150,10 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     const float sc = p.in_scale;
     const float in_thr = 127.5f / sc;                  // |x| >= thr  <=>  rne(|x| * 2^sa0) > 127 (sc is a power of two)
 
-    // ---- biases stay in registers for the whole launch; the weight fragments (16 KiB, L2-resident) are re-read per tile
-    // just ahead of the phase that uses them, so that they are not live across the other phases (168 / 128 registers)
+    // ---- nothing but a few constants stays in registers across phases: the weight fragments and biases (16 KiB + 192 B,
+    // L2-resident) are re-read per tile just ahead of the phase that uses them (128 registers per lane at four workgroups per CU)
     const Requant rq1 = p.rq1, rq2 = p.rq2;
     const RqF f1 = make_rqf<FOLD>(rq1), f2 = make_rqf<FOLD>(rq2);
-    // accumulator register r of lane (li, g): conv1 channel 4 g + r; conv2 n-tile n: channel 8 g + 4 n + r
-    v4i cin1, cin2[2];
-    float bf1[4], bf2[2][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b1 = p.bias1[4 * g + r];
-        cin1[r] = FOLD ? b1 + 0x4B400000 : 0;
-        bf1[r] = (float)b1;
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int b2 = p.bias2[8 * g + 4 * n + r];
-            cin2[n][r] = FOLD ? b2 + 0x4B400000 : 0;
-            bf2[n][r] = (float)b2;
-        }
-    }
     if constexpr (U8) {
         // normalise + quantise is a function of the byte: per channel a 256-entry table built with the reference's
         // fp32 operations in the reference's order ((u/255 - mean)/std, data/__init__.py:43-45; round(x * 2^sa),
@@ -176,17 +176,6 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     // (j = 15 is an idle slot: 15 groups = 60 pixels per row are loaded)
     int qr0 = 4 * wave + g;                            // row of item k: qr0 + 16 k
     const int qj = li;
-    // OUT: relative output offset, (row << 8) | col or -1
-    int oofs[2], orc[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int item = tid + 256 * k;
-        const int px = item >> 1, half = item & 1;
-        const int row = px / TOX, col = px % TOX;
-        orc[k] = item < NW2 * 2 ? ((row << 8) | col) : -1;
-        oofs[k] = (row * (Wo + 2) + col) * 32 + half * 16;
-    }
-
     const int G_ = gridDim.x;
     int tile = y355_xcd_remap(blockIdx.x, G_);
     if (tile >= total_tiles) return;
@@ -197,30 +186,25 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
 #endif
     };
     (void)nstamp;
-    if constexpr (U8) front_lds_barrier();              // the table is complete
+    if constexpr (!U8) {
+        *(v4i *)(wl + tid * 16) = *(const v4i *)(p.wf + tid * 16);
+        if (tid < 4) *(v4i *)(wl + 4096 + 16 * tid) = *(const v4i *)(p.bias1 + 4 * tid);
+    }
+    front_lds_barrier();                                // the table / the fragments are complete
     unsigned int nsat_in = 0, nsat1 = 0, nsat2 = 0;
 
-    for (;; tile += G_) {
-        // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
-        // out of the tile loop as a loop invariant and held in registers
-        int li_ = li, g_ = g, lane_ = lane;
-        asm volatile("" : "+v"(qr0), "+v"(li_), "+v"(g_), "+v"(lane_));
-        int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
-        const int b = tile / (p.tiles_x * p.tiles_y);
+    // ---- a tile's input patch: QITEMS x (3 x float4 | 12 bytes) per thread, all in flight together.  (Issuing the next
+    // tile's under C2 of the current one was measured slower in every form -- all of it, half of it, three or four
+    // workgroups per CU: profiles/r03_notes.md; the other workgroups of the CU cover the wait.)
+    float4 vf[U8 ? 1 : QITEMS][3];
+    uint3 vu[U8 ? QITEMS : 1];
+    auto load_input = [&](int t) {
+        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
         const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
-        const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
-        stamp();
-
-        v4i w1[4];                                         // conv1: variant (dy, dx) = v >> 1, v & 1
-#pragma unroll
-        for (int v = 0; v < 4; ++v) w1[v] = *(const v4i *)(p.wf + v * 1024 + lane_ * 16);
-        // ---- load the tile's input patch: QITEMS x (3 x float4 | 12 bytes) per thread, all in flight together
-        float4 vf[U8 ? 1 : QITEMS][3];
-        uint3 vu[U8 ? QITEMS : 1];
 #pragma unroll
         for (int k = 0; k < QITEMS; ++k) {
             const int r = qr0 + 16 * k;
-            const int gy = min(max(y0p + r, 0), H - 1);           // rows / groups past the patch or the image re-read valid data
+            const int gy = min(max(y0p + r, 0), H - 1);       // rows / groups past the patch or the image re-read valid data
             const int gx = min(max(x0p + 4 * qj, 0), W - 4);
             const size_t o = (size_t)gy * W + gx;
             if constexpr (U8) {
@@ -231,6 +215,28 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                 for (int c = 0; c < 3; ++c) vf[k][c] = *(const float4 *)(xb + c * plane);
             }
         }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using KN = std::integral_constant<int, QITEMS>;
+
+    for (;; tile += G_) {
+        // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
+        // out of the tile loop as a loop invariant and held in registers
+        int li_ = li, g_ = g, lane_ = lane, tid_ = tid;
+        asm volatile("" : "+v"(qr0), "+v"(li_), "+v"(g_), "+v"(lane_), "+v"(tid_));
+        int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+        const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
+        stamp();
+
+        load_input(tile);
+        v4i w1g[U8 ? 4 : 1], b1g;
+        if constexpr (U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1g[v] = *(const v4i *)(p.wf + v * 1024 + lane_ * 16);
+            b1g = *(const v4i *)(p.bias1 + 4 * g_);
+        }
 #if FRONT_DIAG
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp();
@@ -240,12 +246,12 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
         // Patch column L holds global column x0p + 1 + L: the 4x4 neighbourhood of every conv1 window then starts on an
         // 8-byte boundary (one pixel to the left of the aligned 4-pixel groups the loads use: the fourth word of an
         // LDS group comes from the next lane).
-        auto quantise = [&](auto clampc) {
+        auto quantise = [&](auto clampc, auto k0c, auto k1c) {
             constexpr bool CLAMP = decltype(clampc)::value;      // cold: clamp (and count the tile's own clamped values)
             float am = 0.f;
             unsigned int sato = 0;
 #pragma unroll
-            for (int k = 0; k < QITEMS; ++k) {
+            for (int k = decltype(k0c)::value; k < decltype(k1c)::value; ++k) {
                 const int r = qr0 + 16 * k;
                 unsigned int w[4];
                 if constexpr (U8) {
@@ -315,28 +321,54 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
             }
             return U8 ? (sato >> 24) != 0u : !(am < in_thr);          // also true for NaN / Inf inputs
         };
+        if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{}, K0{}, KN{})) != 0ull) {
+            load_input(tile);                                 // cold: the input registers were given up after the hot pass
+            (void)quantise(std::true_type{}, K0{}, KN{});
+        }
+        // conv1: weight variant (dy, dx) = v >> 1, v & 1 and the biases as the MFMAs' C operand (accumulator register r of lane
+        // (li, g) = channel 4 g + r).  fp32 input: from the copy in LDS (the input registers leave no room to hold them
+        // through Q at 128 registers per lane); uint8 input: from global memory, in flight behind the frame bytes
+        v4i w1[4], b1v;
         if constexpr (U8) {
-            if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{})) != 0ull) (void)quantise(std::true_type{});
-        } else {
-            if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{})) != 0ull) (void)quantise(std::true_type{});
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1[v] = w1g[v];
+            b1v = b1g;
         }
         stamp();
         front_lds_barrier();                              // B1: patch complete
         stamp();
+        if constexpr (!U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1[v] = *(const v4i *)(wl + v * 1024 + lane_ * 16);
+            b1v = *(const v4i *)(wl + 4096 + 16 * g_);
+        }
+        v4i cin1;
+        float bf1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cin1[r] = FOLD ? b1v[r] + 0x4B400000 : 0;
+            bf1[r] = (float)b1v[r];
+        }
 
-        v4i w2[2][3][2];                                   // conv2: [n-tile][filter row][dx]; in flight during C1
+        // conv2 fragments [filter row][dx] of n-tile 0 (in flight during C1; n-tile 1's are loaded under the first C2 pass)
+        v4i w2a[3][2];
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) w2[n][ky][dx] = *(const v4i *)(p.wf + 4096 + ((n * 3 + ky) * 2 + dx) * 1024 + lane_ * 16);
+            for (int dx = 0; dx < 2; ++dx) w2a[ky][dx] = *(const v4i *)(p.wf + 4096 + (ky * 2 + dx) * 1024 + lane_ * 16);
+        const v4i b2v[2] = {*(const v4i *)(p.bias2 + 8 * g_), *(const v4i *)(p.bias2 + 8 * g_ + 4)};   // channel 8 g + 4 n + r
         // ---- C1: conv1 + pool1 -> p1.  Group = 16 consecutive windows of the 28 x 28 window grid (row-major);
         // wave w owns groups w, w + 4, ...  Lane (li, g): window li of the group, neighbourhood row g.
         const int gyp0 = 2 * TOY * ty - 1, gxp0 = 2 * TOX * tx - 1;     // pooled coordinates of window (0, 0)
-        auto c1 = [&](auto countc, auto borderc) {
-            constexpr bool COUNT = decltype(countc)::value, BORDER = decltype(borderc)::value;
+        // Passes (COLD = false / true).  FRONT_HOTCOLD: hot = round, pack and write UNCLAMPED, tracking the running max / min of
+        // the rounded values (two ops per four outputs); when they leave [-127, 127] (rare) the cold pass rewrites this
+        // wave's groups clamped and counts the tile's own clamped outputs.  Otherwise: hot = clamp + one detect op per
+        // output, cold = count only.
+        auto c1 = [&](auto coldc, auto borderc) {
+            constexpr bool COLD = decltype(coldc)::value, BORDER = decltype(borderc)::value;
+            constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
             unsigned int satx = 0;
+            float ymx = MAGIC, ymn = MAGIC;
             auto body = [&](int grp) {
                 const int w = grp * 16 + li_;
                 const int py = (w * 2341) >> 16;                  // w / 28 for w < 784
@@ -353,19 +385,26 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                 for (int r = 0; r < 4; ++r) {
                     const int m = max(max(a0[r], a1[r]), max(a2[r], a3[r]));
                     y[r] = rq_round<FOLD>(m, bf1[r], f1);
-                    yc[r] = __builtin_amdgcn_fmed3f(y[r], QLO, QHI);
+                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
                 }
-                const bool inimg = !(BORDER || COUNT) || ((unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp);
-                if constexpr (!COUNT) {
+                const bool inimg = !(BORDER || COLD) || ((unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp);
+                if constexpr (!COLD) {
+                    if constexpr (FRONT_HOTCOLD) {
+                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
+                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
-                    unsigned int word = pack4(yc[0], yc[1], yc[2], yc[3]);
-                    if constexpr (BORDER) word = inimg ? word : 0u;   // windows outside the image: conv2's zero padding
-                    *(unsigned int *)(p1 + (py * P1P + px) * 16 + 4 * g_) = word;
+                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
+                    }
                 } else {
                     const bool own = inimg && py >= 1 && py < P1H - 1 && px >= 1 && px < P1W - 1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                }
+                if constexpr (WRITE) {
+                    unsigned int word = pack4(yc[0], yc[1], yc[2], yc[3]);
+                    if constexpr (BORDER || COLD) word = inimg ? word : 0u;   // windows outside the image: conv2's zero padding
+                    *(unsigned int *)(p1 + (py * P1P + px) * 16 + 4 * g_) = word;
                 }
             };
             // wave w owns groups w, w + 4, ..., two per trip so that one group's epilogue runs under the other's MFMAs
@@ -376,6 +415,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
             }
             if (wave < NG1 % 8) body(wave + 8 * (NG1 / 8));
             static_assert(NG1 % 8 <= 4, "tail groups: at most one per wave");
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
             return satx;
         };
         unsigned int s1 = border ? c1(std::false_type{}, std::true_type{}) : c1(std::false_type{}, std::false_type{});
@@ -384,11 +424,27 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
         front_lds_barrier();                              // B2: p1 complete
         stamp();
 
-        // ---- C2: conv2 + pool2 -> staged int8 tile.  Group = 16 consecutive windows of the 13 x 13 grid (the last
-        // group's padding slots repeat window 168); k-step t = neighbourhood row t, lane group g = neighbourhood column.
-        auto c2 = [&](auto countc) {
-            constexpr bool COUNT = decltype(countc)::value;
+        // ---- C2: conv2 + pool2 -> staged int8 tile, one pass per n-tile (16 output channels: channel 8 g + 4 n + r in
+        // register r of lane group g).  Group = 16 consecutive windows of the 13 x 13 grid (the last group's padding slots
+        // repeat window 168); k-step t = neighbourhood row t, lane group g = neighbourhood column.
+        v4i w2b[3][2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) w2b[ky][dx] = *(const v4i *)(p.wf + 4096 + ((3 + ky) * 2 + dx) * 1024 + lane_ * 16);
+        auto c2 = [&](auto coldc, auto nc, const v4i (&w2)[3][2]) {
+            constexpr bool COLD = decltype(coldc)::value;
+            constexpr int n = decltype(nc)::value;
+            constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
             unsigned int satx = 0;
+            float ymx = MAGIC, ymn = MAGIC;
+            v4i cin2;
+            float bf2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cin2[r] = FOLD ? b2v[n][r] + 0x4B400000 : 0;
+                bf2[r] = (float)b2v[n][r];
+            }
 #pragma unroll 1
             for (int grp = wave; grp < NG2; grp += 4) {
                 const int wraw = grp * 16 + li_;
@@ -396,13 +452,11 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                 const int wy = (w * 5042) >> 16;                  // w / 13 for w < 169
                 const int wx = w - wy * TOX;
                 const char *src = p1 + ((2 * wy) * P1P + 2 * wx + g_) * 16;
-                v4i acc[2][2][2];                                 // [dy][dx][n]
+                v4i acc[2][2];                                    // [dy][dx]
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) acc[dy][dx][n] = cin2[n];
+                    for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = cin2;
                 v4i bq[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) bq[t] = *(const v4i *)(src + t * P1P * 16);
@@ -414,51 +468,51 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                         if (ky < 0 || ky > 2) continue;
 #pragma unroll
                         for (int dx = 0; dx < 2; ++dx)
-#pragma unroll
-                            for (int n = 0; n < 2; ++n)
-                                acc[dy][dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2[n][ky][dx], bq[t], acc[dy][dx][n], 0, 0, 0);
+                            acc[dy][dx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2[ky][dx], bq[t], acc[dy][dx], 0, 0, 0);
                     }
-                float y[2][4], yc[2][4];
+                float y[4], yc[4];
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int r = 0; r < 4; ++r) {
+                    const int m = max(max(acc[0][0][r], acc[0][1][r]), max(acc[1][0][r], acc[1][1][r]));
+                    y[r] = rq_round<FOLD>(m, bf2[r], f2);
+                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
+                }
+                if constexpr (!COLD) {
+                    if constexpr (FRONT_HOTCOLD) {
+                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
+                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = max(max(acc[0][0][n][r], acc[0][1][n][r]), max(acc[1][0][n][r], acc[1][1][n][r]));
-                        y[n][r] = rq_round<FOLD>(m, bf2[n][r], f2);
-                        yc[n][r] = __builtin_amdgcn_fmed3f(y[n][r], QLO, QHI);
+                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
                     }
-                if constexpr (!COUNT) {
-                    uint2 word;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[n][r]) ^ __float_as_uint(yc[n][r]);
-                    word.x = pack4(yc[0][0], yc[0][1], yc[0][2], yc[0][3]);
-                    word.y = pack4(yc[1][0], yc[1][1], yc[1][2], yc[1][3]);
-                    *(uint2 *)(stg + wraw * 32 + 8 * g_) = word;
                 } else {
                     const bool own = wraw < NW2 && TOY * ty + wy < Ho && TOX * tx + wx < Wo;
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) satx += (own && y[n][r] != yc[n][r]) ? 1u : 0u;
+                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
                 }
+                if constexpr (WRITE) *(unsigned int *)(stg + wraw * 32 + 8 * g_ + 4 * n) = pack4(yc[0], yc[1], yc[2], yc[3]);
             }
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
             return satx;
         };
-        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}) != 0) != 0ull) nsat2 += c2(std::true_type{});
+        using N0 = std::integral_constant<int, 0>;
+        using N1 = std::integral_constant<int, 1>;
+        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}, N0{}, w2a) != 0) != 0ull) nsat2 += c2(std::true_type{}, N0{}, w2a);
+        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}, N1{}, w2b) != 0) != 0ull) nsat2 += c2(std::true_type{}, N1{}, w2b);
         stamp();
         front_lds_barrier();                              // B3: staged tile complete
         stamp();
 
-        // ---- OUT: NHWC32 with halo, 16 bytes per thread and item
+        // ---- OUT: NHWC32 with halo, 16 bytes per thread and item (item = 2 * window + half)
         {
             int8_t *outb = p.out + (((size_t)b * (Ho + 2) + TOY * ty + 1) * (Wo + 2) + TOX * tx + 1) * 32;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int row = orc[k] >> 8, col = orc[k] & 0xff;
-                if (orc[k] >= 0 && TOY * ty + row < Ho && TOX * tx + col < Wo)
-                    *(v4i *)(outb + oofs[k]) = *(const v4i *)(stg + (tid + 256 * k) * 16);
+                const int item = tid_ + 256 * k;
+                const int wdw = item >> 1;
+                const int row = (wdw * 5042) >> 16, col = wdw - row * TOX;        // wdw / 13 for wdw < 256
+                if (item < NW2 * 2 && TOY * ty + row < Ho && TOX * tx + col < Wo)
+                    *(v4i *)(outb + (row * (Wo + 2) + col) * 32 + (item & 1) * 16) = *(const v4i *)(stg + item * 16);
             }
         }
         if (tile + G_ >= total_tiles) break;
@@ -518,11 +572,13 @@ void y355_launch_front(const FrontParams &p, hipStream_t s) {
     if (grid > total) grid = total;
     auto foldable = [](const Requant &rq) { return rq.shl == 0 && rq.tmax_log2 <= 22 && rq.sh <= 22 && rq.sh - rq.lk >= -8; };
     const bool fold = foldable(p.rq1) && foldable(p.rq2);
+    FrontParams q = p;
+    q.ev_start = q.ev_stop = nullptr;
     if (p.x) {
-        if (fold) hipLaunchKernelGGL((front_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, total);
-        else hipLaunchKernelGGL((front_kernel<false, false>), dim3(grid), dim3(256), 0, s, p, total);
+        if (fold) Y355_LAUNCH((front_kernel<false, true>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+        else Y355_LAUNCH((front_kernel<false, false>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
     } else {
-        if (fold) hipLaunchKernelGGL((front_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, total);
-        else hipLaunchKernelGGL((front_kernel<true, false>), dim3(grid), dim3(256), 0, s, p, total);
+        if (fold) Y355_LAUNCH((front_kernel<true, true>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+        else Y355_LAUNCH((front_kernel<true, false>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
     }
 }

@@ -874,7 +874,10 @@ int y355_prepare_head(void) {
     return (int)hipFuncSetAttribute((const void *)pairs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
 }
 
-void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid) {
+void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid,
+                          hipEvent_t (*kev)[2]) {
+    hipEvent_t none[2] = {nullptr, nullptr};
+    hipEvent_t *k0 = kev ? kev[0] : none, *k1 = kev ? kev[1] : none, *k2 = kev ? kev[2] : none, *k3 = kev ? kev[3] : none;
     HeadWork wk;
     wk.cbox = (float *)ws.cbox;
     wk.cscore = (float *)ws.cscore;
@@ -913,14 +916,14 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
         wk.rcount = (int *)ws.rcount;
         wk.ovf = (int *)ws.ovf;
         wk.rstride = ws.rstride;
-        hipLaunchKernelGGL(decode_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, s, p, wk);
+        Y355_LAUNCH(decode_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, s, k0[0], k0[1], p, wk);
         if (large) hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     }
-    hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
+    Y355_LAUNCH(head_kernel, dim3(batch), dim3(1024), 0, s, k1[0], k1[1], p, wk);
     if (mid) (void)hipEventRecord(mid, s);
     if (p.nms_thresh >= 1e-4f && p.nms_thresh < 1e4f)
-        hipLaunchKernelGGL(pairs_kernel<true>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
+        Y355_LAUNCH(pairs_kernel<true>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, k2[0], k2[1], p, wk, p.nms_thresh);
     else
-        hipLaunchKernelGGL(pairs_kernel<false>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, p, wk, p.nms_thresh);
-    hipLaunchKernelGGL(resolve_emit_kernel, dim3(batch), dim3(1024), 0, s, p, wk, p.nms_thresh);
+        Y355_LAUNCH(pairs_kernel<false>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, k2[0], k2[1], p, wk, p.nms_thresh);
+    Y355_LAUNCH(resolve_emit_kernel, dim3(batch), dim3(1024), 0, s, k3[0], k3[1], p, wk, p.nms_thresh);
 }

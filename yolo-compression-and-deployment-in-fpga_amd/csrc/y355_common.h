@@ -3,7 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <hip/hip_ext.h>
+
 typedef int v4i __attribute__((ext_vector_type(4)));
+
+// launch; with both events given the launch records its own start / end timestamps into them (profile mode 2: the
+// duration rocprofv3 reports for the kernel, without the gap to the neighbouring launches)
+#define Y355_LAUNCH(kernel, grid, block, lds, stream, e0, e1, ...)                                                       \
+    do {                                                                                                                 \
+        if ((e0) && (e1)) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, (hipEvent_t)(e0), (hipEvent_t)(e1), 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                          \
+    } while (0)
 
 // Fixed-point epilogue of one fused layer (DESIGN.md "requantisation"):
 //   t  = (acc << shl) + bias_t[c]        bias_t = q_b << (F - e_b),  F = max(sa_in + e_w, e_b)
@@ -115,6 +125,7 @@ struct FrontParams {
     float in_scale;       // 2^sa[0]
     Requant rq1, rq2;
     unsigned long long *stamps;   // diagnostic builds only (-DFRONT_DIAG=1)
+    void *ev_start, *ev_stop;     // host side only: see ConvParams
 };
 void y355_front_tiles(int H, int W, int *tx, int *ty);
 void y355_pack_front(const int8_t *q_w1, const int8_t *q_w2, int8_t *dst /*16384; a null tensor leaves its part zero*/);
@@ -256,7 +267,9 @@ struct y355_head_ws { void *cbox, *cscore, *ccls, *corig, *count, *edges, *nedge
 int y355_prepare_head(void);
 // decode, candidate sort, pruned pair walk (edge list), rounds + output.  `mid` (optional) is recorded
 // between the candidate sort and the pair walk.
-void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid);
+// `kev` (optional): start / end events of the four launches decode, candidate sort, pair walk, rounds + output
+void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid,
+                          hipEvent_t (*kev)[2] = nullptr);
 void y355_launch_absmax(const float *x, size_t n, unsigned int *out_bits, hipStream_t s);
 // uint8 HWC BGR frames -> fp32 NCHW RGB, BaseTransform arithmetic (data/__init__.py:30-56, test.py:79)
 void y355_launch_normalize_u8(const uint8_t *frames, float *x, int B, int H, int W, const float *mean_rgb, const float *std_rgb,

@@ -13,6 +13,7 @@ HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "yolo3
 
 MAX_ANCHORS = 16
 NUM_TIMERS = 12
+NUM_KERNEL_TIMERS = 14
 F_GUARD, F_TAP = 1, 2
 OP_LEAKY, OP_POOL, OP_RELU = 1, 2, 4
 OPT_FUSE_FRONT = 1
@@ -116,6 +117,8 @@ _SIGS = {
     "y355_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "y355_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
     "y355_profile_kernel_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
+    "y355_profile_kernels_get": (C.c_int, [C.c_void_p, P(C.c_float)]),
+    "y355_mfma_peak_i8": (C.c_int, [C.c_int, C.c_float, P(C.c_float), P(C.c_float)]),
     "y355_net_create": (C.c_int, [P(NetConfig), P(C.c_void_p)]),
     "y355_net_destroy": (None, [C.c_void_p]),
     "y355_net_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),

@@ -341,6 +341,20 @@ class Engine:
         _ffi.check(self._lib.y355_profile_kernel_get(self._h, arr))
         return list(arr)
 
+    def profile_kernels_ms(self):
+        """own durations (ms) of EVERY launch of the last forward profiled with profile(2): slots 0..9 layers (the fused front
+        end = slot 0), 10 head decode, 11 candidate sort, 12 NMS pair walk, 13 NMS rounds + output."""
+        arr = (C.c_float * _ffi.NUM_KERNEL_TIMERS)()
+        _ffi.check(self._lib.y355_profile_kernels_get(self._h, arr))
+        return list(arr)
+
+
+def mfma_peak_i8(device_id=0, ms_target=50.0):
+    """(Top/s, in-kernel clock in GHz) of back-to-back v_mfma_i32_16x16x64_i8 on this GPU (y355_mfma_peak_i8)."""
+    t, c = C.c_float(), C.c_float()
+    _ffi.check(_ffi.lib().y355_mfma_peak_i8(int(device_id), float(ms_target), C.byref(t), C.byref(c)))
+    return float(t.value), float(c.value)
+
 
 def _act_flag(leaky, relu):
     if leaky and relu:
