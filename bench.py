@@ -633,8 +633,14 @@ def main():
                     shard.pack_detections_kernel(*[t[:B] for t in o_r], B, ref, gather_md)
                     torch.cuda.synchronize()
                     bad_records += int((ref != grecv[0][r * B:(r + 1) * B]).any(dim=1).sum().item())
-                    for a, b_ in zip(o_r, g_full):
-                        bad_full += int((a[:B] != b_[r * B:(r + 1) * B]).sum().item())
+                    # the engine's padded outputs hold stale values past count[i]; the gathered arrays hold zeros there
+                    cnt = o_r[3][:B]
+                    keep = torch.arange(o_r[1].shape[1], device=dev)[None, :] < cnt[:, None]
+                    sl = slice(r * B, (r + 1) * B)
+                    bad_full += int((g_full[3][sl] != cnt).sum().item())
+                    bad_full += int(((o_r[0][:B] != g_full[0][sl]).any(dim=2) & keep).sum().item())
+                    bad_full += int(((o_r[1][:B] != g_full[1][sl]) & keep).sum().item())
+                    bad_full += int(((o_r[2][:B] != g_full[2][sl]) & keep).sum().item())
             rg.close()
         gather_info = {"gather_verified": bad_records == 0 and bad_full == 0, "dist_world_size": dist.get_world_size(),
                        "y355_comm_world": comm_world, "records_compared": world * B, "mismatching_records": bad_records,
@@ -732,7 +738,8 @@ def main():
                          "kernel_ms_sum": round(float(kernel_ms.sum()), 4),
                          # MFMA-only loop MEASURED IN THIS RUN (y355_mfma_peak_i8: v_mfma_i32_16x16x64_i8 back to back on register
                          # operands, two waves per SIMD on every CU, ~50 ms) and the in-kernel clock it held
-                         "peak_measured": round(peak_tops, 1), "peak_measured_clock_ghz": round(peak_clock, 3),
+                         "peak_measured": round(peak_tops, 1),
+                         "peak_measured_implied_clock_ghz": round(peak_tops * 1e12 / (1024 * 32768 / 16) / 1e9, 3),   # 16 cycles per MFMA and SIMD
                          "frac_of_measured_peak": round(dom_tops / peak_tops, 4) if peak_tops else None,
                          "all_conv_achieved": round(achieved, 2),
                          "all_conv_frac": round(achieved * 1e12 / PEAK_I8_DENSE, 4),
@@ -785,7 +792,7 @@ def main():
             failed = bool(flag.item())
         dist.destroy_process_group()
     if failed:
-        sys.exit("bench.py: the gathered detections differ from the single-GPU run")
+        sys.exit("bench.py: the gathered detections differ from the single-GPU run: %s" % json.dumps(gather_info))
 
 
 if __name__ == "__main__":

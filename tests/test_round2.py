@@ -504,8 +504,9 @@ def test_nms_edge_list_limits(case):
 
 @pytest.mark.gpu
 def test_kernel_timestamps_of_the_ring_layers():
-    """y355_profile(h, 2) / y355_profile_kernel_get: the ring layers (conv3_2 .. pred) report their own kernel durations, positive
-    and no longer than the interval between the events around the launch; the other layers report 0; results are unchanged."""
+    """y355_profile(h, 2) / y355_profile_kernels_get: every launch of a forward (the fused front end in slot 0, the eight other layers,
+    the four head / NMS kernels) reports its own duration, positive and no longer than the interval between the events around
+    it; results are unchanged."""
     from yolo355.engine import Engine
     B = 4
     ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2))
@@ -516,13 +517,15 @@ def test_kernel_timestamps_of_the_ring_layers():
     ref = eng.forward(x)
     eng.profile(2)
     got = eng.forward(x)
-    ms, kms = eng.profile_ms(), eng.profile_kernel_ms()
+    ms, kms, allk = eng.profile_ms(), eng.profile_kernel_ms(), eng.profile_kernels_ms()
     eng.profile(False)
     for a, b in zip(ref, got):
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
-    assert all(k == 0 for k in kms[:3]) and all(k > 0 for k in kms[3:]), kms
-    assert all(kms[i] <= ms[i] * 1.25 + 5e-3 for i in range(3, 10)), (kms, ms)        # same forward: the interval contains the kernel
+    assert len(allk) == 14 and allk[:10] == kms
+    assert kms[1] == 0 and all(k > 0 for i, k in enumerate(allk) if i != 1), allk      # slot 1: conv2 runs inside the fused launch
+    assert all(kms[i] <= ms[i] * 1.25 + 5e-3 for i in range(2, 10)), (kms, ms)        # same forward: the interval contains the kernel
+    assert allk[10] + allk[11] <= ms[10] * 1.25 + 5e-3 and allk[12] + allk[13] <= ms[11] * 1.25 + 5e-3, (allk, ms)
     eng.close()
 
 

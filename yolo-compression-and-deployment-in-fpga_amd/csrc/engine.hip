@@ -53,6 +53,8 @@ struct Layer {
     bool loaded = false, bias_dirty = true;
     std::vector<int32_t> q_b;
     int8_t *w_dev = nullptr;
+    int8_t *wpx_dev = nullptr;      // conv3_1: the same weights in convpx.hip's fragment order
+    long long wabs = 0;             // max over output channels of sum |q_w| (0: not loaded): the tight bound of |acc| / 127
     int *bias_dev = nullptr;
     long long *bias_w_dev = nullptr;
     int8_t *out_dev = nullptr;
@@ -75,6 +77,8 @@ int y355_prepare_kernels() {
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(v2): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_ring())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(ring): ") + hipGetErrorString((hipError_t)e));
+    if (int e = y355_prepare_conv_px())
+        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(px): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_convg())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(convg): ") + hipGetErrorString((hipError_t)e));
     kernels_prepared = 1;
@@ -87,9 +91,11 @@ int prepare_kernels() { return y355_prepare_kernels(); }
 // overflow for worst-case operands.
 // act: 0 none (prediction layer), 1 LeakyReLU(0.125) (t' = t >= 0 ? 8 t : t, F' = F + 3), 2 ReLU (utils/modules.py:26 with
 // leakyReLU=False: t' = max(t, 0), F' = F; runs on the generic kernels, whose epilogue honours neg_mul = 0)
+// wabs: max over output channels of sum |q_w| when known (else 0: 127 per weight is assumed) -- only Requant::tmax_log2, the
+// gate of the fp32-exact epilogues, uses this tight bound; `wide` keeps the operand-independent one
 int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool have_out, int act, int retune,
                  const int32_t *q_b, int cout, int cout_pad, Requant *rq, int *frac_bits, std::vector<int32_t> *bias_t,
-                 std::vector<long long> *bias_w) {
+                 std::vector<long long> *bias_w, long long wabs = 0) {
     const int F = std::max(sa_in + e_w, e_b);
     const int shl = F - sa_in - e_w, bshl = F - e_b;
     const int leaky = act == 1 ? 1 : 0;
@@ -116,7 +122,8 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     if (lim >= std::ldexp(1.0L, 62)) return fail(Y355_ERANGE, "fixed-point epilogue exceeds 62 bits");
     rq->wide = lim >= std::ldexp(1.0L, 30) ? 1 : 0;
     {
-        const long long t0 = ((long long)127 * 127 * 9 * cin_real) * (1ll << shl) + bmax;
+        const long long rowsum = wabs > 0 ? wabs : (long long)127 * 9 * cin_real;
+        const long long t0 = (127 * rowsum) * (1ll << shl) + bmax;
         int n = 0;
         while (n < 62 && t0 >= (1ll << n)) ++n;
         rq->tmax_log2 = n;
@@ -369,6 +376,24 @@ extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const
             HIPCHK(hipMemcpy(h->wf_dev + 4096, ff.data() + 4096, 12288, hipMemcpyHostToDevice));
         }
     }
+    {
+        long long best = 0;
+        const size_t per = (size_t)cin * 9;
+        for (int c = 0; c < cout; ++c) {
+            long long sum = 0;
+            for (size_t i = 0; i < per; ++i) sum += std::abs((int)q_w[(size_t)c * per + i]);
+            best = std::max(best, sum);
+        }
+        L.wabs = best;
+    }
+    if (L.kid == Y355_K_CONV3_1 && cin == 32 && cout == 64) {
+        std::vector<int8_t> px(20480);
+        y355_pack_px32(q_w, px.data());
+        if (!L.wpx_dev) {
+            if (int rc = dmalloc(h, (void **)&L.wpx_dev, px.size(), false)) return rc;
+        }
+        HIPCHK(hipMemcpy(L.wpx_dev, px.data(), px.size(), hipMemcpyHostToDevice));
+    }
     L.q_b.assign(q_b, q_b + cout);
     L.e_w = e_w;
     L.e_b = e_b;
@@ -424,7 +449,7 @@ static int refresh_layer(y355_engine *h, int k, bool need_out) {
     std::vector<int32_t> bt;
     std::vector<long long> bw;
     int rc = make_requant(L.cin, h->sa[k], L.e_w, L.e_b, h->sa[k + 1], h->sa_set[k + 1], L.leaky, h->retune[k],
-                          L.q_b.data(), L.cout, L.cout_pad, &L.rq, &L.frac_bits, &bt, &bw);
+                          L.q_b.data(), L.cout, L.cout_pad, &L.rq, &L.frac_bits, &bt, &bw, L.wabs);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(L.bias_dev, bt.data(), sizeof(int) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(L.bias_w_dev, bw.data(), sizeof(long long) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
@@ -494,6 +519,15 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         constexpr bool no_v2 = false;
         constexpr int no_v2_mask = 0, no_ring_mask = 0;
 #endif
+        if (!no_v2 && L.wpx_dev) {                            // conv3_1: weights in registers, pixels as the B operand (convpx.hip)
+            ConvParams q = p;
+            q.w = L.wpx_dev;
+            if (y355_launch_conv_px(L.kid, q, h->stream)) {
+                HIPCHK(hipGetLastError());
+                h->kev_set[k] = p.ev_start != nullptr;
+                return 0;
+            }
+        }
         // layers whose whole weight tensor stays resident in LDS run conv3x3_v2.hip (no per-k-step barrier); the others the ring
         if (!no_v2 && y355_conv_v2_preferred(L.kid) && y355_launch_conv_v2(L.kid, p, h->stream)) {
             HIPCHK(hipGetLastError());
