@@ -11,7 +11,7 @@ import re
 import subprocess
 import sys
 
-GUARDED = ("conv3x3_i8_ring_kernel", "conv3x3_i8_v2_kernel", "conv1_fast_kernel", "front_kernel", "convpx32_kernel")
+GUARDED = ("conv3x3_i8_ring_kernel", "conv3x3_i8_v2_kernel", "conv1_fast_kernel", "front_kernel", "convpx_kernel")
 
 
 def main(build):

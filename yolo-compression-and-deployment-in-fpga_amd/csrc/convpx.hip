@@ -1,35 +1,43 @@
-// yolo355 -- conv3_1 (32 -> 64 channels on the quarter-resolution map, models/slim_yolo_v2.py:246-256; the FPGA's
-// third conv_normal call, c_embedding/yolo_forward.c:1214-1218): production kernel, round 3.
+// yolo355 -- conv3_1, conv3_2 (+pool), conv4_1, conv4_2 (+pool) of the q_bf path (models/slim_yolo_v2.py:246-288; the
+// FPGA's conv_normal calls 3-6, c_embedding/yolo_forward.c:1214-1236): production kernels, round 3.
 //
-// K = 9 taps x 32 channels = 288 is too shallow for the deep layers' ring kernel (its per-tile start-up and its staged
-// two-pass epilogue were the kernel: 31.8 us for 5 us of MFMA work and 66 MB of compulsory traffic).
-// This one turns the GEMM round, as the fused front end does (front.hip):
-//   * the WEIGHTS are the MFMA's A operand (rows = output channels) and stay in registers for the whole launch
-//     (5 k-steps x 4 n-tiles x 4 VGPRs = 80); the PIXELS are the B operand (columns = 16 consecutive pixels of a row),
-//     read from an LDS slab with one ds_read_b128 per k-step (k-step = two taps x 32 channels; 16 pixels at a 32-byte
-//     pitch are conflict-free under gfx950's 4 x 16 lane grouping);
-//   * output channel 16 g + 4 n + r sits in register r of n-tile n of lane group g (weight rows are permuted so on the
-//     host), so a lane ends up with 16 CONSECUTIVE channels of ONE pixel: one packed global_store_dwordx4 per lane,
-//     1 KiB contiguous per wave-instruction -- no LDS staging, no second pass;
-//   * the input slab of a tile (TH + 2 whole padded rows) is ONE contiguous range of the NHWC32 buffer with its zero
-//     halo: a linear LDS-DMA copy (global_load_lds_dwordx4), double-buffered across the tiles a workgroup walks;
-//   * the epilogue is front.hip's fp32 form (two fma + max + med3 on exact integers; FOLD: bias + 0x4B400000 as the
-//     MFMAs' C operand).
-// Integer semantics: DESIGN.md section 2, bit for bit those of conv3x3_v2.hip / conv3x3.hip.
+// These layers have K = 288 .. 1152: too shallow for the deep layers' ring kernel, whose per-tile start-up, per-k-step
+// barrier and staged two-pass epilogue were most of their time (22-31 us per launch for 5-10 us of MFMA work).
+// Here the GEMM is turned round, as in the fused front end (front.hip):
+//   * the WEIGHTS are the MFMA's A operand (rows = output channels).  A wave owns a block of 16 NTN output channels and keeps
+//     ALL of that block's weight fragments in registers for the whole launch (72-144 VGPRs): no weight traffic, no barrier
+//     inside a chunk of work;
+//   * the PIXELS are the B operand (columns = 16 consecutive pixels, or 16 consecutive 2x2 pooling windows), read from an
+//     LDS slab with ds_read_b128.  Pooled layers read the 4x4 input neighbourhood of a window once and feed it to the four
+//     conv outputs of the window (four accumulator sets, same B registers); the pool is an element-wise max;
+//   * output channel (4 NTN) g + 4 n + r sits in register r of n-tile n of lane group g (weight rows are permuted so on the
+//     host), so a lane ends up with 4 NTN CONSECUTIVE channels of ONE pixel: one packed 8 / 16-byte global store per lane,
+//     contiguous across the wave -- no LDS staging, no second pass;
+//   * work is dealt in groups of 16 pixels / windows over the row-major image; workgroup i owns a contiguous, equal share
+//     of all groups of the batch and walks it in chunks of a few rounds of its waves;
+//   * the input lives in LDS as a ROLLING RING of whole padded rows (slot = absolute padded row & (R - 1)): every row is
+//     copied once per workgroup by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces that each stay inside one row: the LDS
+//     pitch is padded to a piece multiple), the rows the NEXT chunk adds are in flight while this chunk computes, and the
+//     chunk boundary waits with a COUNTED vmcnt that leaves the chunk's own output stores in flight.  64- and 128-byte
+//     pixels are XOR-swizzled on the source side so that every ds_read_b128 is conflict-free under gfx950's 4 x 16 lane
+//     grouping (chunk ^ 2 ((x >> 2) & 1) resp. chunk ^ 2 ((x >> 1) & 3));
+//   * the epilogue is front.hip's fp32 form (two fma + max on exact integers).  FOLD 2 (accumulator shift 0, |t| < 2^22): bias +
+//     0x4B400000 rides in as the MFMAs' C operand and the accumulator IS the float 1.5 * 2^23 + t; FOLD 1 (shift 0, |t| < 2^24):
+//     the bias rides in, one v_cvt; FOLD 0: v_cvt + fma; the hot pass stores unclamped and tracks max / min, a cold pass re-does a wave's groups clamped and
+//     counts when a value left [-127, 127].
+// Integer semantics: DESIGN.md section 2, bit for bit those of conv3x3_ring.hip / conv3x3_v2.hip / conv3x3.hip.
 #include "y355_common.h"
 #include <cstring>
 #include <type_traits>
-
-#ifndef PX_ABL
-#define PX_ABL 0                 // timing ablations (WRONG RESULTS): 1 no stores, 2 no epilogue arithmetic, 4 no MFMAs, 8 no LDS reads
+#ifndef PX_R31
+#define PX_R31 11                // groups per wave and chunk, conv3_1 / conv4_1: two chunks per workgroup at B = 64, 416 x 416
+#define PX_R41 6
 #endif
 #ifndef PX_DIAG
-#define PX_DIAG 0                // 1: s_memrealtime stamps (100 MHz) per workgroup at the phase boundaries (y355_debug_stamps, layer 2)
+#define PX_DIAG 0                // 1: s_memrealtime stamps (100 MHz) per workgroup at the chunk boundaries (y355_debug_stamps)
 #endif
 
 namespace {
-constexpr int CIN = 32, COUT = 64, KS = 5, NTN = 4;
-constexpr int PXB = CIN;                             // bytes per input pixel
 constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23
 constexpr float QLO = 12582785.0f, QHI = 12583039.0f;
 
@@ -57,217 +65,443 @@ __device__ __forceinline__ unsigned int ppack4(float a, float b, float c, float 
     const unsigned int cd = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x04000c0cu);
     return ab | cd;
 }
+
+// geometry shared by the kernel, the launcher and the weight packing
+template <int CIN, int NTN, int NCB, bool POOL>
+struct PxGeom {
+    static constexpr int PXB = CIN;                              // bytes per input pixel
+    static constexpr int PPP = 1024 / PXB;                       // pixels per 1 KiB DMA piece (= LDS pitch granule)
+    static constexpr int KPP = CIN >= 64 ? CIN / 64 : 1;         // k-steps per tap
+    static constexpr int KS = CIN >= 64 ? 9 * KPP : 5;           // CIN = 32: two taps per k-step
+    static constexpr int CPB = 16 * NTN;                         // output channels per block (per wave)
+    static constexpr int COUT = CPB * NCB;
+    static constexpr int NFRAG = NCB * KS * NTN;
+    static_assert(CIN == 32 || CIN == 64 || CIN == 128, "input channels");
+    static_assert(!(POOL && CIN < 64), "pooled layers: one tap per k-step");
+};
+
+struct PxArgs {
+    int total_groups;     // groups of 16 pixels / windows in the batch (ngi per image)
+    int ngi;              // groups per image
+    int cg;               // groups per chunk (a multiple of the pixel streams of a workgroup)
+    int pwl;              // LDS row pitch in pixels (a multiple of PPP, >= W + 2)
+    int logr;             // ring of 2^logr rows
+    int ppg;              // DMA pieces a wave issues behind each of its groups
+};
+// image, groups [g0, g1) of it, absolute padded input rows [lo, hi) it reads (row = b * (H + 2) + padded row of the image)
+struct PxChunk { int b, g0, g1, lo, hi; };
+
+// s_waitcnt needs an immediate; n is wave-uniform
+__device__ __forceinline__ void pwait_vmcnt(int n) {
+#define PW_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        PW_CASE(0) PW_CASE(1) PW_CASE(2) PW_CASE(3) PW_CASE(4) PW_CASE(5) PW_CASE(6) PW_CASE(7) PW_CASE(8) PW_CASE(9)
+        PW_CASE(10) PW_CASE(11) PW_CASE(12) PW_CASE(13) PW_CASE(14) PW_CASE(15) PW_CASE(16)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef PW_CASE
+}
 }  // namespace
 
-// TH rows x the whole map width per tile; NW waves; groups of 16 consecutive (row-major) pixels of the tile, wave w owns
-// groups w, w + NW, ...
-template <int TH, int NW, bool FOLD>
-__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx32_kernel(const ConvParams p, const int total_tiles, const int slab_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // two slabs of slab_bytes (a multiple of 1 KiB)
+template <int CIN, int NTN, int NCB, bool POOL, int NW, int FOLD>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx_kernel(const ConvParams p, const PxArgs a) {
+    using G = PxGeom<CIN, NTN, NCB, POOL>;
+    constexpr int PXB = G::PXB, PPP = G::PPP, KPP = G::KPP, KS = G::KS, CPB = G::CPB, COUT = G::COUT;
+    constexpr int NPS = NW / NCB;                        // pixel streams: waves that share a channel block
+    constexpr int NV = POOL ? 4 : 1;                     // conv outputs per column (pooling window)
+    static_assert(NW % NCB == 0, "waves per channel block");
+    static_assert(NTN == 4 || NTN == 2, "16- or 8-byte stores");
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // ring of 2^logr rows of PWL * PXB bytes
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave % NCB, ps = wave / NCB;
     const int li = lane & 15, g = lane >> 4;
     const int H = p.H, W = p.W;
-    const int PW = W + 2;
-    const int tiles_y = p.tiles_y;
+    const int PW = W + 2, PWL = a.pwl;
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+    const int npw = Ho * Wo;                             // pixels / windows per image
+    const int rowb = PWL * PXB;                          // bytes per slab row
 
-    // ---- weights: A fragments [k-step][n-tile], registers for the whole launch
+    // ---- weights of this wave's channel block: A fragments [k-step][n-tile], registers for the whole launch
     v4i wf[KS][NTN];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int n = 0; n < NTN; ++n) wf[ks][n] = *(const v4i *)(p.w + (ks * NTN + n) * 1024 + lane * 16);
-    // accumulator register r of n-tile n of lane group g = channel 16 g + 4 n + r
+        for (int n = 0; n < NTN; ++n) wf[ks][n] = *(const v4i *)(p.w + ((size_t)(cb * KS + ks) * NTN + n) * 1024 + lane * 16);
+    // accumulator register r of n-tile n of lane group g = channel cb * CPB + 4 NTN g + 4 n + r
     v4i cin[NTN];
     float bf[NTN][4];
 #pragma unroll
     for (int n = 0; n < NTN; ++n) {
-        const v4i bv = *(const v4i *)(p.bias_t + 16 * g + 4 * n);
+        const v4i bv = *(const v4i *)(p.bias_t + cb * CPB + 4 * NTN * g + 4 * n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            cin[n][r] = FOLD ? bv[r] + 0x4B400000 : 0;
+            cin[n][r] = FOLD == 2 ? bv[r] + 0x4B400000 : FOLD == 1 ? bv[r] : 0;
             bf[n][r] = (float)bv[r];
         }
     }
     const Requant rq = p.rq;
     const float s_pos = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, rq.lk - rq.sh))));
     const float s_neg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)rq.neg_mul * ldexpf(1.0f, -rq.sh))));
-    const float c_pos = FOLD ? MAGIC - MAGIC * s_pos : MAGIC, c_neg = FOLD ? MAGIC - MAGIC * s_neg : MAGIC;
+    const float c_pos = FOLD == 2 ? MAGIC - MAGIC * s_pos : MAGIC, c_neg = FOLD == 2 ? MAGIC - MAGIC * s_neg : MAGIC;
     const float scl = ldexpf(1.0f, rq.shl);
-    // B operand of k-step ks: tap 2 ks + (g >> 1), channel half g & 1 (tap 9 multiplies zero weights: it re-reads tap 8)
-    int koff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int tap = min(2 * ks + (g >> 1), 8);
-        koff[ks] = ((tap / 3) * PW + tap % 3) * PXB + 16 * (g & 1);
-    }
-    const float invW = 1.0f / (float)W;
+    const float invWo = 1.0f / (float)Wo;
 
-    auto tile_rows = [&](int t, int &b, int &y0) {
-        b = t / tiles_y;
-        y0 = (t - b * tiles_y) * TH;
-        return min(TH, H - y0);
+    // ---- this workgroup's share of the batch's groups, walked in chunks of <= cg groups that stay inside one image
+    const int G_ = gridDim.x;
+    const int gbeg = (int)((long long)a.total_groups * blockIdx.x / G_), gend = (int)((long long)a.total_groups * (blockIdx.x + 1) / G_);
+    if (gbeg >= gend) return;
+    constexpr int MUL = POOL ? 2 : 1;
+    const int R = 1 << a.logr, RM = R - 1;
+    auto chunk_at = [&](int gg) {
+        PxChunk c;
+        c.b = gg / a.ngi;
+        c.g0 = gg - c.b * a.ngi;
+        c.g1 = min(min(c.g0 + a.cg, a.ngi), c.g0 + (gend - gg));
+        const int ya = (16 * c.g0) / Wo, yb = (min(16 * c.g1, npw) - 1) / Wo;
+        c.lo = c.b * (H + 2) + MUL * ya;
+        c.hi = c.b * (H + 2) + MUL * yb + (POOL ? 4 : 3);
+        return c;
     };
-    // slab of tile t = padded rows y0 .. y0 + rows + 1, contiguous in the input buffer; whole 1 KiB pieces, piece q by wave q % NW
-    auto issue_slab = [&](int t, int buf) {
-        int b, y0;
-        const int rows = tile_rows(t, b, y0);
-        const int8_t *src = p.in + ((size_t)b * (H + 2) + y0) * PW * PXB;
-        const int npiece = ((rows + 2) * PW * PXB + 1023) >> 10;
-        for (int q = wave; q < npiece; q += NW) pglds16(src + (size_t)q * 1024 + lane * 16, smem + buf * slab_bytes + q * 1024);
+    // absolute padded rows [r0, r1) -> ring slots row & RM; piece q = 1 KiB = PPP pixels of ONE row, by wave q % NW.
+    // Lane l writes LDS chunk l % CPX of pixel l / CPX of the piece and reads the source chunk the swizzle puts there.
+    constexpr int CPX = PXB / 16;                        // 16-byte chunks per pixel
+    const int dpx = lane / CPX, dch = lane % CPX;
+    const int ppr = PWL / PPP;                           // pieces per row
+    // pieces [q, q + NW, ...) < npiece of rows r0 ..: at most `count` of them; (rr, pc) = (q / ppr, q % ppr) travel with the cursor
+    struct Cursor { int q, rr, pc; };
+    auto cursor_at = [&](int q) { Cursor c; c.q = q; c.rr = q / ppr; c.pc = q - c.rr * ppr; return c; };
+    auto issue_pieces = [&](int r0, int npiece, Cursor &c, int count) {
+        int done = 0;
+        for (; c.q < npiece && done < count; ++done) {
+            const int row = r0 + c.rr, col = c.pc * PPP + dpx;
+            int sch = dch;
+            if constexpr (CPX == 4) sch ^= ((col >> 2) & 1) << 1;
+            if constexpr (CPX == 8) sch ^= ((col >> 1) & 3) << 1;
+            pglds16(p.in + ((row * PW + min(col, PW - 1)) * PXB + 16 * sch), smem + (row & RM) * rowb + c.pc * 1024);
+            c.q += NW;
+            c.pc += NW;
+            while (c.pc >= ppr) { c.pc -= ppr; ++c.rr; }
+        }
+        return done;
+    };
+    auto issue_rows = [&](int r0, int r1) {
+        Cursor c = cursor_at(wave);
+        issue_pieces(r0, (r1 - r0) * ppr, c, 1 << 30);
     };
 
-    int tile = blockIdx.x;
-    if (tile >= total_tiles) return;
     int nstamp = 0;
     auto stamp = [&]() {
 #if PX_DIAG
+#if PX_DIAG == 2      // every wave, 16 stamps each (256 workgroups x 8 waves)
+        if (p.stamps && lane == 0 && nstamp < 16 && blockIdx.x < 128) p.stamps[((size_t)blockIdx.x * NW + wave) * 16 + nstamp++] = __builtin_amdgcn_s_memrealtime();
+#else
         if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
     };
     (void)nstamp;
     stamp();
-    issue_slab(tile, 0);
+    PxChunk ch = chunk_at(gbeg);
+    issue_rows(ch.lo, ch.hi);
+    int loaded = ch.hi;                                  // rows below `loaded` (and not yet overwritten) are in the ring or in flight
     unsigned int nsat = 0;
-    int buf = 0;
-    for (;; tile += gridDim.x, buf ^= 1) {
-        // the slab of this tile has landed (and the previous tile's stores have drained); every wave is past its reads of the
-        // other buffer, which the next tile's slab now overwrites
+    int gg = gbeg, nstores = -1;                         // stores this wave issued in the previous chunk (-1: wait for everything)
+    for (;;) {
+        // Everything this chunk reads has landed: the rows were issued BEFORE the previous chunk's output stores, so a counted
+        // wait leaves those stores in flight.  Behind the barrier every wave is done with the previous chunk's rows.
         stamp();
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        pwait_vmcnt(nstores);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp();
         __builtin_amdgcn_s_barrier();
+        if (loaded < ch.hi) {                            // rows that could not be issued ahead (the ring was full: image boundaries)
+            issue_rows(max(loaded, ch.lo), ch.hi);
+            loaded = ch.hi;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         stamp();
-        const bool more = tile + (int)gridDim.x < total_tiles;
-        if (more) issue_slab(tile + gridDim.x, buf ^ 1);
-        int b, y0;
-        const int rows = tile_rows(tile, b, y0);
-        const int npix = rows * W;
-        const int ngrp = (npix + 15) >> 4;
-        const char *slab = smem + buf * slab_bytes;
-        int8_t *outb = p.out + (((size_t)b * (H + 2) + y0 + 1) * PW + 1) * COUT;      // wave-uniform; the lane's part is a 32-bit offset
+        const int gnext = gg + (ch.g1 - ch.g0);
+        const bool more = gnext < gend;
+        PxChunk nx = ch;
+        if (more) nx = chunk_at(gnext);
+        // the next chunk's new rows, as far as they fit beside the rows this chunk still reads, go out a few pieces at a time
+        // behind each group's MFMAs (the SIMD's other wave computes while this one issues); the chunk boundary may leave in
+        // flight only the stores issued after the LAST piece
+        int pf_r0 = 0, pf_np = 0;
+        if (more) {
+            const int top = min(nx.hi, ch.lo + R);
+            pf_r0 = max(loaded, nx.lo);
+            if (top > pf_r0) {
+                pf_np = (top - pf_r0) * ppr;
+                loaded = top;
+            }
+        }
+        Cursor pfc = cursor_at(wave);
+        auto prefetch = [&](int count) {
+            if (issue_pieces(pf_r0, pf_np, pfc, count) > 0) nstores = 0;
+        };
+        stamp();
+        int8_t *outb = p.out + (((size_t)ch.b * (Ho + 2) + 1) * (Wo + 2) + 1) * COUT + cb * CPB;    // wave-uniform
+        const int rbase = ch.b * (H + 2);
 
-        // Hot pass: round, pack and store UNCLAMPED, tracking the running max / min of the rounded values (two ops per four
-        // outputs).  When they leave [-127, 127] (rare) the cold pass recomputes this wave's groups from the slab, which is still
-        // in LDS, stores them clamped and counts the clamped outputs of real pixels.
         float ymx = MAGIC, ymn = MAGIC;
-        auto body = [&](int grp, auto coldc) {
-            constexpr bool COLD = decltype(coldc)::value;
-            const int pr = grp * 16 + li;
-            const int pc = min(pr, npix - 1);                      // padding lanes of the last group repeat its last pixel
-            const int py = (int)(((float)pc + 0.5f) * invW);       // pc / W (exact: pc < 2^16)
-            const int px = pc - py * W;
-            const char *src = slab + (py * PW + px) * PXB;
-            v4i acc[NTN];
+        // ---- one group = issue (addresses, B reads, MFMAs) + finish (pool, requantise, pack, store).  (A software pipeline over
+        // two accumulator sets with the finish interleaved behind the next group's MFMAs, pinned read-then-MFMA orders and a
+        // raised priority for the SIMD's second wave were each measured: no change, profiles/r03_notes.md.)
+        auto locate = [&](int grp, int &oy, int &ox) {
+            const int pc = min(grp * 16 + li, npw - 1);            // padding lanes of an image's last group repeat its last pixel
+            oy = (int)(((float)pc + 0.5f) * invWo);                // pc / Wo (exact: pc < 2^16)
+            ox = pc - oy * Wo;
+        };
+        auto issue = [&](int grp, v4i (&acc)[NV][NTN]) {
+            int oy, ox;
+            locate(grp, oy, ox);
+            const int ar = rbase + MUL * oy, x0 = MUL * ox;        // absolute padded row / padded column of the neighbourhood's corner
+            // byte offset inside a row of neighbourhood column c: pixel x0 + c, chunk g (CIN = 32: the half is added per
+            // k-step), swizzled by the pixel's x; byte offset of neighbourhood row r in the ring
+            constexpr int NC = POOL ? 4 : 3;
+            int xoff[NC], roff[NC];
 #pragma unroll
-            for (int n = 0; n < NTN; ++n) acc[n] = cin[n];
-            v4i bq[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if constexpr (PX_ABL & 8) bq[ks] = (v4i){py, px, ks, grp};
-                else bq[ks] = *(const v4i *)(src + koff[ks]);
+            for (int c = 0; c < NC; ++c) {
+                const int x = x0 + c;
+                int sch = CIN == 32 ? 0 : g;
+                if constexpr (CPX == 4) sch ^= ((x >> 2) & 1) << 1;
+                if constexpr (CPX == 8) sch ^= ((x >> 1) & 3) << 1;
+                xoff[c] = x * PXB + 16 * sch;
+                roff[c] = ((ar + c) & RM) * rowb;
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int n = 0; n < NTN; ++n) {
-                    if constexpr (PX_ABL & 4) asm volatile("" : "+v"(acc[n]) : "v"(wf[ks][n]), "v"(bq[ks]));
-                    else acc[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[ks][n], bq[ks], acc[n], 0, 0, 0);
+                for (int n = 0; n < NTN; ++n) acc[v][n] = cin[n];
+            if constexpr (!POOL) {
+                v4i bq[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if constexpr (CIN == 32) {                     // k-step = taps 2 ks, 2 ks + 1 (lane groups 0-1 / 2-3), 32 channels each
+                        const int t0 = 2 * ks, t1 = 2 * ks + 1 < 9 ? 2 * ks + 1 : 8;   // tap 9 multiplies zero weights
+                        const int o0 = roff[t0 / 3] + xoff[t0 % 3], o1 = roff[t1 / 3] + xoff[t1 % 3];
+                        bq[ks] = *(const v4i *)(smem + (g < 2 ? o0 : o1) + 16 * (g & 1));
+                    } else {
+                        const int tap = ks / KPP, h = ks % KPP;
+                        bq[ks] = *(const v4i *)(smem + roff[tap / 3] + (xoff[tap % 3] ^ (h << 6)));
+                    }
                 }
-            v4i word;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int n = 0; n < NTN; ++n) acc[0][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[ks][n], bq[ks], acc[0][n], 0, 0, 0);
+            } else {
+                // neighbourhood row r feeds conv output (dy, dx) with filter tap (r - dy, c - dx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v4i bq[4][KPP];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int h = 0; h < KPP; ++h) bq[c][h] = *(const v4i *)(smem + roff[r] + (xoff[c] ^ (h << 6)));
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int ty = r - dy;
+                        if (ty < 0 || ty > 2) continue;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int tx = c - dx;
+                                if (tx < 0 || tx > 2) continue;
+#pragma unroll
+                                for (int h = 0; h < KPP; ++h)
+#pragma unroll
+                                    for (int n = 0; n < NTN; ++n)
+                                        acc[2 * dy + dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[(ty * 3 + tx) * KPP + h][n], bq[c][h],
+                                                                                                   acc[2 * dy + dx][n], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+        };
+        auto finish = [&](int grp, const v4i (&acc)[NV][NTN], auto coldc) {
+            constexpr bool COLD = decltype(coldc)::value;
+            int oy, ox;
+            locate(grp, oy, ox);
+            unsigned int word[NTN];
 #pragma unroll
             for (int n = 0; n < NTN; ++n) {
                 float y[4], yc[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float tf = FOLD ? __int_as_float(acc[n][r]) : fmaf((float)acc[n][r], scl, bf[n][r]);
-                    if constexpr (PX_ABL & 2) y[r] = tf;
-                    else y[r] = pvmax(fmaf(tf, s_pos, c_pos), fmaf(tf, s_neg, c_neg));
+                    int m = acc[0][n][r];
+                    if constexpr (POOL) m = max(max(m, acc[1][n][r]), max(acc[2][n][r], acc[3][n][r]));
+                    const float tf = FOLD == 2 ? __int_as_float(m) : FOLD == 1 ? (float)m : fmaf((float)m, scl, bf[n][r]);
+                    y[r] = pvmax(fmaf(tf, s_pos, c_pos), fmaf(tf, s_neg, c_neg));
                     yc[r] = COLD ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
-                    if constexpr (COLD) nsat += (pr < npix && y[r] != yc[r]) ? 1u : 0u;
+                    if constexpr (COLD) nsat += (grp * 16 + li < npw && y[r] != yc[r]) ? 1u : 0u;
                 }
-                if constexpr (!COLD && !(PX_ABL & 2)) {
+                if constexpr (!COLD) {
                     ymx = pvmax3(pvmax3(ymx, y[0], y[1]), y[2], y[3]);
                     ymn = pvmin3(pvmin3(ymn, y[0], y[1]), y[2], y[3]);
                 }
-                if constexpr (PX_ABL & 2) word[n] = (int)(__float_as_uint(yc[0]) ^ __float_as_uint(yc[1]) ^ __float_as_uint(yc[2]) ^ __float_as_uint(yc[3]));
-                else word[n] = (int)ppack4(yc[0], yc[1], yc[2], yc[3]);
+                word[n] = ppack4(yc[0], yc[1], yc[2], yc[3]);
             }
-            if constexpr (PX_ABL & 1) asm volatile("" :: "v"(word));
-            else if (pr < npix) *(v4i *)(outb + ((py * PW + px) * COUT + 16 * g)) = word;
+            // unconditional: the padding lanes rewrite the image's last pixel with the same bytes, and the number of stores a
+            // wave has in flight stays a function of its group count (the counted wait above)
+            int8_t *dst = outb + ((oy * (Wo + 2) + ox) * COUT + 4 * NTN * g);
+            if constexpr (NTN == 4) *(v4i *)dst = (v4i){(int)word[0], (int)word[1], (int)word[2], (int)word[3]};
+            else *(uint2 *)dst = make_uint2(word[0], word[NTN - 1]);
         };
+        nstores = 0;                                               // stores issued after the last prefetched piece
         {
-            int grp = wave;
+            v4i acc[NV][NTN];
 #pragma unroll 1
-            for (; grp + NW < ngrp; grp += 2 * NW) {               // two groups per trip: one's epilogue under the other's MFMAs
-                body(grp, std::false_type{});
-                body(grp + NW, std::false_type{});
+            for (int grp = ch.g0 + ps; grp < ch.g1; grp += NPS) {
+                issue(grp, acc);
+                prefetch(a.ppg);
+                finish(grp, acc, std::false_type{});
+                ++nstores;
             }
-            if (grp < ngrp) body(grp, std::false_type{});
+            prefetch(1 << 30);
         }
-        if (__builtin_amdgcn_ballot_w64(ymx > QHI || ymn < QLO) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(ymx > QHI || ymn < QLO) != 0ull) {   // cold: the rows are still in the ring
+            v4i accC[NV][NTN];
 #pragma unroll 1
-            for (int grp = wave; grp < ngrp; grp += NW) body(grp, std::true_type{});
+            for (int grp = ch.g0 + ps; grp < ch.g1; grp += NPS) {
+                issue(grp, accC);
+                finish(grp, accC, std::true_type{});
+            }
+            nstores = -1;
         }
         stamp();
         if (!more) break;
+        gg = gnext;
+        ch = nx;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp();
     if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
 }
 
-// A fragments of conv3_1 for convpx32_kernel (20 KiB): fragment (ks * 4 + n), lane (i = l & 15, g = l >> 4), 16 bytes:
-// row i = output channel 16 (i >> 2) + 4 n + (i & 3); k = tap 2 ks + (g >> 1), input channels 16 (g & 1) .. + 15
-void y355_pack_px32(const int8_t *q_w /*[64][32][3][3]*/, int8_t *dst /*20480*/) {
-    memset(dst, 0, KS * NTN * 1024);
-    for (int ks = 0; ks < KS; ++ks)
-        for (int n = 0; n < NTN; ++n)
-            for (int l = 0; l < 64; ++l) {
-                const int i = l & 15, g = l >> 4, tap = 2 * ks + (g >> 1);
-                const int ch = 16 * (i >> 2) + 4 * n + (i & 3);
-                if (tap > 8) continue;
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int ci = 16 * (g & 1) + kk;
-                    dst[(ks * NTN + n) * 1024 + l * 16 + kk] = q_w[((size_t)ch * CIN + ci) * 9 + tap];
+// ------------------------------------------------------------------------------------------
+namespace {
+// A fragments: fragment ((cb * KS + ks) * NTN + n), lane (i = l & 15, g = l >> 4), 16 bytes:
+//   row i = output channel cb * CPB + 4 NTN (i >> 2) + 4 n + (i & 3)
+//   CIN = 32:  k = tap 2 ks + (g >> 1), input channels 16 (g & 1) .. + 15
+//   CIN >= 64: k = tap ks / KPP, input channels 64 (ks % KPP) + 16 g .. + 15
+template <int CIN, int NTN, int NCB, bool POOL>
+void px_pack(const int8_t *q_w, int cout, int8_t *dst) {
+    using G = PxGeom<CIN, NTN, NCB, POOL>;
+    memset(dst, 0, (size_t)G::NFRAG * 1024);
+    for (int cb = 0; cb < NCB; ++cb)
+        for (int ks = 0; ks < G::KS; ++ks)
+            for (int n = 0; n < NTN; ++n)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, g = l >> 4;
+                    const int ch = cb * G::CPB + 4 * NTN * (i >> 2) + 4 * n + (i & 3);
+                    const int tap = CIN == 32 ? 2 * ks + (g >> 1) : ks / G::KPP;
+                    const int c0 = CIN == 32 ? 16 * (g & 1) : 64 * (ks % G::KPP) + 16 * g;
+                    if (tap > 8 || ch >= cout) continue;
+                    for (int kk = 0; kk < 16; ++kk)
+                        dst[(((size_t)cb * G::KS + ks) * NTN + n) * 1024 + l * 16 + kk] = q_w[((size_t)ch * CIN + c0 + kk) * 9 + tap];
                 }
-            }
 }
 
-namespace {
-#ifndef PX_NW_
-#define PX_NW_ 8
-#endif
-constexpr int PX_TH = 13, PX_NW = PX_NW_;
-size_t px_slab_bytes(int W) { return ((size_t)(PX_TH + 2) * (W + 2) * PXB + 1023) / 1024 * 1024; }
-template <bool FOLD>
-void px_launch(const ConvParams &p_in, hipStream_t s) {
-    ConvParams p = p_in;
-    p.tiles_y = (p.H + PX_TH - 1) / PX_TH;
-    p.ev_start = p.ev_stop = nullptr;
-    const int total = p.tiles_y * p.B;
-    const int slab = (int)px_slab_bytes(p.W);
-    int grid = 256;                                         // one 8-wave workgroup per CU; at B = 64, 416 x 416: two tiles each
-    if (grid > total) grid = total;
-    Y355_LAUNCH((convpx32_kernel<PX_TH, PX_NW, FOLD>), dim3(grid), dim3(PX_NW * 64), 2 * (size_t)slab, s, p_in.ev_start, p_in.ev_stop, p, total, slab);
-}
+template <int CIN, int NTN, int NCB, bool POOL, int NW>
+struct PxInst {
+    using G = PxGeom<CIN, NTN, NCB, POOL>;
+    static constexpr int NPS = NW / NCB;
+    // rounds: groups per pixel stream per chunk
+    static PxArgs args(const ConvParams &p, int rounds) {
+        PxArgs a;
+        const int Ho = POOL ? p.H / 2 : p.H, Wo = POOL ? p.W / 2 : p.W;
+        a.ngi = (Ho * Wo + 15) / 16;
+        a.total_groups = a.ngi * p.B;
+        a.cg = rounds * NPS;
+        a.pwl = (p.W + 2 + G::PPP - 1) / G::PPP * G::PPP;
+        // two consecutive chunks of an image are in the ring together: MUL * (output rows they touch) + 2 (+ 1 pooled) rows
+        const int rows2 = (2 * 16 * a.cg + Wo - 1) / Wo + 1;
+        const int need = (POOL ? 2 : 1) * rows2 + (POOL ? 2 : 2);
+        a.logr = 2;
+        while ((1 << a.logr) < need) ++a.logr;
+        // a chunk adds about MUL * 16 cg / Wo rows = that many * pwl / PPP pieces, dealt over NW waves and `rounds` groups each
+        const int newrows = (POOL ? 2 : 1) * ((16 * a.cg + Wo - 1) / Wo + 1);
+        const int per_wave = (newrows * (a.pwl / G::PPP) + NW - 1) / NW;
+        a.ppg = (per_wave + rounds - 1) / rounds;
+        return a;
+    }
+    static size_t lds_bytes(const PxArgs &a) { return ((size_t)a.pwl * G::PXB) << a.logr; }
+    template <int FOLD>
+    static void launch_(const ConvParams &p_in, const PxArgs &a, hipStream_t s) {
+        ConvParams p = p_in;
+        p.ev_start = p.ev_stop = nullptr;
+        int grid = 256;                                            // one NW-wave workgroup per CU
+        if (grid > a.total_groups) grid = a.total_groups;
+        Y355_LAUNCH((convpx_kernel<CIN, NTN, NCB, POOL, NW, FOLD>), dim3(grid), dim3(NW * 64), lds_bytes(a), s, p_in.ev_start, p_in.ev_stop, p, a);
+    }
+    static bool launch(const ConvParams &p, int rounds, hipStream_t s) {
+        if (p.cstride != G::COUT || !p.out_halo || p.W < 16 || (POOL && ((p.H | p.W) & 1))) return false;
+        if ((long long)p.B * (p.H + 2) * (p.W + 2) * G::PXB >= (1ll << 31)) return false;     // 32-bit row arithmetic
+        const PxArgs a = args(p, rounds);
+        if (lds_bytes(a) > 160 * 1024) return false;
+        if (p.rq.shl == 0 && p.rq.tmax_log2 <= 22 && p.rq.sh <= 22 && p.rq.sh - p.rq.lk >= -8) launch_<2>(p, a, s);
+        else if (p.rq.shl == 0) launch_<1>(p, a, s);
+        else launch_<0>(p, a, s);
+        return true;
+    }
+    static int prepare() {
+        int e = (int)hipFuncSetAttribute((const void *)convpx_kernel<CIN, NTN, NCB, POOL, NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (!e) e = (int)hipFuncSetAttribute((const void *)convpx_kernel<CIN, NTN, NCB, POOL, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (!e) e = (int)hipFuncSetAttribute((const void *)convpx_kernel<CIN, NTN, NCB, POOL, NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }
+};
+//                   CIN NTN NCB POOL  NW
+using PX_C3_1 = PxInst<32, 4, 1, false, 8>;       // 32 -> 64
+using PX_C3_2 = PxInst<64, 2, 2, true, 8>;        // 64 -> 64, pooled: two 32-channel blocks x four window streams
+using PX_C4_1 = PxInst<64, 4, 2, false, 8>;       // 64 -> 128
+using PX_C4_2 = PxInst<128, 2, 4, true, 8>;       // 128 -> 128, pooled: four 32-channel blocks x two window streams
 }  // namespace
 
 int y355_prepare_conv_px(void) {
-    int e = (int)hipFuncSetAttribute((const void *)convpx32_kernel<PX_TH, PX_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (!e) e = (int)hipFuncSetAttribute((const void *)convpx32_kernel<PX_TH, PX_NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int e = PX_C3_1::prepare();
+    if (!e) e = PX_C3_2::prepare();
+    if (!e) e = PX_C4_1::prepare();
+    if (!e) e = PX_C4_2::prepare();
     return e;
 }
 
-// conv3_1 only; false = not available for this launch (statistics mode, head-room guard, 64-bit epilogue, t beyond fp32's
-// exact range, a map too wide for two slabs in LDS): the caller falls back to conv3x3_v2.hip / conv3x3.hip.
-// `p.w` must be the y355_pack_px32 layout.
+size_t y355_px_packed_bytes(int kid) {
+    switch (kid) {
+    case Y355_K_CONV3_1: return (size_t)PX_C3_1::G::NFRAG * 1024;
+    case Y355_K_CONV3_2: return (size_t)PX_C3_2::G::NFRAG * 1024;
+    case Y355_K_CONV4_1: return (size_t)PX_C4_1::G::NFRAG * 1024;
+    case Y355_K_CONV4_2: return (size_t)PX_C4_2::G::NFRAG * 1024;
+    default: return 0;
+    }
+}
+
+// q_w [cout][cin][3][3] of layer `kid` -> the fragment order convpx_kernel streams; false: the layer has no such kernel
+bool y355_pack_px(int kid, const int8_t *q_w, int cout, int cin, int8_t *dst) {
+    switch (kid) {
+    case Y355_K_CONV3_1: if (cin != 32 || cout != 64) return false; px_pack<32, 4, 1, false>(q_w, cout, dst); return true;
+    case Y355_K_CONV3_2: if (cin != 64 || cout != 64) return false; px_pack<64, 2, 2, true>(q_w, cout, dst); return true;
+    case Y355_K_CONV4_1: if (cin != 64 || cout != 128) return false; px_pack<64, 4, 2, false>(q_w, cout, dst); return true;
+    case Y355_K_CONV4_2: if (cin != 128 || cout != 128) return false; px_pack<128, 2, 4, true>(q_w, cout, dst); return true;
+    default: return false;
+    }
+}
+
+// false = not available for this launch (statistics mode, head-room guard, 64-bit epilogue, t beyond fp32's exact range, a
+// map too wide for two slabs in LDS): the caller falls back to the ring / v2 / generic kernels.  `p.w` = y355_pack_px layout.
 bool y355_launch_conv_px(int kid, const ConvParams &p, hipStream_t s) {
-    if (kid != Y355_K_CONV3_1 || (p.mode & 0xff) != 0 || p.rq.wide || p.guard || p.rq.tmax_log2 > 24) return false;
-    if (p.cstride != COUT || !p.out_halo || 2 * px_slab_bytes(p.W) > 160 * 1024 || p.W < 8) return false;
-    const bool fold = p.rq.shl == 0 && p.rq.tmax_log2 <= 22 && p.rq.sh <= 22 && p.rq.sh - p.rq.lk >= -8;
-    if (fold) px_launch<true>(p, s);
-    else px_launch<false>(p, s);
-    return true;
+    if ((p.mode & 0xff) != 0 || p.rq.wide || p.guard || p.rq.tmax_log2 > 24) return false;
+    switch (kid) {
+    case Y355_K_CONV3_1: return PX_C3_1::launch(p, PX_R31, s);
+    case Y355_K_CONV3_2: return PX_C3_2::launch(p, 2, s);
+    case Y355_K_CONV4_1: return PX_C4_1::launch(p, PX_R41, s);
+    case Y355_K_CONV4_2: return PX_C4_2::launch(p, 2, s);
+    default: return false;
+    }
 }

@@ -53,7 +53,7 @@ struct Layer {
     bool loaded = false, bias_dirty = true;
     std::vector<int32_t> q_b;
     int8_t *w_dev = nullptr;
-    int8_t *wpx_dev = nullptr;      // conv3_1: the same weights in convpx.hip's fragment order
+    int8_t *wpx_dev = nullptr;      // conv3_1 .. conv4_2: the same weights in convpx.hip's fragment order
     long long wabs = 0;             // max over output channels of sum |q_w| (0: not loaded): the tight bound of |acc| / 127
     int *bias_dev = nullptr;
     long long *bias_w_dev = nullptr;
@@ -386,13 +386,14 @@ extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const
         }
         L.wabs = best;
     }
-    if (L.kid == Y355_K_CONV3_1 && cin == 32 && cout == 64) {
-        std::vector<int8_t> px(20480);
-        y355_pack_px32(q_w, px.data());
-        if (!L.wpx_dev) {
-            if (int rc = dmalloc(h, (void **)&L.wpx_dev, px.size(), false)) return rc;
+    if (const size_t pxb = idx > 0 ? y355_px_packed_bytes(L.kid) : 0) {
+        std::vector<int8_t> px(pxb);
+        if (y355_pack_px(L.kid, q_w, cout, cin, px.data())) {
+            if (!L.wpx_dev) {
+                if (int rc = dmalloc(h, (void **)&L.wpx_dev, px.size(), false)) return rc;
+            }
+            HIPCHK(hipMemcpy(L.wpx_dev, px.data(), px.size(), hipMemcpyHostToDevice));
         }
-        HIPCHK(hipMemcpy(L.wpx_dev, px.data(), px.size(), hipMemcpyHostToDevice));
     }
     L.q_b.assign(q_b, q_b + cout);
     L.e_w = e_w;
@@ -519,7 +520,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         constexpr bool no_v2 = false;
         constexpr int no_v2_mask = 0, no_ring_mask = 0;
 #endif
-        if (!no_v2 && L.wpx_dev) {                            // conv3_1: weights in registers, pixels as the B operand (convpx.hip)
+        if (!no_v2 && L.wpx_dev) {                            // conv3_1 .. conv4_2: weights in registers, pixels as the B operand (convpx.hip)
             ConvParams q = p;
             q.w = L.wpx_dev;
             if (y355_launch_conv_px(L.kid, q, h->stream)) {

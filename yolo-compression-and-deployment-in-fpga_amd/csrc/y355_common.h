@@ -216,10 +216,11 @@ enum {
 bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_v2(void);
 bool y355_conv_v2_preferred(int kid);     // true: this layer's production kernel is the resident-weight one of conv3x3_v2.hip
-// conv3_1 with the weights in registers and the pixels as the MFMA's B operand (convpx.hip); p.w = y355_pack_px32 layout
+// conv3_1 .. conv4_2 with the weights in registers and the pixels as the MFMA's B operand (convpx.hip); p.w = y355_pack_px layout
 bool y355_launch_conv_px(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_px(void);
-void y355_pack_px32(const int8_t *q_w /*[64][32][3][3]*/, int8_t *dst /*20480*/);
+size_t y355_px_packed_bytes(int kid);           // 0: the layer has no such kernel
+bool y355_pack_px(int kid, const int8_t *q_w, int cout, int cin, int8_t *dst);
 // deep-prefetch ring kernels (conv3x3_ring.hip), layers with >= 64 input channels
 bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_ring(void);
