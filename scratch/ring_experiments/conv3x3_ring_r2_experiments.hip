@@ -19,14 +19,26 @@
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #ifndef Y355_DIAG
-#define Y355_DIAG 0                 // 1 / 2: s_memtime stamps per workgroup / per wave (y355_debug_stamps); never in the production build
+#define Y355_DIAG 0
+#endif
+#ifndef Y355_RING_AORDER
+#define Y355_RING_AORDER 0       // 0: compiler-placed LDS reads/waits; 1: hand-placed step (volatile asm)
+#endif
+#ifndef Y355_ABL
+#define Y355_ABL 0               // timing ablations (WRONG RESULTS): 1 no A reads, 2 no B reads, 4 no refill DMAs, 8 no barriers
+#endif
+#ifndef Y355_RING_YSWZ
+#define Y355_RING_YSWZ 0         // 1: row-dependent chunk swizzle for the pooled (window-ordered) tiles: measured, no gain (profiles/r02_notes.md)
 #endif
 #ifndef Y355_RING_PF
-#define Y355_RING_PF 5              // k-steps of weights in flight (ring of PF + 2 slots); 4..7 measured equal (profiles/r02_notes.md)
+#define Y355_RING_PF 5            // k-steps of weights in flight (ring of PF + 2 slots)
 #endif
-// The timing ablations, the hand-placed (volatile asm) k-step, the row-dependent chunk swizzle, the refill-position and
-// half-tile variants of round 2 live in scratch/ring_experiments/conv3x3_ring_r2_experiments.hip; none of them paid
-// (profiles/r02_notes.md) and the production kernel keeps ONE body.
+#ifndef Y355_RING_DMA_AT2
+#define Y355_RING_DMA_AT2 -2     // >= 0: the younger half of the workgroup (waves NW/2..) refills after this m-tile instead
+#endif
+#ifndef Y355_RING_DMA_AT
+#define Y355_RING_DMA_AT -1      // m-tile after whose MFMAs a step's refill DMAs go out (-1: right after the barrier)
+#endif
 
 __device__ __forceinline__ void rglds16(const void *g, void *lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -54,6 +66,53 @@ __device__ __forceinline__ void rwait_vmcnt_dyn(int n) {
 #undef RW_CASE
 }
 
+// LDS reads and waits the compiler does not see (Y355_RING_AORDER): the reads carry no latency
+// information for it, the waits are tied to the registers they publish so no MFMA moves above them
+__device__ __forceinline__ void rds128(v4i &d, unsigned addr) {
+#if defined(Y355_ABL) && (Y355_ABL & 32)
+    return;
+#endif
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void rds128_o(v4i &d, unsigned addr) {
+#if defined(Y355_ABL) && (Y355_ABL & 32)
+    return;
+#endif
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+#ifndef Y355_RING_BUILTIN_MFMA
+#define Y355_RING_BUILTIN_MFMA 0
+#endif
+#ifndef Y355_RING_SAFEWAIT
+#define Y355_RING_SAFEWAIT 0
+#endif
+__device__ __forceinline__ void rwait_lgkm(int n) {
+    if (Y355_RING_SAFEWAIT) n = 0;
+#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
+        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
+    }
+#undef RL_CASE
+}
+__device__ __forceinline__ void rwait_lgkm2(int n, v4i &a, v4i &b) {
+#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(a), "+v"(b) :: "memory"); break;
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
+        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
+    }
+#undef RL_CASE
+}
+__device__ __forceinline__ void rwait_lgkm4(int n, v4i &a, v4i &b, v4i &c, v4i &d) {
+#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); break;
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
+        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
+    }
+#undef RL_CASE
+}
+
 // slab pieces issued in steps lo..hi (step u issues one when 1 <= (u mod 9) <= ppw); negative steps
 // are the previous tile's (none before the first tile: its slab went out whole in the prologue)
 constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
@@ -67,7 +126,7 @@ constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
 }
 
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ>
-__global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
     constexpr int NW = WM * WN;
     constexpr int NTHR = NW * 64;
     constexpr int NCH = CIN / 64, SPC = 9, KS = NCH * SPC;
@@ -119,7 +178,13 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     constexpr int PSTEP = NW * 16 / PWL;
     const int pix0 = wave * 16 + (lane >> 2);
     const int ppy0 = pix0 / PWL, ppx0 = min(pix0 % PWL, PW - 1);     // pitch padding re-reads column PW-1
-    const int pwithin = ((lane & 3) ^ ((lane >> 3) & 3)) << 4;
+    // Pooled (2x2-window ordered) tiles: chunk ^ (((x >> 1) + 2 y) & 3).  With the x-only swizzle an A-fragment read of a
+    // window-ordered m-tile costs 8.56 LDS cycles (4 = conflict-free; scratch/bank_sim_ring.py reproduces the measured
+    // 39 % conflict share); adding 2 y brings it to 4.84.  Rows one apart then differ in address bit 5: the three taps of
+    // the middle filter row read at (base ^ 32), everything else is unchanged.
+    constexpr bool YSWZ = POOL && Y355_RING_YSWZ;
+    static_assert(!YSWZ || (PWL % 16 == 0 && PSTEP % 2 == 0), "a 16-pixel DMA piece stays inside one patch row; pieces step an even number of rows");
+    const int pwithin = ((lane & 3) ^ ((((lane >> 3) & 3) + (YSWZ ? 2 * ppy0 : 0)) & 3)) << 4;
     auto decode = [&](int tile, int &b, int &y0, int &x0, int &nb) {
         nb = tile % p.nblk;
         tile /= p.nblk;
@@ -163,6 +228,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     };
     stamp();
     stamp();
+    // two workgroups per CU (half-size tiles): the second half of the grid starts late, so that one workgroup's prologue and
+    // epilogue run under the other's k-loop instead of both doing the same phase at the same time
+    if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+        for (int i = 0; i < p.stagger; i += 16) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles per trip
+    }
     int b, y0, x0, nb;
     decode(tile, b, y0, x0, nb);
     int sl = 0;                                                // slab slot of the current chunk
@@ -192,11 +262,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
-            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ (((ox + dx) >> 1) & 3)) << 4);
+            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ ((((ox + dx) >> 1) + (YSWZ ? 2 * oy : 0)) & 3)) << 4);
     }
     const Requant rq = p.rq;
     unsigned int nsat = 0;
     bool first = true;
+#if defined(Y355_RING_PRIO)
+    if (Y355_RING_PRIO == 1 ? wave >= NW / 2 : wave < NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
     for (;;) {
         int ntile = tile + gridDim.x;
@@ -275,50 +348,156 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                     }
                     if (fine) stamp();
                 }
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(Y355_ABL & 8)) __builtin_amdgcn_s_barrier();
                 if (Y355_DIAG && first && c == (NCH > 1 ? 1 : 0)) stamp();
                 // ---- refill: one slab piece (t = 1..PPW) into the slot that died two barriers ago,
                 // W(s+1+PF) into the ring slot read in step s-2
                 const int wqs = wq;
-                {
+                auto refill = [&]() {
+                    if constexpr (Y355_ABL & 4) return;
                     if (t >= 1 && t <= PPW) {
                         issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
                     }
                     const int ksn = s_idx + 1 + PF;
                     const bool nxt = ksn >= KS;
                     issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wqs + PF + 1));
-                }
+                };
+                if constexpr (Y355_RING_DMA_AT < 0 && !(Y355_ABL & 4)) refill();
                 const int ko = (t / 3) * PWL * 64;
                 const int acol = t % 3;
+                constexpr int dummy3 = 0;
+                (void)dummy3;
                 const int cur = ROLL ? (t & 1) : (s_idx & 1);     // rolled: every chunk starts with its B fragments in bfb[0]
                 v4i af[MT];
                 wq = wrap(wq + 1);
-                {
-                    if (t == 0) {
-                        af[0] = *(const v4i *)(smem + abase[0][acol] + soff + ko);
-                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + abase[1][acol] + soff + ko);
+                if constexpr (Y355_RING_AORDER == 0) {
+                    const int yx = (YSWZ && t / 3 == 1) ? 32 : 0;              // middle filter row of a y-swizzled slab
+                    const int yx2 = (YSWZ && (t + 1) / 3 == 1) ? 32 : 0;
+                    if (t == 0 && (!(Y355_ABL & 1) || c == 0)) {
+                        af[0] = *(const v4i *)(smem + (abase[0][acol] ^ yx) + soff + ko);
+                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + (abase[1][acol] ^ yx) + soff + ko);
                     } else {
                         af[0] = afp[0];
                         if constexpr (MT > 1) af[1] = afp[1];
                     }
-                    if (s_idx + 1 < KS) {                            // B fragments of step s+1, under this step's MFMAs
+                    if constexpr (Y355_ABL & 1) {
+#pragma unroll
+                        for (int m = 2; m < MT; ++m) af[m] = af[m & 1];
+                        afp[0] = af[0];
+                        if constexpr (MT > 1) afp[1] = af[1];
+                    }
+                    if ((Y355_ABL & 2) && s_idx + 1 < KS) {
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = bfb[cur][tt];
+                    }
+                    if (!(Y355_ABL & 2) && s_idx + 1 < KS) {     // B fragments of step s+1, under this step's MFMAs
                         const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
-                        if (m == MT - 1 && t + 1 < SPC) {            // next step's first A fragments (same slab)
+                        if (!(Y355_ABL & 1) && m + 2 < MT) af[m + 2] = *(const v4i *)(smem + (abase[m + 2][acol] ^ yx) + soff + ko);
+                        if (!(Y355_ABL & 1) && m == MT - 1 && t + 1 < SPC) {   // next step's first A fragments (same slab)
                             const int ko2 = ((t + 1) / 3) * PWL * 64;
                             const int acol2 = (t + 1) % 3;
-                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
-                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                            afp[0] = *(const v4i *)(smem + (abase[0][acol2] ^ yx2) + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + (abase[1][acol2] ^ yx2) + soff + ko2);
                         }
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
                             acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                        if constexpr (Y355_RING_DMA_AT >= 0) {
+                            if constexpr (Y355_RING_DMA_AT2 >= 0) {
+                                const int at = wave >= NW / 2 ? Y355_RING_DMA_AT2 : Y355_RING_DMA_AT;
+                                if (m == 0 || m == Y355_RING_DMA_AT2 || m == Y355_RING_DMA_AT) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (m == (at < MT ? at : MT - 1)) refill();
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            } else if (m == (Y355_RING_DMA_AT < MT ? Y355_RING_DMA_AT : MT - 1)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                refill();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
                     }
+                } else {
+                    // Hand-placed step (all of it volatile asm, so it executes in the order written).  Measured
+                    // with scratch/ubench/mfma_clean.hip on this part: a ds_read_b128 issued beside MFMAs costs
+                    // the SIMD ~9 cycles when the reads are spread one per MFMA and 17-28 when they go out in a
+                    // bunch (24 MFMAs + 10 reads + barrier: 917-932 cycles spread, 1082 bunched, 804 without
+                    // reads), and hipcc waits lgkmcnt(0) before the first MFMA that uses any of them.  Here one
+                    // read follows each of the step's first MFMAs -- this step's later A fragments, then B(s+1),
+                    // then the next step's first two A fragments -- and every m-tile waits (counted, LDS returns
+                    // in order) only for its own fragment.
+                    static_assert(Y355_RING_AORDER == 0 || MT == 6 || MT == 2, "hand-placed step: 6 or 2 m-tiles");
+                    static_assert(Y355_RING_AORDER == 0 || !YSWZ, "the hand-placed step does not implement the row swizzle");
+                    const bool has_b = s_idx + 1 < KS;
+                    const bool has_a = t + 1 < SPC;
+                    unsigned abs_off = (unsigned)(soff + ko);
+                    asm volatile("" : "+s"(abs_off));             // opaque: keeps the per-read address adds next to the reads
+                    unsigned off2 = (unsigned)(soff + ((t + 1) / 3) * PWL * 64);
+                    asm volatile("" : "+s"(off2));
+                    const int acol2 = (t + 1) % 3;
+                    const unsigned wbn = (unsigned)(OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024) + lane * 16;
+                    // read queue of the step: af[G0..MT-1], then B(s+1)[0..3], then afp[0..G0-1]; entry k goes out
+                    // right after the step's k-th MFMA.  Everything below is constant after unrolling.
+                    constexpr int G0 = MT < 2 ? MT : 2;
+                    constexpr int NA = MT - G0;
+                    const int nbq = has_b ? NT : 0;
+                    const int Q = NA + nbq + (has_a ? G0 : 0);
+                    const int pre = (t == 0) ? G0 : 0;          // new slab: af[0..G0-1] were not prefetched
+                    if (t == 0) {
+#pragma unroll
+                        for (int m = 0; m < G0; ++m) rds128(af[m], (unsigned)abase[m][acol] + abs_off);
+                    } else {
+                        af[0] = afp[0];
+                        if constexpr (MT > 1) af[1] = afp[1];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        if (t == 0 || m >= G0) {
+                            const int done = NT * m < Q ? NT * m : Q;          // queue entries issued before this m-tile
+                            const int posm = (t == 0) ? m : m - G0;            // issue index of af[m]
+                            rwait_lgkm(pre + done - posm - 1);                // no register tie: a tie makes hipcc copy the
+                                                                              // fragment BEFORE the wait (stale data)
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) {
+#if Y355_RING_BUILTIN_MFMA
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (!(Y355_ABL & 16)) acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                            else asm volatile("" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bfb[cur][tt]));
+                            __builtin_amdgcn_sched_barrier(0);
+#else
+                            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bfb[cur][tt]));
+#endif
+                            const int k = m * NT + tt;
+                            if (k < Q) {
+                                if (k < NA) {
+                                    rds128(af[G0 + (k < NA ? k : 0)], (unsigned)abase[G0 + (k < NA ? k : 0)][acol] + abs_off);
+                                } else if (has_b && k - NA < NT) {
+                                    const int k2 = k - NA;
+                                    if (k2 == 0) rds128_o<0>(bfb[cur ^ 1][0], wbn);
+                                    else if (k2 == 1) rds128_o<1024>(bfb[cur ^ 1][1], wbn);
+                                    else if (k2 == 2) rds128_o<2048>(bfb[cur ^ 1][2], wbn);
+                                    else rds128_o<3072>(bfb[cur ^ 1][3], wbn);
+                                } else {
+                                    const int k3 = (k - NA - nbq) & (G0 - 1);
+                                    rds128(afp[k3], (unsigned)abase[k3][acol2] + off2);
+                                }
+                            }
+                        }
+                        if constexpr (Y355_RING_DMA_AT >= 0) {
+                            if constexpr (Y355_RING_DMA_AT2 >= 0) {
+                                const int at = wave >= NW / 2 ? Y355_RING_DMA_AT2 : Y355_RING_DMA_AT;
+                                if (m == (at < MT ? at : MT - 1)) refill();
+                            } else if (m == (Y355_RING_DMA_AT < MT ? Y355_RING_DMA_AT : MT - 1)) refill();
+                        }
+                    }
+                    // B(s+1) and the next step's first A fragments are in registers before the barrier
+                    if (has_b || has_a) rwait_lgkm(0);
                 }
             }
             // 9 steps: the last one (cur = 0) read the next chunk's first fragments into bfb[1]
@@ -482,12 +661,13 @@ struct ConvInstR {
         return (int)hipFuncSetAttribute((const void *)conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
-    static bool launch(const ConvParams &p_in, hipStream_t s) {
+    static bool launch(const ConvParams &p_in, hipStream_t s, int grid_max = 256, int stagger = 0) {
         ConvParams p = p_in;
         p.tiles_x = (p.W + TW - 1) / TW;
         p.tiles_y = (p.H + TH - 1) / TH;
+        p.stagger = stagger;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
-        int grid = 256;                                        // one persistent workgroup per CU
+        int grid = grid_max;                                   // one persistent workgroup per CU (two for the half tiles)
         if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;   // fewer, each walking more tiles (throughput mode)
         if (grid > total) grid = total;
         if (p.ev_start && p.ev_stop) {
@@ -511,6 +691,9 @@ struct RSet {
     using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
     using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
     using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
+    // experiment (Y355_RING_HALF): half-size tiles, two 4-wave workgroups per CU, staggered start
+    using C67H = ConvInstR<256, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
+    using C5H = ConvInstR<128, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
     static int prepare() {
         int e = C3_2::prepare();
         if (!e) e = C4_1::prepare();
@@ -518,6 +701,10 @@ struct RSet {
         if (!e) e = C5::prepare();
         if (!e) e = C67::prepare();
         if (!e) e = PRED::prepare();
+#ifdef Y355_EXPERIMENTS
+        if (!e) e = C67H::prepare();
+        if (!e) e = C5H::prepare();
+#endif
         return e;
     }
     static bool launch(int kid, const ConvParams &p, hipStream_t s) {
@@ -525,8 +712,20 @@ struct RSet {
         case Y355_K_CONV3_2: return C3_2::launch(p, s);
         case Y355_K_CONV4_1: return C4_1::launch(p, s);
         case Y355_K_CONV4_2: return C4_2::launch(p, s);
-        case Y355_K_CONV5: return C5::launch(p, s);
-        case Y355_K_CONV67: return C67::launch(p, s);
+        case Y355_K_CONV5: {
+#ifdef Y355_EXPERIMENTS
+            static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
+            if (half & 2) return C5H::launch(p, s, 512, half >> 8);
+#endif
+            return C5::launch(p, s);
+        }
+        case Y355_K_CONV67: {
+#ifdef Y355_EXPERIMENTS
+            static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
+            if (half & 1) return C67H::launch(p, s, 512, half >> 8);
+#endif
+            return C67::launch(p, s);
+        }
         case Y355_K_PRED: return PRED::launch(p, s);
         default: return false;
         }

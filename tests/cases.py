@@ -9,6 +9,8 @@ E2E = {
     "find": (dict(seed=2), synth.ANCHOR_SIZE_MASK, "noise"),
     "gap": (dict(seed=3, bias_gain=40.0, weight_gain=3.0), synth.ANCHOR_SIZE, "noise"),
     "batch": (dict(seed=2), synth.ANCHOR_SIZE_MASK, "noise"),
+    # round 3: weights that quantize to the trained model's exponents (c_embedding/yolo_forward.c:32-33), FPGA size 240 x 320
+    "ctable": (dict(seed=4, ctable=True, pred_gain=3.0, obj_bias=-1.0), synth.ANCHOR_SIZE_MASK, "blocks"),
 }
 
 # fp32 model families: (tag, arch, [H, W], classes, weight seed, image seeds, pattern,

@@ -18,7 +18,7 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     g = {}
-    for f in ("prep_layers.npz", "e2e.npz", "guard.npz"):
+    for f in ("prep_layers.npz", "e2e.npz", "guard.npz", "r3.npz"):
         with np.load(os.path.join(ROOT, "tests", "golden", f)) as z:
             for k in z.files:
                 g[k] = z[k]

@@ -133,5 +133,11 @@ def test_conv2d_fuse_operator_matches_reference_layer(golden):
         assert float(y.abs().max()) == float(golden["layer/%d/ymax" % n][0])
         q = torch.round(y.cpu() * (2.0 ** sa_out)).numpy().astype(np.int32)
         assert np.array_equal(q, golden["layer/%d/q_out" % n])
-    with pytest.raises(NotImplementedError):
-        m(torch.rand(1, cin, 4, 4).cuda() * 0.123)           # not fake-quantized -> refused, no fallback
+    # operands that are not fake-quantized (utils/modules.py:28-29 accepts any fp32 tensor): the same layer on the bf16 MFMA
+    # (y355_conv2d_bf16), within the bf16 tolerance of the fp32 reference -- still on the GPU, no CPU / PyTorch fallback
+    xr = (torch.rand(1, cin, 6, 7) * 0.123 - 0.06).cuda()
+    yr = m(xr)
+    with torch.no_grad():
+        want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xr.cpu(), m.convs[0].weight.cpu(), m.convs[0].bias.cpu(), padding=1), 0.125)
+    assert yr.is_cuda and yr.shape == want.shape
+    assert float((yr.cpu() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()) + 0.03

@@ -19,6 +19,12 @@ from cases import E2E
 BOX_TOL, SCORE_TOL = 2e-5, 2e-6
 
 
+def _same_list(msg):
+    """dets_match verdicts that mean "the same detections in the same order": identical lists, or identical boxes / classes
+    with every score inside the tolerance (the strict pass also bounds every box coordinate by BOX_TOL; a coordinate a hair
+    past it that still rounds to the same grid cell reports "same boxes").  What is NOT accepted here is the tie-group
+    fallback: oracle and engine order ties identically by definition."""
+    return msg in ("exact", "empty") or msg.startswith("same boxes")
 def _rand_i8(seed, shape):
     return (synth.uniform_u8(seed, shape).astype(np.int32) - 128).clip(-127, 127)
 
@@ -120,10 +126,10 @@ def test_end_to_end(golden, tag):
         # against the oracle with the same (score desc, index asc) tie order: strict
         ob, os_, oc, _ = O.postprocess(r["box"][0], r["cls_scores"][0], conf, 0.5, C)
         ok, msg = dets_match((ob, os_, oc), dets[0], BOX_TOL, SCORE_TOL, all_scores=r["cls_scores"][0].max(1))
-        assert ok, (tag, conf, "vs oracle", msg)
+        # the oracle orders ties like the engine (score desc, anchor index asc): identical lists, no tie tolerance (VERDICT r2
+        # item 7); tie tolerance is kept for the reference's goldens only (its argsort()[::-1] is unstable)
+        assert ok and _same_list(msg), (tag, conf, "vs oracle", msg)
         modes.append(msg.split(":")[0])
-        # the oracle orders ties like the engine (score desc, anchor index asc): on the tie-free fixture the lists are identical
-        assert tag != "diverse" or msg == "exact", (tag, conf, msg)
     # frozen trackers, whole batch at once == the reference run one image at a time (G7)
     eng.set_thresholds(confs[0], 0.5)
     xs = np.concatenate([synth.make_images(s, 1, H, W, pattern) for s in img_seeds])
@@ -137,7 +143,7 @@ def test_end_to_end(golden, tag):
             ok, msg = dets_match(ref, dets[si], BOX_TOL, SCORE_TOL, all_scores=rb["cls_scores"][si].max(1))
             assert ok, (tag, si, msg)
         ok, msg = dets_match(rb["dets"][si][:3], dets[si], BOX_TOL, SCORE_TOL, all_scores=rb["cls_scores"][si].max(1))
-        assert ok, (tag, si, "vs oracle", msg)
+        assert ok and _same_list(msg), (tag, si, "vs oracle", msg)
         modes.append(msg.split(":")[0])
     print("%s: comparison modes vs the oracle: %s" % (tag, modes))       # pytest -s / -rP shows how many were exact
     eng.close()
@@ -220,7 +226,7 @@ def test_full_batch_properties():
     assert np.array_equal(pred[:4], r["pred_q"].astype(np.int8))
     for i in range(4):
         ok, msg = dets_match(r["dets"][i][:3], dets[i], BOX_TOL, SCORE_TOL, all_scores=r["cls_scores"][i].max(1))
-        assert ok, (i, msg)
+        assert ok and _same_list(msg), (i, msg)      # oracle vs engine: same tie order by definition
     d16 = eng.forward(x[:16])
     for i in range(16):
         for a, b in zip(d16[i], dets[i]):

@@ -26,6 +26,12 @@ QF32_CASES = [
 EMA = dict(weights=dict(seed=2), size=[96, 160], classes=2, batch=2, seeds=[41, 42, 43, 44, 45])
 
 
+def _same_list(msg):
+    """dets_match verdicts that mean "the same detections in the same order": identical lists, or identical boxes / classes
+    with every score inside the tolerance (the strict pass also bounds every box coordinate by BOX_TOL; a coordinate a hair
+    past it that still rounds to the same grid cell reports "same boxes").  What is NOT accepted here is the tie-group
+    fallback: oracle and engine order ties identically by definition."""
+    return msg in ("exact", "empty") or msg.startswith("same boxes")
 @pytest.fixture(scope="module")
 def r2():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "r2.npz"))
@@ -301,8 +307,10 @@ def test_config4_full_batch_tiny_int8():
     """BASELINE configs[3]: YOLOv3tiny int8, B = 128, 416 x 416: two images bit-exact against the integer oracle on every
     prediction map, detections tie-tolerantly equal, + periodicity + batch independence.  Against the reference's fp32
     model the int8 form is held to a stated DETECTION-level tolerance (the reference has no int8 tiny model: parity
-    unpinned): >= 60 % of either side matched at (same class, IoU >= 0.5, |score err| <= 0.2), counts
-    within 15 %."""
+    unpinned).  Measured on the MI355X (round 3, printed below with -s): 90.7 % of the reference's and 92.3 %
+    of the engine's detections matched at (same class, IoU >= 0.5, |score err| <= 0.2), 1213 detections against 1230; the
+    assertions sit a few points under the measurement (a layer with a wrong exponent or slope costs tens of points): >= 85 % /
+    87 % matched, counts within 5 %."""
     from oracle import net_int8_oracle as N
     from oracle import fp32_oracle as F
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "fp32.npz"))
@@ -320,11 +328,12 @@ def test_config4_full_batch_tiny_int8():
         assert np.array_equal(got, ref["t"][nt - 2 + k]), k
     for i in range(2):
         ok, msg = dets_match(ref["dets"][i][:3], dets[i], all_scores=ref["cls_scores"][i].max(axis=1))
-        assert ok, (i, msg)
+        assert ok and _same_list(msg), (i, msg)         # integer oracle vs engine: same tie order by definition
     gref = tuple(gold["%s/0/det0.01/%s" % (tag, k)] for k in ("boxes", "scores", "cls"))
     fr, fg = dets_close(gref, dets[0], 0.5, 0.2)
-    assert fr >= 0.6 and fg >= 0.6, "int8 tiny vs the reference's fp32 detections: matched %.3f / %.3f" % (fr, fg)
-    assert abs(len(dets[0][1]) - len(gref[1])) <= 0.15 * len(gref[1])
+    print("MEASURED config4 vs fp32 reference: matched fr=%.4f fg=%.4f, detections %d vs %d" % (fr, fg, len(dets[0][1]), len(gref[1])))
+    assert fr >= 0.85 and fg >= 0.87, "int8 tiny vs the reference's fp32 detections: matched %.3f / %.3f" % (fr, fg)
+    assert abs(len(dets[0][1]) - len(gref[1])) <= 0.05 * len(gref[1])
     net.close()
 
 

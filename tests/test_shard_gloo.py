@@ -81,8 +81,8 @@ def test_shard_range_partitions_the_batch():
 
 
 def test_pack_unpack_roundtrip_and_record_layout():
-    """the wire format of include/yolo355.h ("multi-GPU exchange"): 16-byte header + boxes + scores + cls, rounded up to
-    16 bytes; entries past count zeroed; padding records carry count -1 and are dropped"""
+    """the wire format of include/yolo355.h ("multi-GPU exchange"): 16-byte header (count, the image's own count, 0, 0) + boxes +
+    scores + cls, rounded up to 16 bytes; entries past count zeroed; padding records carry -1 / -1 and are dropped"""
     for md in (16, 7):
         per = [_fake_dets(i, md) for i in range(3)]
         boxes = torch.from_numpy(np.stack([p[0] for p in per]))
@@ -94,7 +94,11 @@ def test_pack_unpack_roundtrip_and_record_layout():
         assert rec.shape == (5, shard.record_bytes(md)) and shard.record_bytes(md) % 16 == 0
         assert shard.record_bytes(16) == 16 + 24 * 16 and shard.record_bytes(7) == 16 + 176
         r32 = rec.view(torch.int32)
-        assert r32[:, 0].tolist() == [per[0][3], per[1][3], per[2][3], -1, -1] and int(r32[:, 1:4].abs().sum()) == 0
+        assert r32[:, 0].tolist() == [per[0][3], per[1][3], per[2][3], -1, -1] and int(r32[:, 2:4].abs().sum()) == 0
+        assert r32[:, 1].tolist() == r32[:, 0].tolist() and shard.truncated_images(rec) == 0      # nothing was cut
+        big = count.clone()
+        big[1] = md + 5                                       # an image with more detections than the record holds
+        assert shard.truncated_images(shard.pack_detections(boxes, scores, cls, big, records=5)) == 1
         b, s, c, n = shard.unpack_records(rec, md, 3)
         assert n.tolist() == [p[3] for p in per]
         for i, p in enumerate(per):

@@ -26,6 +26,7 @@
 // The pruning is exact: a pair is skipped only when real IoU < 0.999*thr and the union is not
 // degenerate, where the fp32 formula of the reference cannot exceed thr.
 #include "y355_common.h"
+#include <algorithm>
 #include <cstdlib>
 
 #define NMS_CAP Y355_NMS_CAP   // max anchors per image handled by this head (416x416: 3380)
@@ -75,30 +76,54 @@ struct HeadWork {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// ---- decode_kernel: grid (ceil(N / 256), batch), one anchor per thread, in the (level, anchor, cell)
-// enumeration the sort below consumes.  The decode is ~500 VALU instructions per anchor (9 expf, ~14
-// IEEE divisions): spread over every CU instead of the 64 workgroups of the per-image sort.
-__global__ __launch_bounds__(256) void decode_kernel(const HeadParams p, const HeadWork wk) {
+// ---- decode_kernel: one anchor per thread, output in the (level, anchor, cell) enumeration the sort below consumes.
+// The decode is ~500 VALU instructions per anchor (9 expf, ~14 IEEE divisions): spread over every CU instead of the 64
+// workgroups of the per-image sort.  A workgroup owns DEC_CELLS(A) consecutive cells of one level and all their anchors:
+// the cells' prediction vectors (one contiguous range of the NHWC map) are staged in LDS with 16-byte loads, and every
+// anchor's channel walk reads LDS.  (Round 2 read the map straight from global memory, consecutive lanes a whole pixel
+// apart: byte / dword loads that each touched 64 cache lines -- 860 MB fetched per launch on the YOLOv3tiny graph for
+// 14 MB of maps, 148 us)
+#define DEC_THREADS 256
+__host__ __device__ static inline int dec_cells(int A) { return DEC_THREADS / A; }
+__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const HeadParams p, const HeadWork wk, const int pitch) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];        // dec_cells(A) x pitch bytes (pitch = cell bytes + 4: no bank conflicts)
     const int b = blockIdx.y;
-    const int np = blockIdx.x * 256 + threadIdx.x;
     const int A = p.A, C = p.C;
+    const int NCELL = dec_cells(A);
     const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
     const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0, N1 = N0 + HW1 * A;
     const int HW2 = p.nlev > 2 ? p.lev[2].Hs * p.lev[2].Ws : 0;
     const int N = N1 + HW2 * A;
-    if (np >= N) return;
-    const int lv = (np >= N0 ? 1 : 0) + (np >= N1 ? 1 : 0);
+    const int nb0 = (HW0 + NCELL - 1) / NCELL, nb1 = (HW1 + NCELL - 1) / NCELL;
+    int blk = blockIdx.x;
+    const int lv = (blk >= nb0 ? 1 : 0) + (blk >= nb0 + nb1 ? 1 : 0);
+    blk -= lv == 0 ? 0 : (lv == 1 ? nb0 : nb0 + nb1);
     const HeadLevel &L = p.lev[lv];
     const int lbase = lv == 0 ? 0 : (lv == 1 ? N0 : N1);
-    const int npl = np - lbase, HWl = lv == 0 ? HW0 : (lv == 1 ? HW1 : HW2);
-    const int a = npl / HWl, cell = npl % HWl;
+    const int HWl = lv == 0 ? HW0 : (lv == 1 ? HW1 : HW2);
+    const int cell0 = blk * NCELL, ncell = min(NCELL, HWl - cell0);
+    const int es = L.pred ? 1 : 4, cellb = L.cstride * es;            // bytes per cell (a multiple of 16: cstride is padded)
+    {
+        const char *src = (L.pred ? (const char *)L.pred : (const char *)L.pred_f) + ((size_t)b * HWl + cell0) * cellb;
+        const int n16 = ncell * cellb / 16, per = cellb / 16;
+        for (int k = threadIdx.x; k < n16; k += DEC_THREADS) {
+            const v4i v = *(const v4i *)(src + (size_t)k * 16);
+            const int c = k / per, w = k - c * per;
+            int *dst = (int *)(dsm + c * pitch + w * 16);
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+    }
+    __syncthreads();
+    const int a = threadIdx.x / NCELL, lc = threadIdx.x - a * NCELL;
+    if (a >= A || lc >= ncell) return;
+    const int cell = cell0 + lc;
+    const int np = lbase + a * HWl + cell;      // slot in the (level, anchor, cell) order
     const int n = lbase + cell * A + a;        // the reference's anchor index (:337-341)
     const int gy = cell / L.Ws, gx = cell % L.Ws;
-    const size_t po = ((size_t)(b * L.Hs + gy) * L.Ws + gx) * L.cstride;
-    const int8_t *pq = L.pred ? L.pred + po : nullptr;
-    const float *pf = L.pred_f + po;
+    const char *row = dsm + lc * pitch;
+    const bool i8 = L.pred != nullptr;
     const float dq = L.dq;
-    auto ld = [&](int c) -> float { return pq ? (float)pq[c] * dq : pf[c]; };
+    auto ld = [&](int c) -> float { return i8 ? (float)((const int8_t *)row)[c] * dq : ((const float *)row)[c]; };
     const float conf = ld(a);
     const float obj = sigmoidf_(conf);
     const int c0 = A + a * C;
@@ -870,6 +895,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
 unsigned long long *y355_nms_stamps_dev = nullptr;
 
 int y355_prepare_head(void) {
+    if (int e = (int)hipFuncSetAttribute((const void *)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
     if (int e = (int)hipFuncSetAttribute((const void *)pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS)) return e;
     return (int)hipFuncSetAttribute((const void *)pairs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
 }
@@ -916,7 +942,15 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
         wk.rcount = (int *)ws.rcount;
         wk.ovf = (int *)ws.ovf;
         wk.rstride = ws.rstride;
-        Y355_LAUNCH(decode_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, s, k0[0], k0[1], p, wk);
+        // every level's map has the same element size and padded channel count
+        const int ncell = dec_cells(p.A);
+        int nblk = 0, cellb = 0;
+        for (int l = 0; l < p.nlev; ++l) {
+            nblk += (p.lev[l].Hs * p.lev[l].Ws + ncell - 1) / ncell;
+            cellb = std::max(cellb, p.lev[l].cstride * (p.lev[l].pred ? 1 : 4));
+        }
+        const int pitch = cellb + 4;
+        Y355_LAUNCH(decode_kernel, dim3(nblk, batch), dim3(DEC_THREADS), (size_t)ncell * pitch, s, k0[0], k0[1], p, wk, pitch);
         if (large) hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     }
     Y355_LAUNCH(head_kernel, dim3(batch), dim3(1024), 0, s, k1[0], k1[1], p, wk);

@@ -83,7 +83,6 @@ struct ConvParams {
     int out_halo;         // 1: output buffer carries a zero halo
     int tiles_x, tiles_y, nblk;
     Requant rq;
-    int stagger;          // ring kernel, two workgroups per CU: the second half of the grid starts 64*stagger cycles late
     int mode;             // 0 run, 1 statistics only
     int guard;            // evaluate the head-room guard
     // host side only (ring launcher): when set, the launch records the kernel's own start / end timestamps into these

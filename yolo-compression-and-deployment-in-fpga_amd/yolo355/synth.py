@@ -95,12 +95,20 @@ def pred_channels(num_classes, num_anchors=5):
     return num_anchors * (1 + 4 + num_classes)
 
 
+# exponents of the trained FPGA model, recorded only in the C driver (c_embedding/yolo_forward.c:32-33)
+C_TABLE_SCALE_W = [6, 8, 8, 9, 9, 9, 10, 10, 10, 9]
+C_TABLE_SCALE_B = [7, 6, 5, 5, 5, 6, 5, 5, 5, 10]
+
+
 def make_weights(seed, num_classes=2, num_anchors=5, bias_gain=1.0, weight_gain=1.0,
-                 obj_bias=None, pred_gain=1.0):
+                 obj_bias=None, pred_gain=1.0, ctable=False):
     """fp32 (W[cout,cin,3,3], b[cout]) for the 10 convs, PyTorch-default-like
     U(+-1/sqrt(fan_in)).  `obj_bias` (float) overrides the objectness biases of the
     pred layer (the "sparse detections" fixture); `pred_gain` scales the
-    pred weights (not biases) so that logits spread over the int8 range (few score ties)."""
+    pred weights (not biases) so that logits spread over the int8 range (few score ties).
+    `ctable`: one weight and one bias per tensor are set to 0.9 * 127 / 2^e with e from the C driver's tables, so that
+    the per-tensor power-of-two quantizer (retune_bias_quantize.py:73-119) lands on exactly those exponents -- like a
+    trained, BN-folded tensor: a few large values, the bulk small."""
     out = []
     for li, (name, cin, cout, _pool, _act) in enumerate(SLIM_LAYERS):
         if cout is None:
@@ -112,6 +120,14 @@ def make_weights(seed, num_classes=2, num_anchors=5, bias_gain=1.0, weight_gain=
             w = w * np.float32(pred_gain)
             if obj_bias is not None:
                 b[:num_anchors] = np.float32(obj_bias)
+        if ctable:
+            w = w.copy()
+            b = b.copy()
+            tw, tb = 0.9 * 127.0 / 2.0 ** C_TABLE_SCALE_W[li], 0.9 * 127.0 / 2.0 ** C_TABLE_SCALE_B[li]
+            w *= np.float32(min(1.0, 0.5 * tw / float(np.abs(w).max())))       # the bulk stays below the planted maximum
+            b *= np.float32(min(1.0, 0.5 * tb / float(np.abs(b).max())))
+            w.flat[(7 * li + 3) % w.size] = np.float32(tw if li % 2 == 0 else -tw)
+            b.flat[(5 * li + 1) % b.size] = np.float32(-tb if li % 3 == 0 else tb)
         out.append((name, w.astype(np.float32), b.astype(np.float32)))
     return out
 

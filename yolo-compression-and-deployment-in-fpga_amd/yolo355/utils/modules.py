@@ -5,7 +5,9 @@ activation)) so checkpoints load unchanged.  `forward` of the BN-folded modules 
 MI355X through the C ABI when the operands are the fake-quantized tensors of the quantized
 path (values q / 2^e with |q| <= 127, the only regime the FPGA path and this engine define):
 the result is the exact fp32 tensor the reference's nn.Conv2d + LeakyReLU(0.125) produces.
-Anything else (raw fp32 operands, training) raises -- there is no CPU / PyTorch fallback.
+Operands that are NOT dyadic int8 values (utils/modules.py:28-29 accepts any fp32 tensor) run the same layer on the bf16
+MFMA through y355_conv2d_bf16 (operands and result rounded to bf16, the tolerance of the fp32 model families); training
+raises -- there is no CPU / PyTorch fallback.
 """
 import numpy as np
 import torch
@@ -25,10 +27,8 @@ def _int8_operands(module, x):
             q_b, e_b = prep.as_dyadic_int8(conv.bias)
         else:
             q_b, e_b = np.zeros(conv.out_channels, np.int32), 0
-    except ValueError as err:
-        raise NotImplementedError(
-            "yolo355 operator modules run the int8 power-of-two quantized path only "
-            "(input / weights must be fake-quantized: %s)" % err)
+    except ValueError:
+        return None                                       # not fake-quantized operands: the bf16 route
     return q_in, sa_in, q_w, e_w, q_b, e_b
 
 
@@ -37,7 +37,11 @@ class _FusedBase(nn.Module):
 
     def forward(self, x):
         from ..engine import conv3x3_i8_raw
-        q_in, sa_in, q_w, e_w, q_b, e_b = _int8_operands(self, x)
+        ops = _int8_operands(self, x)
+        if ops is None:
+            # the reference's module takes any fp32 tensor (utils/modules.py:28-29, :39-40): same layer on the bf16 MFMA
+            return _conv_bn_act_forward(self.convs, x)
+        q_in, sa_in, q_w, e_w, q_b, e_b = ops
         t, frac = conv3x3_i8_raw(q_in, q_w, q_b, sa_in, e_w, e_b, leaky=self.leaky, relu=not self.leaky,
                                  device_id=x.device.index if x.is_cuda and x.device.index is not None else 0)
         y = torch.from_numpy(t.astype(np.float32) * np.float32(2.0 ** (-frac)))
