@@ -163,7 +163,8 @@ def forward_backbone_int(x_f32, qlayers, trackers, quant_freeze=True, find=False
     trackers: list of 11 RangeTracker (input, conv1..conv7, pred); updated in place with
     the reference's first-call / EMA / freeze semantics.
     Returns dict: sa (11 exponents used), maps (list of post-quant, post-pool int32 maps,
-    unclamped unless saturate), pred_q, sat (per-tracker count of |q|>127), guard (per-layer
+    unclamped unless saturate), pred_q, sat (per-tracker count of |q|>127), sat_out (per layer: the same count taken on the
+    layer's OUTPUT map, i.e. after the 2x2 max of a pooled layer -- what a kernel that pools before it clamps can count), guard (per-layer
     max |t'| * 2^(r-F'), the quantity `find` compares with 2^15), acc_max.
     """
     x = np.asarray(x_f32, dtype=np.float32)
@@ -175,7 +176,7 @@ def forward_backbone_int(x_f32, qlayers, trackers, quant_freeze=True, find=False
     sat.append(int((np.abs(q) > 127).sum()))
     if saturate:
         q = np.clip(q, -127, 127)
-    maps, guard, acc_max = [], [], []
+    maps, guard, acc_max, sat_out = [], [], [], []
     for k, L in enumerate(qlayers):
         t, Fx, acc = conv_layer_int(q, L["q_w"], L["q_b"], sa[k], L["e_w"], L["e_b"], LEAKY[k])
         acc_max.append(int(np.abs(acc).max()))
@@ -190,6 +191,7 @@ def forward_backbone_int(x_f32, qlayers, trackers, quant_freeze=True, find=False
         sa.append(ek)
         q = rne_shift(t, Fx - ek)
         sat.append(int((np.abs(q) > 127).sum()))
+        sat_out.append(int((np.abs(maxpool2x2(q) if POOL_AFTER[k] else q) > 127).sum()))
         if saturate:
             q = np.clip(q, -127, 127)
         if POOL_AFTER[k]:
@@ -197,7 +199,7 @@ def forward_backbone_int(x_f32, qlayers, trackers, quant_freeze=True, find=False
         q = q.astype(np.int32)
         if keep:
             maps.append(q)
-    return dict(sa=sa, maps=maps, pred_q=q, sat=sat, guard=guard, acc_max=acc_max)
+    return dict(sa=sa, maps=maps, pred_q=q, sat=sat, sat_out=sat_out, guard=guard, acc_max=acc_max)
 
 
 # ----------------------------------------------------------------------------- head

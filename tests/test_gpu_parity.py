@@ -179,6 +179,14 @@ def test_saturation_is_counted_not_silent():
     assert np.array_equal(eng.get_feature(9, 1), r["pred_q"].astype(np.int8))
     sat, _ = eng.counters()
     assert sat > 0
+    # per layer the engine's count is the oracle's, taken on the layer's output map (pooled layers pool before they clamp);
+    # this walks the cold passes of the fused front end and of the convpx kernels as well as the integer epilogues
+    got = [eng.layer_stats(k)["saturated"] for k in range(10)]
+    print("saturated per layer", got, "oracle", r["sat_out"], "input", r["sat"][0])
+    assert got[2:] == r["sat_out"][2:], (got, r["sat_out"])
+    assert got[1] == r["sat_out"][1] and got[0] in (r["sat_out"][0], r["sat_out"][0] + r["sat"][0]), (got, r["sat_out"], r["sat"][0])
+    assert sat == sum(got) or sat == sum(got) + r["sat"][0], (sat, got)
+    assert any(got[k] > 0 for k in (2, 3, 4, 5)), got
     eng.close()
 
 
