@@ -38,19 +38,6 @@ __device__ __forceinline__ void rwait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
 }
 
-// fp32 epilogue on exact integers (FPE): 1.5 * 2^23 and the clamp bounds around it
-constexpr float RMAGIC = 12582912.0f, RQLO = 12582785.0f, RQHI = 12583039.0f;
-__device__ __forceinline__ float rvmax(float a, float b) {       // v_max_f32 without the canonicalising multiply
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ unsigned int rpack4(float a, float b, float c, float d) {   // low bytes of four floats M + q
-    const unsigned int ab = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x0c0c0400u);
-    const unsigned int cd = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x04000c0cu);
-    return ab | cd;
-}
-
 // s_waitcnt needs an immediate; callers pass values that are constants after unrolling, so the switch
 // folds to one instruction
 __device__ __forceinline__ void rwait_vmcnt_dyn(int n) {
@@ -79,11 +66,7 @@ constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
     return n;
 }
 
-// FPE: the requantisation runs in fp32 on exact integers (launcher-proved: accumulator shift 0, no left requant shift, right
-// shift <= 17, so every t = acc + bias that does not saturate is below 2^24 and converts exactly; a larger one converts to
-// something at least as large and saturates either way).  The biases come from a 1 KiB LDS copy that the prologue's first
-// LDS-DMA makes (oldest in the vmcnt stream: every later wait covers it; no global load in the epilogue).
-template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ, bool FPE = false>
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ>
 __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
     constexpr int NW = WM * WN;
     constexpr int NTHR = NW * 64;
@@ -104,7 +87,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     constexpr int WSLOTS = PF + 2;
     constexpr int OFF_W = 2 * SLABB;
     constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;
-    constexpr int OFF_BIAS = OFF_DUMMY + 1024;                     // FPE: the layer's biases (<= 256 int32)
+    constexpr int OFF_BIAS = OFF_DUMMY + 1024;                     // SWAP: the layer's biases (<= 256 int32), DMA'd once
     constexpr int SROWS = POOL ? MT * WM * 4 : MT * WM * 16;
     constexpr int SSTR = BN + 16;
     constexpr int OROWS = POOL ? BM / 4 : BM;
@@ -112,15 +95,20 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     // otherwise every lane stores its own 4 adjacent channels directly (16 lanes = 64 contiguous bytes
     // of a pixel) -- measured faster than staging in two passes, which serialises the requantisation
     constexpr bool DIRECT = DIRECT_REQ && (SROWS * SSTR > SLABB);
-    constexpr int NPASS = (!DIRECT && SROWS * SSTR > SLABB) ? 2 : 1;
+    // SWAP (unpooled layers): the MFMA's operands trade places -- weights as A, pixels as B.  The fragments are the same
+    // registers (A and B fragments have the same lane layout); what changes is D: a lane then holds pixel `li` of the m-tile
+    // and output rows 4g + r of every n-tile, which the weight packing (channel = 16j... = j * NT + t) makes the 16 CONSECUTIVE
+    // channels 16g .. 16g + 15 of that pixel, byte 4r + t.  The tile leaves as one 16-byte store per m-tile and lane: no LDS
+    // staging, no epilogue barrier.
+    constexpr bool SWAP = DIRECT_REQ && !POOL;
+    constexpr int NPASS = (!DIRECT && !SWAP && SROWS * SSTR > SLABB) ? 2 : 1;
     constexpr int RP = SROWS / NPASS;                              // staged rows per pass
     constexpr int CG = BN / 16;
     constexpr int NITP = (RP * CG + NTHR - 1) / NTHR;              // output stores per thread per pass
-    constexpr int NIT = DIRECT ? (POOL ? MT : MT * 4) : NPASS * NITP;   // output stores per thread per tile (static)
+    constexpr int NIT = SWAP ? MT : DIRECT ? (POOL ? MT : MT * 4) : NPASS * NITP;   // output stores per thread per tile (static)
     static_assert(CIN % 64 == 0 && NT == 4, "64-channel chunks, four n-tiles per wave");
     static_assert(PPW <= 8 && PF >= 2 && PF <= 8, "slab pieces go out at t = 1..PPW");
-    static_assert(!(FPE && (DIRECT_REQ || ROLL)), "the fp32 epilogue is written for the staged path and the unrolled chunk loop");
-    static_assert(DIRECT || (RP * SSTR <= SLABB && MT % NPASS == 0), "staging fits the dead slot");
+    static_assert(DIRECT || SWAP || (RP * SSTR <= SLABB && MT % NPASS == 0), "staging fits the dead slot");
     constexpr int UNRC = ROLL ? 1 : NCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -194,8 +182,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     decode(tile, b, y0, x0, nb);
     int sl = 0;                                                // slab slot of the current chunk
     int wq = 0;                                                // ring slot of W(s) at step s
-    // ---- prologue: (FPE: the biases,) slab 0 whole, then W(0) .. W(PF)
-    if constexpr (FPE) rglds16(p.bias_t + min(lane * 4, p.cstride - 4), wave == 0 ? smem + OFF_BIAS : smem + OFF_DUMMY);
+    // ---- prologue: (SWAP: the biases, oldest in the vmcnt stream so that every later wait covers them,) slab 0 whole,
+    // then W(0) .. W(PF)
+    if constexpr (SWAP)
+        rglds16(p.bias_t + min(lane * 4, p.cstride - 4), wave == 0 ? smem + OFF_BIAS : smem + OFF_DUMMY);
 #pragma unroll
     for (int j = 0; j < PPW; ++j) issue_slab_piece(b, y0, x0, 0, 0, j);
 #pragma unroll
@@ -204,6 +194,25 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         else issue_w(nb, k - KS, k);                           // KS > PF for every layer here; keeps counts static
     }
     pstamp(1);
+    // per-lane A-fragment bases (integer divisions): computed while the prologue's DMAs are in flight
+    int abase[MT][3];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int row = (wm * MT + m) * 16 + li;
+        row = min(row, BM - 1);
+        int oy, ox;
+        if constexpr (POOL) {
+            const int w = row >> 2, r = row & 3;
+            oy = 2 * (w / (TW / 2)) + (r >> 1);
+            ox = 2 * (w % (TW / 2)) + (r & 1);
+        } else {
+            oy = row / TW;
+            ox = row % TW;
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ (((ox + dx) >> 1) & 3)) << 4);
+    }
     const Requant rq = p.rq;
     unsigned int nsat = 0;
     bool first = true;
@@ -214,30 +223,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         if (!more) ntile = tile;                               // keep the operation counts static
         int b2, y2, x2, nb2;
         decode(ntile, b2, y2, x2, nb2);
-        // per-lane A-fragment bases (integer divisions): computed while the prologue's (or the previous tile's prefetch) DMAs
-        // are in flight, per tile from an opaque copy of the lane id so that they are not live across the epilogue
-        int abase[MT][3];
-        {
-            int li_a = li, g_a = g;
-            asm volatile("" : "+v"(li_a), "+v"(g_a));
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                int row = (wm * MT + m) * 16 + li_a;
-                row = min(row, BM - 1);
-                int oy, ox;
-                if constexpr (POOL) {
-                    const int w = row >> 2, r = row & 3;
-                    oy = 2 * (w / (TW / 2)) + (r >> 1);
-                    ox = 2 * (w % (TW / 2)) + (r & 1);
-                } else {
-                    oy = row / TW;
-                    ox = row % TW;
-                }
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g_a ^ (((ox + dx) >> 1) & 3)) << 4);
-            }
-        }
 
         v4i acc[MT][NT];
 #pragma unroll
@@ -352,7 +337,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                         }
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
-                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                            acc[m][tt] = SWAP ? __builtin_amdgcn_mfma_i32_16x16x64_i8(bfb[cur][tt], af[m], acc[m][tt], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
                     }
                 }
             }
@@ -369,16 +355,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         // ---- epilogue: integer pipeline (32-bit path of conv3x3.hip) into registers, then through the
         // slab slot that just died (slot sl ^ 1: `sl` already points at the next tile's chunk 0)
         {
-            // the epilogue's lane-dependent addresses are re-derived here from an opaque copy of the thread id: computed once
-            // per launch they would be live (or spilled) across the whole k-loop
-            int tid_e = threadIdx.x;
-            asm volatile("" : "+v"(tid_e));
-            const int tid = tid_e, lane = tid_e & 63, li = lane & 15, g = lane >> 4;
-            (void)lane;
             const int ncol = wn * (NT * 16) + li * NT;
             int bias[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bias[t] = FPE ? 0 : p.bias_t[nb * BN + ncol + t];
+            for (int t = 0; t < NT; ++t) bias[t] = p.bias_t[nb * BN + ncol + t];
             constexpr int RPM = POOL ? 1 : 4;                   // staged rows per m-tile and lane
             // sh_l (a left requant shift; sh_r = 0 then) folded into the accumulator shift and the bias:
             // ((t' << sh_l) + hm1 + rb) >> sh_r with t' = max(t, t << lk) equals the same form on T = t << sh_l
@@ -392,18 +372,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
                 return (x + rq.hm1 + rb) >> rq.sh_r;
             };
-            // FPE: t = acc + bias in integers (exact), then fp32; the two scales are powers of two built in scalar registers
-            const float s_pos = __int_as_float((127 + rq.lk - rq.sh_r) << 23), s_neg = __int_as_float((127 - rq.sh_r) << 23);
-            int biasf[NT];
-            if constexpr (FPE) {
-                const v4i bv = *(const v4i *)(smem + OFF_BIAS + (nb * BN + ncol) * 4);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) biasf[t] = bv[t];
-            }
-            auto requantf = [&](int v, int t) {
-                const float tf = (float)(v + biasf[t]);
-                return rvmax(fmaf(tf, s_pos, RMAGIC), fmaf(tf, s_neg, RMAGIC));
-            };
             unsigned int satx = 0;                              // sum of (clamped ^ unclamped): non-zero iff something saturated
             if (Y355_DIAG && first) stamp();
             char *stg = smem + (sl ^ 1) * SLABB;
@@ -412,7 +380,58 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
             const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
             const int oy0 = POOL ? (y0 >> 1) : y0, ox0 = POOL ? (x0 >> 1) : x0;
             int8_t *outb = p.out + (size_t)b * (Ho + 2 * halo) * (Wo + 2 * halo) * p.cstride + nb * BN;
-            if constexpr (DIRECT) {
+            if constexpr (SWAP) {
+                // lane = pixel li of each of its m-tiles, channels cb .. cb + 15 (byte 4r + t = accumulator r of n-tile t)
+                const int cb = wn * (NT * 16) + 16 * g;
+                int bsw[4][NT];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const v4i bv = *(const v4i *)(smem + OFF_BIAS + (nb * BN + cb + 4 * r) * 4);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bsw[r][t] = bv[t] << rq.sh_l;
+                }
+                auto requant_sw = [&](int v, int r, int t) {
+                    int x = (v << shl2) + bsw[r][t];
+                    x = max(x, x << rq.lk);
+                    const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
+                    return (x + rq.hm1 + rb) >> rq.sh_r;
+                };
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    v4i o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned int w = 0;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int qq = requant_sw(acc[m][t][r], r, t);
+                            const int q = y355_clamp8<int>(qq);
+                            satx += (unsigned int)(q ^ qq);
+                            w |= (unsigned int)(q & 0xff) << (8 * t);
+                        }
+                        o[r] = (int)w;
+                    }
+                    const int row = (wm * MT + m) * 16 + li;
+                    const int oy = oy0 + row / OTW, ox = ox0 + row % OTW;
+                    int8_t *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.cstride + cb;
+                    if (!(row < OROWS && oy < Ho && ox < Wo)) dst = p.sink + tid * 16;   // keeps the store count static
+                    *(v4i *)dst = o;
+                }
+                if (satx) {                                     // cold: count the clamped outputs of real pixels exactly
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int row = (wm * MT + m) * 16 + li;
+                        const bool real = row < OROWS && oy0 + row / OTW < Ho && ox0 + row % OTW < Wo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const int qq = requant_sw(acc[m][t][r], r, t);
+                                nsat += (real && y355_clamp8<int>(qq) != qq) ? 1u : 0u;
+                            }
+                    }
+                }
+            } else if constexpr (DIRECT) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -459,7 +478,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                     for (int r = 0; r < RPM; ++r) {
                         const int lrow = POOL ? (wm * MH + mm) * 4 + g : (wm * MH + mm) * 16 + 4 * g + r;
                         unsigned int w = 0;
-                        float yq[NT];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
                             int v;
@@ -469,26 +487,12 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                             } else {
                                 v = acc[m][t][r];
                             }
-                            if constexpr (FPE) {
-                                yq[t] = requantf(v, t);
-                            } else {
-                                const int qq = requant(v, t);
-                                const int q = y355_clamp8<int>(qq);
-                                satx += (unsigned int)(q ^ qq);     // v_xad_u32; the exact count is taken below, rarely
-                                w |= (unsigned int)(q & 0xff) << (8 * t);
-                            }
-                        }
-                        if constexpr (FPE) {
-                            float yc[NT];
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) {
-                                yc[t] = __builtin_amdgcn_fmed3f(yq[t], RQLO, RQHI);
-                                satx += __float_as_uint(yc[t]) ^ __float_as_uint(yq[t]);
-                            }
-                            w = rpack4(yc[0], yc[1], yc[2], yc[3]);
+                            const int qq = requant(v, t);
+                            const int q = y355_clamp8<int>(qq);
+                            satx += (unsigned int)(q ^ qq);         // v_xad_u32; the exact count is taken below, rarely
+                            w |= (unsigned int)(q & 0xff) << (8 * t);
                         }
                         *(unsigned int *)(stg + lrow * SSTR + ncol) = w;
-                        if constexpr (FPE) __builtin_amdgcn_sched_barrier(0);   // one row at a time: short live ranges (no spill)
                     }
                 }
                 if (Y355_DIAG && first) stamp();                   // requantised and staged (this wave)
@@ -522,14 +526,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                             } else {
                                 v = acc[m][t][r];
                             }
-                            if constexpr (FPE) {
-                                asm volatile("" : "+v"(v));        // recompute here: do not keep the hot pass's 96 values alive for this branch
-                                const float y = requantf(v, t);
-                                nsat += (srow < OROWS && (y > RQHI || y < RQLO)) ? 1u : 0u;
-                            } else {
-                                const int qq = requant(v, t);
-                                nsat += (srow < OROWS && y355_clamp8<int>(qq) != qq) ? 1u : 0u;
-                            }
+                            const int qq = requant(v, t);
+                            nsat += (srow < OROWS && y355_clamp8<int>(qq) != qq) ? 1u : 0u;
                         }
                     }
             }
@@ -549,14 +547,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT, bool FPE>
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT>
 struct ConvInstR {
     static constexpr int PWL = (TW + 2 + 7) / 8 * 8;
     static constexpr int SLABB = ((TH + 2) * PWL * 64 + 1023) / 1024 * 1024;
     static constexpr int WB = (BN / 16) * 1024;
-    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(PF + 2) * WB + 1024 + (FPE ? 1024 : 0);
+    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(PF + 2) * WB + 1024 + (DIRECT && !POOL ? 1024 : 0);
     static int prepare() {
-        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT, FPE>,
+        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     static bool launch(const ConvParams &p_in, hipStream_t s) {
@@ -570,24 +568,24 @@ struct ConvInstR {
         if (p.ev_start && p.ev_stop) {
             hipEvent_t e0 = (hipEvent_t)p.ev_start, e1 = (hipEvent_t)p.ev_stop;
             p.ev_start = p.ev_stop = nullptr;
-            hipExtLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT, FPE>), dim3(grid), dim3(WM * WN * 64), LDS, s,
+            hipExtLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s,
                                   e0, e1, 0, p, total);
         } else {
-            hipLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT, FPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
+            hipLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
         }
         return true;
     }
 };
 
 // must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
-template <bool ROLL, bool DIRECT, bool FPE>
+template <bool ROLL, bool DIRECT, bool SW>
 struct RSet {
-    using C3_2 = ConvInstR<64, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
-    using C4_1 = ConvInstR<64, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
-    using C4_2 = ConvInstR<128, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
-    using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
-    using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
-    using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
+    using C3_2 = ConvInstR<64, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
+    using C4_1 = ConvInstR<64, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, SW>;
+    using C4_2 = ConvInstR<128, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
+    using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, SW>;
+    using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, SW>;
+    using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, Y355_RING_PF, ROLL, SW>;
     static int prepare() {
         int e = C3_2::prepare();
         if (!e) e = C4_1::prepare();
@@ -610,21 +608,14 @@ struct RSet {
     }
 };
 
-int y355_prepare_conv_ring(void) {
-    const int e = RSet<false, false, false>::prepare();
-    return e ? e : RSet<false, false, true>::prepare();
-}
+#ifndef Y355_RING_SWAP
+#define Y355_RING_SWAP 1            // unpooled layers: weights as the MFMA's A operand, 16-byte stores straight from the accumulators
+#endif
+int y355_prepare_conv_ring(void) { return RSet<false, false, Y355_RING_SWAP != 0>::prepare(); }
 
 bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s) {
     if ((p.mode & 0xff) != 0 || p.rq.wide || p.guard) return false;   // those go to conv3x3.hip
-    // ROLL = false (chunk loop unrolled) and staged epilogue: measured best of the four combinations (144.5 k img/s vs 140-142 k,
-    // one stream, B = 64, round 1); round 3's operand-swapped form with 16-byte stores straight from the accumulators
-    // (scratch/ring_experiments/conv3x3_ring_r3_swap.hip) shortens the epilogue by 0.9 us and changes nothing end to end
-    // fp32 epilogue where the host can prove it exact (header of the kernel): no accumulator / left requant shift, a right shift
-    // of at most 17 bits, the reference's slope
-#ifndef Y355_RING_NO_FPE
-    if (p.rq.shl == 0 && p.rq.sh_l == 0 && p.rq.sh_r <= 17 && p.rq.neg_mul == 1 && p.cstride >= 4 && p.cstride <= 256)
-        return RSet<false, false, true>::launch(kid, p, s);
-#endif
-    return RSet<false, false, false>::launch(kid, p, s);
+    // ROLL = false (chunk loop unrolled); pooled layers: staged epilogue (measured best of the four combinations, 144.5 k img/s
+    // vs 140-142 k, one stream, B = 64, round 1)
+    return RSet<false, false, Y355_RING_SWAP != 0>::launch(kid, p, s);
 }

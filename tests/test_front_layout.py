@@ -135,3 +135,40 @@ def test_front_fp32_requant_is_the_integer_pipeline():
         yb = np.maximum((tb.astype(np.float64) * s_pos + np.float64(c_pos)).astype(np.float32),
                         (tb.astype(np.float64) * s_neg + np.float64(c_neg)).astype(np.float32))
         assert np.array_equal(yb, y), sh
+
+
+def test_ring_fp32_requant_covers_the_whole_int32_range():
+    """conv3x3_ring.hip's FPE epilogue (conv5 .. pred): t = acc + bias may be ANY int32 -- the launcher only proves that the
+    right shift is at most 17 bits.  Then every t that does not saturate is below 2^24 (exact in fp32) and every larger one
+    converts (round to nearest even) to something at least as large and saturates either way: the byte AND the 'this value
+    was clamped' flag equal the integer pipeline's for leaky (max(t, 8 t)) and linear (pred) layers, at and around 2^24,
+    the clamp boundary, the rounding ties and the int32 limits."""
+    M = np.float32(12582912.0)
+    lo, hi = np.float32(M - 127), np.float32(M + 127)
+    rng = np.random.default_rng(11)
+    edge = np.concatenate([np.arange(-4, 5) + s * 2 ** k for k in range(20, 32) for s in (-1, 1)]
+                          + [np.array([-2 ** 31, -2 ** 31 + 1, 2 ** 31 - 1, 2 ** 31 - 2])])
+    for lk in (0, 3):
+        for sh in range(0, 18):
+            t = np.concatenate([rng.integers(-2 ** 31, 2 ** 31, 100000), rng.integers(-2 ** 25, 2 ** 25, 100000),
+                                rng.integers(-130 << sh, (130 << sh) + 1, 50000), edge,
+                                (np.arange(-140, 141)[:, None] * 2 ** sh + (2 ** sh >> 1) + np.arange(-3, 4)[None, :]).ravel(),
+                                (np.arange(-140, 141)[:, None] * (2 ** sh) // (2 ** lk) + np.arange(-3, 4)[None, :]).ravel()]).astype(np.int64)
+            t = t[(t >= -2 ** 31) & (t < 2 ** 31)]
+            tp = np.maximum(t, t * 2 ** lk)                                            # exact in int64
+            half = (1 << (sh - 1)) - 1 if sh > 0 else 0
+            qq = (tp + half + ((tp >> sh) & (1 if sh > 0 else 0))) >> sh               # the integer pipeline: RNE shift
+            q_ref, sat_ref = np.clip(qq, -127, 127), np.abs(qq) > 127
+            tf = t.astype(np.int32).astype(np.float32)                                 # v_cvt_f32_i32: round to nearest even
+            y = np.maximum((tf.astype(np.float64) * 2.0 ** (lk - sh) + np.float64(M)).astype(np.float32),
+                           (tf.astype(np.float64) * 2.0 ** -sh + np.float64(M)).astype(np.float32))
+            yc = np.minimum(np.maximum(y, lo), hi)
+            q = (yc.view(np.uint32) & 0xff).astype(np.uint8).view(np.int8).astype(np.int64)
+            assert np.array_equal(q, q_ref), (lk, sh)
+            assert np.array_equal(y != yc, sat_ref), (lk, sh)
+    # and the bound is tight: one more bit of shift and an odd t just above 2^24 lands on a tie it is not on
+    sh, t = 18, np.array([2 ** 24 + 2 ** 17 + 1], np.int64)
+    qq = (t + (1 << (sh - 1)) - 1 + ((t >> sh) & 1)) >> sh
+    tf = t.astype(np.int32).astype(np.float32)
+    y = (tf.astype(np.float64) * 2.0 ** -sh + np.float64(M)).astype(np.float32)
+    assert int(y.view(np.uint32)[0] & 0xff) != int(qq[0])
