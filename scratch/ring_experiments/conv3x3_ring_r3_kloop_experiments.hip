@@ -24,6 +24,15 @@
 #ifndef Y355_DIAG12
 #define Y355_DIAG12 (Y355_DIAG == 1 || Y355_DIAG == 2)
 #endif
+#ifndef Y355_ABL
+#define Y355_ABL 0                  // timing experiments only (wrong results): 1 no LDS reads, 2 no refill DMAs, 4 no waits / barriers, 8 no MFMAs
+#endif
+#ifndef Y355_RING_BASM
+#define Y355_RING_BASM 0
+#endif
+#ifndef Y355_RING_AHEAD
+#define Y355_RING_AHEAD 0           // 1: every A fragment read one k-step ahead (experiment)
+#endif
 #ifndef Y355_RING_PF
 #define Y355_RING_PF 5              // k-steps of weights in flight (ring of PF + 2 slots); 4..7 measured equal (profiles/r02_notes.md)
 #endif
@@ -54,9 +63,19 @@ __device__ __forceinline__ unsigned int rpack4(float a, float b, float c, float 
     return ab | cd;
 }
 
+// ds_read_b128 the compiler cannot sink (it places a builtin read of next step's B fragments at the END of the step, into
+// the registers the current step's fragments die in, and the next step then starts with the read's latency): volatile asm,
+// destination registers of its own, completion by an explicit lgkmcnt(0) before the next barrier
+__device__ __forceinline__ v4i rlds128(const char *p) {
+    v4i d;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"((unsigned int)(size_t)(const __attribute__((address_space(3))) char *)p) : "memory");
+    return d;
+}
+
 // s_waitcnt needs an immediate; callers pass values that are constants after unrolling, so the switch
 // folds to one instruction
 __device__ __forceinline__ void rwait_vmcnt_dyn(int n) {
+    if (Y355_ABL & (4 | 16)) return;
 #define RW_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     switch (n < 0 ? 0 : (n > 63 ? 63 : n)) {
         RW_CASE(0) RW_CASE(1) RW_CASE(2) RW_CASE(3) RW_CASE(4) RW_CASE(5) RW_CASE(6) RW_CASE(7) RW_CASE(8) RW_CASE(9)
@@ -86,6 +105,17 @@ constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
 // shift <= 17, so every t = acc + bias that does not saturate is below 2^24 and converts exactly; a larger one converts to
 // something at least as large and saturates either way).  The biases come from a 1 KiB LDS copy that the prologue's first
 // LDS-DMA makes (oldest in the vmcnt stream: every later wait covers it; no global load in the epilogue).
+// ablation helpers (Y355_ABL, timing only): an LDS read that is not one, an MFMA that is an add
+#if Y355_ABL & 1
+#define RD(ptr) ((v4i){(int)(size_t)(ptr), lane, tid, wave})
+#else
+#define RD(ptr) (*(const v4i *)(ptr))
+#endif
+#if Y355_ABL & 8
+#define MM(d, a, b) do { (d)[0] += (a)[0] ^ (b)[0]; } while (0)
+#else
+#define MM(d, a, b) (d) = __builtin_amdgcn_mfma_i32_16x16x64_i8((a), (b), (d), 0, 0, 0)
+#endif
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ, bool FPE = false>
 __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
     constexpr int NW = WM * WN;
@@ -253,6 +283,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         // W(1..PF), the slab pieces issued with them, and the previous tile's NIT output stores.
         v4i bfb[2][NT];
         v4i afp[2];
+        v4i afb[2][MT];
+        (void)afp; (void)afb;
         if (first) rwait_vmcnt<PF * WPW>();
         else rwait_vmcnt<PF * WPW + ring_sp(-PF, -1, PPW, true) + NIT>();
         __builtin_amdgcn_s_barrier();
@@ -313,28 +345,80 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                     }
                     if (fine) stamp();
                 }
-                __builtin_amdgcn_s_barrier();
+                if (Y355_RING_BASM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the B fragments read under the previous step
+#ifdef Y355_ABL_BAR2                                   // timing experiment only (wrong results): a barrier every second k-step
+                if ((s_idx & 1) == 0)
+#endif
+                if (!(Y355_ABL & 4)) __builtin_amdgcn_s_barrier();
                 if (Y355_DIAG12 && first && c == (NCH > 1 ? 1 : 0)) stamp();
                 // ---- refill: one slab piece (t = 1..PPW) into the slot that died two barriers ago,
                 // W(s+1+PF) into the ring slot read in step s-2
                 const int wqs = wq;
                 {
-                    if (t >= 1 && t <= PPW) {
+                    if (!(Y355_ABL & 2) && t >= 1 && t <= PPW) {
                         issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
                     }
                     const int ksn = s_idx + 1 + PF;
                     const bool nxt = ksn >= KS;
-                    issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wqs + PF + 1));
+                    if (!(Y355_ABL & 2)) issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wqs + PF + 1));
                 }
                 const int ko = (t / 3) * PWL * 64;
                 const int acol = t % 3;
                 const int cur = ROLL ? (t & 1) : (s_idx & 1);     // rolled: every chunk starts with its B fragments in bfb[0]
                 wq = wrap(wq + 1);
+#if Y355_RING_AHEAD
+                // A fragments one whole k-step ahead (all MT of them, into the other half of afb), like the B fragments: no MFMA
+                // of a step waits for an LDS read issued inside it, except in a chunk's first step (the slab has only just landed).
+                // The reads are pinned between the MFMAs (two behind every fourth MFMA): left alone, the scheduler sinks them to
+                // the end of the step and the next step starts with their latency.
+                {
+                    static_assert(!ROLL, "parity by tap");
+                    const int pa = t & 1;
+                    if (t == 0) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) afb[0][m] = *(const v4i *)(smem + abase[m][acol] + soff + ko);
+                    }
+                    if (s_idx + 1 < KS) {                            // B fragments of step s+1
+                        const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
+                    }
+                    if (t + 1 < SPC) {
+                        const int ko2 = ((t + 1) / 3) * PWL * 64;
+                        const int acol2 = (t + 1) % 3;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) afb[pa ^ 1][m] = *(const v4i *)(smem + abase[m][acol2] + soff + ko2);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afb[pa][m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                    if (t > 0 && Y355_RING_AHEAD == 3) {
+                        // B fragments of the next step first (straight behind the barrier: they then need registers of their own
+                        // and have the whole step to land), then one A read behind every fourth MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    }
+                    if (t > 0 && Y355_RING_AHEAD == 1) {
+                        constexpr int NRD = NT + MT;                 // reads of a full step
+#pragma unroll
+                        for (int i = 0; i < (NRD + 1) / 2; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // 4 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // 2 DS read
+                        }
+                    }
+                }
+#else
                 v4i af[MT];
                 {
                     if (t == 0) {
-                        af[0] = *(const v4i *)(smem + abase[0][acol] + soff + ko);
-                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + abase[1][acol] + soff + ko);
+                        af[0] = RD(smem + abase[0][acol] + soff + ko);
+                        if constexpr (MT > 1) af[1] = RD(smem + abase[1][acol] + soff + ko);
                     } else {
                         af[0] = afp[0];
                         if constexpr (MT > 1) af[1] = afp[1];
@@ -342,22 +426,23 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                     if (s_idx + 1 < KS) {                            // B fragments of step s+1, under this step's MFMAs
                         const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
+                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = Y355_RING_AHEAD == 0 && Y355_RING_BASM ? rlds128(wbn + tt * 1024) : RD(wbn + tt * 1024);
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
+                        if (m + 2 < MT) af[m + 2] = RD(smem + abase[m + 2][acol] + soff + ko);
                         if (m == MT - 1 && t + 1 < SPC) {            // next step's first A fragments (same slab)
                             const int ko2 = ((t + 1) / 3) * PWL * 64;
                             const int acol2 = (t + 1) % 3;
-                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
-                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                            afp[0] = RD(smem + abase[0][acol2] + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = RD(smem + abase[1][acol2] + soff + ko2);
                         }
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
-                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                            MM(acc[m][tt], af[m], bfb[cur][tt]);
                     }
                 }
+#endif
             }
             // 9 steps: the last one (cur = 0) read the next chunk's first fragments into bfb[1]
             if constexpr (ROLL) {
