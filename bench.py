@@ -38,7 +38,7 @@ PEAK_I8_DENSE = 5.0e15                          # MI355X dense int8 MFMA (2x bf1
 LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7", "pred"]
 
 
-DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, false, false>"
+DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, false, false"   # prefix: the last template argument selects the epilogue (true = fp32)
 
 
 TRAFFIC_FILES = ["r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
@@ -722,7 +722,7 @@ def main():
                          "bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": round(dom_tops * 1e12 / PEAK_I8_DENSE, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": DOMINANT_KERNEL + " (conv6 and conv7: 2 launches/step, the largest share of "
+                         "kernel": DOMINANT_KERNEL + ", true> (conv6 and conv7: 2 launches/step, the largest share of "
                                    "the step of any kernel; int8 ops = 2 x 398.72e6 MAC x %d images per launch)" % B,
                          "launch_ms": round(dom_ms, 4),
                          "launch_ms_source": ("kernel start/end timestamps of the launch (hipExtLaunchKernelGGL events), mean of "
