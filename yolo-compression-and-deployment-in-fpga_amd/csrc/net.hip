@@ -231,6 +231,10 @@ struct NLayer {
     RequantG rq{};
     Requant rq1{};            // first layer (conv1.hip epilogue)
     bool dirty = true;
+    // bf16 3x3 layers that have a ring instantiation (convr.hip): its id and the weights in its fragment order
+    int rid = -1;
+    char *wr_dev = nullptr;
+    size_t wr_bytes = 0;
 };
 
 __global__ void pool_bf16_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int cbytes, int Ho, int Wo,
@@ -409,6 +413,9 @@ __global__ void absmax_bf16_kernel(const char *t, size_t n_elems, unsigned int *
 }
 }  // namespace
 
+#ifndef Y355_USE_CONVR
+#define Y355_USE_CONVR 1            // 0 (A/B builds): every layer of the generic nets on convg.hip
+#endif
 struct y355_net {
     y355_net_config cfg{};
     const ArchDef *arch = nullptr;
@@ -480,6 +487,7 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (N > 16 * Y355_NMS_CAP) return y355_fail(Y355_EINVAL, "more than 65536 anchors per image not supported");
     HIPCHK(hipSetDevice(cfg->device_id));
     if (int e = y355_prepare_kernels()) return e;
+    if (y355_prepare_convr(cfg->device_id)) return y355_fail(Y355_EHIP, "hipFuncSetAttribute(convr) / sink allocation failed");
     y355_net *h = new y355_net();
     h->cfg = *cfg;
     h->arch = &A;
@@ -541,6 +549,13 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
             }
             L.w_bytes = y355_convg_packed_bytes(ki, in_kbytes(h, o), o.ksize * o.ksize, L.cout_pad);
             rc = nmalloc(h, (void **)&L.w_dev, L.w_bytes, true);
+            if (!rc && h->bf && o.ksize == 3 && !o.stride2 && !o.res1 && Y355_USE_CONVR) {
+                L.rid = y355_convr_select(in_kbytes(h, o), L.cout_pad, o.pool, ti.H, ti.W);
+                if (L.rid >= 0) {
+                    L.wr_bytes = (size_t)(in_kbytes(h, o) / 64) * 9 * (L.cout_pad / 16) * 1024;
+                    rc = nmalloc(h, (void **)&L.wr_dev, L.wr_bytes, true);
+                }
+            }
         }
         if (!rc) rc = nmalloc(h, (void **)&L.bias_dev, sizeof(float) * L.cout_pad, true);
         if (!rc) rc = nmalloc(h, (void **)&L.bias_w_dev, sizeof(long long) * L.cout_pad, true);
@@ -638,6 +653,14 @@ extern "C" int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, con
         std::vector<char> packed(L.w_bytes);
         y355_convg_pack(ki, w, nullptr, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, packed.data());
         HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        if (L.rid >= 0) {                                      // the same fragments in the ring kernel's (bn, wn, nt) order
+            const Y355ConvRInfo &ri = *y355_convr_info(L.rid);
+            ConvGInfo kr{};
+            kr.bf = 1; kr.chb = 64; kr.bn = ri.bn; kr.wn = ri.wn; kr.nt = ri.nt;
+            std::vector<char> pr(L.wr_bytes);
+            y355_convg_pack(kr, w, nullptr, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, pr.data());
+            HIPCHK(hipMemcpy(L.wr_dev, pr.data(), pr.size(), hipMemcpyHostToDevice));
+        }
     }
     std::vector<float> bias(L.cout_pad, 0.f);
     if (b) memcpy(bias.data(), b, sizeof(float) * cout);
@@ -944,6 +967,15 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
         p.taps = o.ksize * o.ksize;
         p.slope = act_slope(o.act);
         p.out_f32 = to.pred && h->bf;
+        if (L.rid >= 0) {                                      // bf16 3x3: weights through an LDS ring (convr.hip)
+            ConvGParams q = p;
+            q.w = L.wr_dev;
+            q.nblk = L.cout_pad / y355_convr_info(L.rid)->bn;
+            if (y355_launch_convr(L.rid, q, h->cfg.device_id, s)) {
+                HIPCHK(hipGetLastError());
+                return 0;
+            }
+        }
         ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, s);
     } else if (o.type == OP_POOL) {
         const Tensor &ti = h->T[o.in], &to = h->T[o.out];
