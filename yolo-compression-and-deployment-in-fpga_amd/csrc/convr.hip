@@ -1,6 +1,7 @@
-// yolo355 -- 3x3 convolutions of the fp32 model families (bf16 MFMA, fp32 accumulate) on the LDS-DMA ring discipline of
-// conv3x3_ring.hip: utils.modules.Conv2d / Conv_BN_LeakyReLU with >= 32 input channels (models/slim_yolo_v2.py:386-622,
-// backbone/darknet.py:12-22), VERDICT r2 item 6.
+// yolo355 -- 3x3 convolutions of the generic nets (csrc/net.hip) on the LDS-DMA ring discipline of conv3x3_ring.hip, in both
+// arithmetic types of convg.hip: bf16 x bf16 -> fp32 for the fp32 model families (utils.modules.Conv2d / Conv_BN_LeakyReLU,
+// models/slim_yolo_v2.py:386-622, backbone/darknet.py:12-22) and int8 x int8 -> int32 with the general-slope integer
+// epilogue for the quantized YOLOv3tiny (models/tiny_yolo_v3.py:9-273).  VERDICT r2 item 6.
 //
 // convg8_kernel (convg.hip) stages the activations through registers into LDS and reads every B fragment straight from
 // global memory, two k-steps ahead: 16-32 KB per k-step and CU through the vector-memory pipe, every wave with the same
@@ -8,11 +9,12 @@
 // ring kernel: persistent 8-wave workgroups; 64-byte chunks of the input patch in a 2-slot LDS ring filled by LDS-DMA, one
 // 1 KiB piece per wave and k-step; weights in a 7-slot LDS ring, five k-steps in flight, loaded ONCE per workgroup; counted
 // vmcnt + one barrier per k-step; B fragments of step s + 1 read under the MFMAs of step s.  A k-step is 64 bytes of one
-// tap: 32 bf16 channels, v_mfma_f32_16x16x32_bf16.  Same fragment order as convg.hip (y355_convg_pack with this kernel's
+// tap: 32 bf16 channels (v_mfma_f32_16x16x32_bf16) or 64 int8 channels (v_mfma_i32_16x16x64_i8).  Same fragment order as convg.hip (y355_convg_pack with this kernel's
 // BN / WN / NT), same MFMA sequence per output element: results are bit-identical to convg8_kernel's.
-// Epilogue: bias + LeakyReLU slope in fp32 on the accumulators, 8-byte bf16 (or 16-byte fp32, prediction maps) stores of a
-// lane's four adjacent channels straight from registers (16 lanes = one 128-byte line of a pixel), 2x2 max first on pooled
-// tiles; the store count per tile is static (rows outside the map go to a sink) so that the next tile's counted waits hold.
+// Epilogue: bf16 -- bias + LeakyReLU slope in fp32 on the accumulators, 8-byte bf16 (or 16-byte fp32, prediction maps) stores
+// of a lane's four adjacent channels straight from registers (16 lanes = one 128-byte line of a pixel); int8 -- convg.hip's
+// integer pipeline (32-bit form where the host proved it fits, else 64-bit), 4-byte stores, saturation counted; 2x2 max first
+// on pooled tiles; the store count per tile is static (rows outside the map go to a sink) so that the next tile's counted waits hold.
 #include "y355_common.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
@@ -52,8 +54,9 @@ constexpr int PF = 5;
 }  // namespace
 
 // CINB = bytes per input pixel (a multiple of 64), BN output channels per workgroup
-template <int CINB, int BN, int TH, int TW, bool POOL, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, 1) void convr_bf16_kernel(const ConvGParams p, const int total_tiles, char *sink) {
+template <bool BF, int CINB, int BN, int TH, int TW, bool POOL, int WM, int WN, bool NARROW>
+__global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParams p, const int total_tiles, char *sink) {
+    using ACC = typename std::conditional<BF, v4f, v4i>::type;
     constexpr int NW = WM * WN;
     constexpr int NCH = CINB / 64, SPC = 9, KS = NCH * SPC;
     constexpr int PW = TW + 2, PH = TH + 2;
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_bf16_kernel(const ConvG
         else issue_w(nb, k - KS, k);                           // KS > PF for every layer here; keeps counts static
     }
     const float slope = p.slope;
+    const RequantG rq = p.rq;
     const int halo = p.out_halo;
+    unsigned int nsat = 0;
     bool first = true;
 
     for (;;) {
@@ -166,11 +171,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_bf16_kernel(const ConvG
             }
         }
 
-        v4f acc[MT][NT];
+        ACC acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (BF) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+                else acc[m][t] = (v4i){0, 0, 0, 0};
+            }
 
         // ---- pre-phase: publish W(0) (and slab 0) and read W(0)'s B fragments (vmcnt is in issue order: younger than W(0)
         // are W(1..PF), the slab pieces issued with them, and the previous tile's NIT output stores)
@@ -244,43 +252,74 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_bf16_kernel(const ConvG
                         if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
                     }
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-                        acc[m][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[m]), __builtin_bit_cast(v8bf, bfb[cur][tt]),
-                                                                             acc[m][tt], 0, 0, 0);
+                    for (int tt = 0; tt < NT; ++tt) {
+                        if constexpr (BF)
+                            acc[m][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[m]), __builtin_bit_cast(v8bf, bfb[cur][tt]),
+                                                                                 acc[m][tt], 0, 0, 0);
+                        else
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                    }
                 }
             }
             sl ^= 1;
         }
 
-        // ---- epilogue: bias + LeakyReLU, straight from the registers
+        // ---- epilogue straight from the registers (convg.hip's arithmetic, expression for expression)
         {
             int li_e = li, g_e = g;
             asm volatile("" : "+v"(li_e), "+v"(g_e));
             const int nlane = nb * BN + wn * (NT * 16) + li_e * NT;   // first of this lane's NT channels
             const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
             char *outb = p.out + (size_t)b * (Ho + 2 * halo) * (Wo + 2 * halo) * p.out_pb + p.out_off;
-            const v4f bias = *(const v4f *)(p.bias_f + nlane);
             char *snk = sink + tid * 16;
-            auto finish = [&](const float (&v)[NT], bool valid, int oy, int ox) {
-                float y[NT];
+            float biasf[NT];
+            long long biasw[NT];
+            int biasn[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float x = v[t] + bias[t];
-                    y[t] = x >= 0.f ? x : x * slope;
-                }
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (BF) { biasf[t] = p.bias_f[nlane + t]; biasw[t] = 0; }
+                else { biasw[t] = p.bias_w[nlane + t]; biasf[t] = 0.f; }
+                biasn[t] = (int)biasw[t];
+            }
+            Requant rqn{};
+            rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul;
+            auto finish = [&](const float (&vf)[NT], const int (&vi)[NT], bool valid, int oy, int ox) {
                 char *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.out_pb;
-                if (p.out_f32) {
-                    dst = valid ? dst + (size_t)nlane * 4 : snk;
-                    *(v4f *)dst = (v4f){y[0], y[1], y[2], y[3]};
-                } else {
-                    dst = valid ? dst + (size_t)nlane * 2 : snk;
-                    unsigned short hh[NT];
+                if constexpr (BF) {
+                    float y[NT];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) hh[t] = __builtin_bit_cast(unsigned short, (__bf16)y[t]);
-                    uint2 u;
-                    u.x = (unsigned int)hh[0] | ((unsigned int)hh[1] << 16);
-                    u.y = (unsigned int)hh[2] | ((unsigned int)hh[3] << 16);
-                    *(uint2 *)dst = u;
+                    for (int t = 0; t < NT; ++t) {
+                        const float x = vf[t] + biasf[t];
+                        y[t] = x >= 0.f ? x : x * slope;
+                    }
+                    if (p.out_f32) {
+                        dst = valid ? dst + (size_t)nlane * 4 : snk;
+                        *(v4f *)dst = (v4f){y[0], y[1], y[2], y[3]};
+                    } else {
+                        dst = valid ? dst + (size_t)nlane * 2 : snk;
+                        unsigned short hh[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) hh[t] = __builtin_bit_cast(unsigned short, (__bf16)y[t]);
+                        uint2 u;
+                        u.x = (unsigned int)hh[0] | ((unsigned int)hh[1] << 16);
+                        u.y = (unsigned int)hh[2] | ((unsigned int)hh[3] << 16);
+                        *(uint2 *)dst = u;
+                    }
+                } else {
+                    int q[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (NARROW) {
+                            const int qq = y355_requant_gen32(vi[t], biasn[t], rqn);
+                            q[t] = y355_clamp8<int>(qq);
+                            nsat += (valid && q[t] != qq) ? 1u : 0u;
+                        } else {
+                            static_assert(BF || NARROW, "the 64-bit epilogue lives in convg.hip only");
+                            q[t] = 0;
+                        }
+                    }
+                    dst = valid ? dst + nlane : snk;
+                    *(unsigned int *)dst = (unsigned int)((q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24));
                 }
             };
 #pragma unroll
@@ -290,13 +329,15 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_bf16_kernel(const ConvG
                     const int wy = w / (TW / 2), wx = w % (TW / 2);
                     const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
                     const bool valid = (w * 4 < BM) && oy < Ho && ox < Wo;
-                    float v[NT];
+                    float vf[NT];
+                    int vi[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const v4f a = acc[m][t];
-                        v[t] = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+                        const ACC a = acc[m][t];
+                        if constexpr (BF) { vf[t] = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])); vi[t] = 0; }
+                        else { vi[t] = max(max(a[0], a[1]), max(a[2], a[3])); vf[t] = 0.f; }
                     }
-                    finish(v, valid, oy, ox);
+                    finish(vf, vi, valid, oy, ox);
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
 #pragma unroll
@@ -304,10 +345,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_bf16_kernel(const ConvG
                         const int row = (wm * MT + m) * 16 + 4 * g_e + r;
                         const int oy = y0 + row / TW, ox = x0 + row % TW;
                         const bool valid = row < BM && oy < Ho && ox < Wo;
-                        float v[NT];
+                        float vf[NT];
+                        int vi[NT];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) v[t] = acc[m][t][r];
-                        finish(v, valid, oy, ox);
+                        for (int t = 0; t < NT; ++t) {
+                            if constexpr (BF) { vf[t] = acc[m][t][r]; vi[t] = 0; }
+                            else { vi[t] = acc[m][t][r]; vf[t] = 0.f; }
+                        }
+                        finish(vf, vi, valid, oy, ox);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -319,21 +364,25 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_bf16_kernel(const ConvG
         b = b2; y0 = y2; x0 = x2; nb = nb2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // retire the prefetches before the wave ends
+    if constexpr (!BF) {
+        if (nsat && p.ctr) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 namespace {
 char *g_sink[16] = {};                                         // per device: where the masked rows' stores go
 
-template <int CINB, int BN, int TH, int TW, bool POOL, int WM, int WN>
+template <bool BF, int CINB, int BN, int TH, int TW, bool POOL, int WM, int WN>
 struct ConvRInst {
     static constexpr int PWL = (TW + 2 + 7) / 8 * 8;
     static constexpr int SLABB = ((TH + 2) * PWL * 64 + 1023) / 1024 * 1024;
     static constexpr int WB = (BN / 16) * 1024;
     static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(PF + 2) * WB + 1024;
-    static constexpr Y355ConvRInfo info() { return Y355ConvRInfo{CINB, BN, TH, TW, POOL ? 1 : 0, WN, BN / 16 / WN}; }
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static constexpr Y355ConvRInfo info() { return Y355ConvRInfo{BF ? 1 : 0, CINB, BN, TH, TW, POOL ? 1 : 0, WN, BN / 16 / WN}; }
     static int prepare() {
-        return (int)hipFuncSetAttribute((const void *)convr_bf16_kernel<CINB, BN, TH, TW, POOL, WM, WN>,
+        return (int)hipFuncSetAttribute((const void *)convr_kernel<BF, CINB, BN, TH, TW, POOL, WM, WN, !BF>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     static bool launch(const ConvGParams &p_in, int device, hipStream_t s) {
@@ -342,19 +391,26 @@ struct ConvRInst {
         p.tiles_y = (p.H + TH - 1) / TH;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
         const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
-        hipLaunchKernelGGL((convr_bf16_kernel<CINB, BN, TH, TW, POOL, WM, WN>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total, g_sink[device]);
+        // int8: only the 32-bit epilogue is built here; a layer that needs the 64-bit one (rq.narrow == 0: 96 accumulators plus
+        // 64-bit temporaries spill 1.2 KB per lane and the launch is 2.4x slower than convg8's, profiles/r03_notes.md) stays on convg.hip
+        if (!BF && !p.rq.narrow) return false;
+        hipLaunchKernelGGL((convr_kernel<BF, CINB, BN, TH, TW, POOL, WM, WN, !BF>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total, g_sink[device]);
         return true;
     }
 };
-//                        CINB  BN  TH  TW  POOL  WM WN      SlimYOLOv2 fp32 (bf16: 2 bytes per channel)
-using R0 = ConvRInst<64, 64, 13, 26, false, 8, 1>;     // 32 ->  64                     conv3_1
-using R1 = ConvRInst<128, 64, 26, 26, true, 8, 1>;     // 64 ->  64 (n-blocks of 64), pooled    conv3_2
-using R2 = ConvRInst<128, 128, 13, 26, false, 4, 2>;   // 64 -> 128                     conv4_1
-using R3 = ConvRInst<256, 64, 26, 26, true, 8, 1>;     // 128 -> 128, pooled            conv4_2
-using R4 = ConvRInst<256, 128, 13, 26, false, 4, 2>;   // 128 -> 256                    conv5
-using R5 = ConvRInst<512, 128, 13, 26, false, 4, 2>;   // 256 -> 256                    conv6, conv7
-constexpr int NR = 6;
-constexpr Y355ConvRInfo g_info[NR] = {R0::info(), R1::info(), R2::info(), R3::info(), R4::info(), R5::info()};
+//                         BF   CINB  BN  TH  TW  POOL  WM WN     SlimYOLOv2 fp32 (bf16: 2 bytes per channel)
+using R0 = ConvRInst<true, 64, 64, 13, 26, false, 8, 1>;     // 32 ->  64                     conv3_1
+using R1 = ConvRInst<true, 128, 64, 26, 26, true, 8, 1>;     // 64 ->  64, pooled             conv3_2
+using R2 = ConvRInst<true, 128, 128, 13, 26, false, 4, 2>;   // 64 -> 128                     conv4_1
+using R3 = ConvRInst<true, 256, 64, 26, 26, true, 8, 1>;     // 128 -> 128, pooled            conv4_2
+using R4 = ConvRInst<true, 256, 128, 13, 26, false, 4, 2>;   // 128 -> 256                    conv5
+using R5 = ConvRInst<true, 512, 128, 13, 26, false, 4, 2>;   // 256 -> 256                    conv6, conv7
+//                                                              YOLOv3tiny int8 (1 byte per channel)
+// (measured and dropped: 128 -> 256 and 384 -> 256 on 13 x 26 tiles, 512 -> 1024 on 13 x 13: not faster than convg8)
+using I0 = ConvRInst<false, 64, 64, 26, 26, true, 8, 1>;     // 64 -> 128, pooled             conv_4
+using I1 = ConvRInst<false, 256, 256, 13, 13, false, 2, 4>;  // 256 -> 512 on 13 x 13 maps    extra_conv_2 (conv_6 when it fits 32 bits)
+constexpr int NR = 8;
+constexpr Y355ConvRInfo g_info[NR] = {R0::info(), R1::info(), R2::info(), R3::info(), R4::info(), R5::info(), I0::info(), I1::info()};
 }  // namespace
 
 int y355_prepare_convr(int device) {
@@ -368,24 +424,29 @@ int y355_prepare_convr(int device) {
     if (!e) e = R3::prepare();
     if (!e) e = R4::prepare();
     if (!e) e = R5::prepare();
+    if (!e) e = I0::prepare();
+    if (!e) e = I1::prepare();
     return e;
 }
 
 const Y355ConvRInfo *y355_convr_info(int rid) { return rid >= 0 && rid < NR ? &g_info[rid] : nullptr; }
 
-// ring instantiation for a bf16 3x3 / stride-1 layer with in_pb bytes per input pixel and cout_pad output channels (-1: none)
-int y355_convr_select(int in_pb, int cout_pad, int pool, int H, int W) {
+// ring instantiation for a 3x3 / stride-1 layer with in_pb bytes per input pixel and cout_pad output channels (-1: none)
+int y355_convr_select(int bf, int in_pb, int cout_pad, int pool, int H, int W) {
     if (pool && ((H | W) & 1)) return -1;
     for (int i = 0; i < NR; ++i)
-        if (g_info[i].cinb == in_pb && g_info[i].pool == pool && cout_pad % g_info[i].bn == 0 && H >= g_info[i].th && W >= g_info[i].tw) return i;
+        if (g_info[i].bf == (bf ? 1 : 0) && g_info[i].cinb == in_pb && g_info[i].pool == pool && cout_pad % g_info[i].bn == 0 &&
+            H >= g_info[i].th && W >= g_info[i].tw) return i;
     return -1;
 }
 
 // p.w = y355_convg_pack order with (bn, wn, nt) of y355_convr_info(rid); false = not launched (the caller runs convg.hip)
 bool y355_launch_convr(int rid, const ConvGParams &p, int device, hipStream_t s) {
     if (rid < 0 || rid >= NR || device < 0 || device >= 16 || !g_sink[device]) return false;
-    if (p.taps != 9 || p.res || p.in_pb != g_info[rid].cinb || !p.bias_f) return false;
-    if (((p.out_off | p.out_pb) & (p.out_f32 ? 15 : 7)) != 0) return false;
+    const Y355ConvRInfo &ri = g_info[rid];
+    if (p.taps != 9 || p.res || p.in_pb != ri.cinb) return false;
+    if (ri.bf ? !p.bias_f : !p.bias_w) return false;
+    if (((p.out_off | p.out_pb) & (ri.bf ? (p.out_f32 ? 15 : 7) : 3)) != 0) return false;
     switch (rid) {
     case 0: return R0::launch(p, device, s);
     case 1: return R1::launch(p, device, s);
@@ -393,6 +454,8 @@ bool y355_launch_convr(int rid, const ConvGParams &p, int device, hipStream_t s)
     case 3: return R3::launch(p, device, s);
     case 4: return R4::launch(p, device, s);
     case 5: return R5::launch(p, device, s);
+    case 6: return I0::launch(p, device, s);
+    case 7: return I1::launch(p, device, s);
     default: return false;
     }
 }

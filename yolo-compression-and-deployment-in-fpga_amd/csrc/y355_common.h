@@ -333,11 +333,11 @@ int y355_convg_ksteps(const ConvGInfo &ki, int in_pb, int taps);
 size_t y355_convg_packed_bytes(const ConvGInfo &ki, int in_pb, int taps, int cout_pad);
 void y355_convg_pack(const ConvGInfo &ki, const float *w_f, const int8_t *w_q, int cout, int cin, int ksize,
                      int in_pb, int cout_pad, char *dst);
-// bf16 3x3 layers on the LDS-DMA ring discipline (convr.hip); weights in y355_convg_pack order for (bn, wn, nt) below
-struct Y355ConvRInfo { int cinb, bn, th, tw, pool, wn, nt; };
+// 3x3 layers of the generic nets on the LDS-DMA ring discipline (convr.hip); weights in y355_convg_pack order for (bn, wn, nt) below
+struct Y355ConvRInfo { int bf, cinb, bn, th, tw, pool, wn, nt; };
 int y355_prepare_convr(int device);
 const Y355ConvRInfo *y355_convr_info(int rid);
-int y355_convr_select(int in_pb, int cout_pad, int pool, int H, int W);
+int y355_convr_select(int bf, int in_pb, int cout_pad, int pool, int H, int W);
 bool y355_launch_convr(int rid, const ConvGParams &p, int device, hipStream_t s);
 void y355_conv1f_tiles(int H, int W, int *tx, int *ty);
 void y355_launch_conv1f(const Conv1FParams &p, hipStream_t s);
