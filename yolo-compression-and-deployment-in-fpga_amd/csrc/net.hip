@@ -232,6 +232,7 @@ struct NLayer {
     Requant rq1{};            // first layer (conv1.hip epilogue)
     bool dirty = true;
     // 3x3 layers that have a ring instantiation (convr.hip): its id and the weights in its fragment order
+    long long wabs = 0;       // int8: max over output channels of sum |q_w| (0 = unknown)
     int rid = -1;
     char *wr_dev = nullptr;
     size_t wr_bytes = 0;
@@ -707,6 +708,16 @@ extern "C" int y355_net_load_layer_i8(y355_net *h, int idx, const int8_t *q_w, c
     L.q_b.assign(q_b, q_b + cout);
     L.e_w = e_w;
     L.e_b = e_b;
+    {   // max over output channels of sum |q_w|: the layer's own bound on |acc| (127 * wabs) for the 32-bit-epilogue test
+        long long wabs = 0;
+        const size_t per = (size_t)cin * ksize * ksize;
+        for (int c = 0; c < cout; ++c) {
+            long long s = 0;
+            for (size_t k = 0; k < per; ++k) s += std::abs((int)q_w[(size_t)c * per + k]);
+            wabs = std::max(wabs, s);
+        }
+        L.wabs = wabs;
+    }
     L.loaded = true;
     L.dirty = true;
     return 0;
@@ -779,7 +790,9 @@ static int refresh_i8(y355_net *h) {
         L.rq.neg_mul = nm;
         {
             // 32-bit epilogue (y355_requant_gen32) when |t| * max(2^max(0, lk - sh), neg_mul * 2^max(0, -sh)) + rounding < 2^31
-            long double t32 = ((long double)127 * 127 * o.ksize * o.ksize * o.cin) * std::ldexp(1.0L, shl) + bmax;
+            // |acc| <= 127 * (sum |q_w| of the channel): the layer's own weights give a tighter bound than 127 per weight
+            const long double accmax = L.wabs > 0 ? (long double)127 * L.wabs : (long double)127 * 127 * o.ksize * o.ksize * o.cin;
+            long double t32 = accmax * std::ldexp(1.0L, shl) + bmax;
             const long double fpos = std::ldexp(1.0L, std::max(0, lk - sh)), fneg = (long double)nm * std::ldexp(1.0L, std::max(0, -sh));
             t32 = t32 * std::max(fpos, fneg) + std::ldexp(1.0L, std::max(sh, 0));
             L.rq.narrow = (t32 < std::ldexp(1.0L, 31) && bmax < std::ldexp(1.0L, 31)) ? 1 : 0;
