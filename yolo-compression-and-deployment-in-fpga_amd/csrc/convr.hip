@@ -370,6 +370,85 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
 }
 
 // ------------------------------------------------------------------------------------------
+// 1x1 convolutions of the int8 nets (conv_1x1_2, pred_1, pred_2 of YOLOv3tiny, models/tiny_yolo_v3.py:31-39): convg.hip stages a
+// 3x3-haloed patch per tile for them (26-36 us per launch for 5-13 MMAC per image).  Here a workgroup keeps the fragments of ONE
+// block of 64 output channels in LDS (all k-steps), a wave takes 16 consecutive pixels of the batch at a time, reads their
+// channels straight from global memory as A fragments (all k-steps in flight together) and stores four adjacent channels of
+// four pixels per lane.  Fragment and k order are convg.hip's, the epilogue is its 32-bit general-slope form: bit-identical.
+template <int MAXKS>
+__global__ __launch_bounds__(256) void pw_i8_kernel(const ConvGParams p, const int npix, const int ks_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int nb = blockIdx.x % p.nblk, wg = blockIdx.x / p.nblk, nwg = gridDim.x / p.nblk;
+    const char *wsrc = p.w + (size_t)nb * ks_n * 4 * 1024;
+    for (int i = tid; i < ks_n * 4 * 64; i += 256) *(v4i *)(smem + i * 16) = *(const v4i *)(wsrc + (size_t)i * 16);
+    __syncthreads();
+    const int H = p.H, W = p.W, HW = H * W;
+    int biasn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) biasn[t] = (int)p.bias_w[nb * 64 + li * 4 + t];
+    Requant rqn{};
+    rqn.shl = p.rq.shl; rqn.sh = p.rq.sh; rqn.lk = p.rq.lk; rqn.neg_mul = p.rq.neg_mul;
+    unsigned int nsat = 0;
+    const int ngroups = (npix + 15) / 16;
+    for (int grp = wg * 4 + wave; grp < ngroups; grp += nwg * 4) {
+        const int pi = min(grp * 16 + li, npix - 1);
+        const int b = pi / HW, r = pi - b * HW, y = r / W, x = r - y * W;
+        const char *src = p.in + (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * p.in_pb + g * 16;
+        v4i a[MAXKS];
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks)
+            if (ks < ks_n) a[ks] = *(const v4i *)(src + ks * 64);
+        v4i acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (v4i){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) {
+            if (ks < ks_n) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const v4i bq = *(const v4i *)(smem + ((ks * 4 + t) * 64 + lane) * 16);
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], bq, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // row 4 g + rr of the group = pixel, column li = channels 64 nb + 4 li .. + 3 (n-tile t = channel 4 li + t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int po = grp * 16 + 4 * g + rr;
+            if (po >= npix) continue;
+            const int bo = po / HW, ro = po - bo * HW, yo = ro / W, xo = ro - yo * W;
+            char *dst = p.out + (((size_t)bo * (H + 2 * p.out_halo) + yo + p.out_halo) * (W + 2 * p.out_halo) + xo + p.out_halo) * p.out_pb + p.out_off +
+                        nb * 64 + li * 4;
+            int q[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int qq = y355_requant_gen32(acc[t][rr], biasn[t], rqn);
+                q[t] = y355_clamp8<int>(qq);
+                nsat += q[t] != qq ? 1u : 0u;
+            }
+            *(unsigned int *)dst = (unsigned int)((q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24));
+        }
+    }
+    if (nsat && p.ctr) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
+}
+
+// p.w = y355_convg_pack order for (bn 64, wn 1, nt 4), taps 1, p.nblk = cout_pad / 64; false = not launched
+bool y355_launch_pw_i8(const ConvGParams &p, hipStream_t s) {
+    if (p.taps != 1 || p.res || !p.bias_w || !p.rq.narrow || p.nblk < 1 || p.in_pb % 64 || p.in_pb > 1024) return false;
+    if (((p.out_off | p.out_pb) & 3) != 0) return false;
+    if ((long long)p.B * p.H * p.W >= (1ll << 30)) return false;
+    const int ks_n = p.in_pb / 64, npix = p.B * p.H * p.W;
+    int per_nb = (npix + 63) / 64;                               // workgroups per n-block: 64 pixels per pass of its four waves
+    if (per_nb * p.nblk > 2048) per_nb = 2048 / p.nblk;
+    const size_t lds = (size_t)ks_n * 4 * 1024;
+    if (ks_n <= 8) hipLaunchKernelGGL(pw_i8_kernel<8>, dim3(per_nb * p.nblk), dim3(256), lds, s, p, npix, ks_n);
+    else hipLaunchKernelGGL(pw_i8_kernel<16>, dim3(per_nb * p.nblk), dim3(256), lds, s, p, npix, ks_n);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
 namespace {
 char *g_sink[16] = {};                                         // per device: where the masked rows' stores go
 

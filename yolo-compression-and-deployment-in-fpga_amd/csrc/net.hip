@@ -550,6 +550,12 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
             }
             L.w_bytes = y355_convg_packed_bytes(ki, in_kbytes(h, o), o.ksize * o.ksize, L.cout_pad);
             rc = nmalloc(h, (void **)&L.w_dev, L.w_bytes, true);
+            if (!rc && !h->bf && o.ksize == 1 && !o.stride2 && !o.res1 && L.cout_pad % 64 == 0 && in_kbytes(h, o) % 64 == 0 && in_kbytes(h, o) <= 1024 &&
+                Y355_USE_CONVR) {                              // int8 1x1: pointwise kernel of convr.hip (when the epilogue fits 32 bits)
+                L.rid = -2;
+                L.wr_bytes = (size_t)(in_kbytes(h, o) / 64) * (L.cout_pad / 16) * 1024;
+                rc = nmalloc(h, (void **)&L.wr_dev, L.wr_bytes, true);
+            }
             if (!rc && o.ksize == 3 && !o.stride2 && !o.res1 && Y355_USE_CONVR) {
                 L.rid = y355_convr_select(h->bf ? 1 : 0, in_kbytes(h, o), L.cout_pad, o.pool, ti.H, ti.W);
                 if (L.rid >= 0) {
@@ -696,10 +702,13 @@ extern "C" int y355_net_load_layer_i8(y355_net *h, int idx, const int8_t *q_w, c
         std::vector<char> packed(L.w_bytes);
         y355_convg_pack(ki, nullptr, q_w, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, packed.data());
         HIPCHK(hipMemcpy(L.w_dev, packed.data(), packed.size(), hipMemcpyHostToDevice));
-        if (L.rid >= 0) {                                      // the same fragments in the ring kernel's (bn, wn, nt) order
-            const Y355ConvRInfo &ri = *y355_convr_info(L.rid);
+        if (L.rid >= 0 || L.rid == -2) {                       // the same fragments in the ring / pointwise kernel's (bn, wn, nt) order
             ConvGInfo kr{};
-            kr.bf = 0; kr.chb = 64; kr.bn = ri.bn; kr.wn = ri.wn; kr.nt = ri.nt;
+            kr.bf = 0; kr.chb = 64; kr.bn = 64; kr.wn = 1; kr.nt = 4;
+            if (L.rid >= 0) {
+                const Y355ConvRInfo &ri = *y355_convr_info(L.rid);
+                kr.bn = ri.bn; kr.wn = ri.wn; kr.nt = ri.nt;
+            }
             std::vector<char> pr(L.wr_bytes);
             y355_convg_pack(kr, nullptr, q_w, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, pr.data());
             HIPCHK(hipMemcpy(L.wr_dev, pr.data(), pr.size(), hipMemcpyHostToDevice));
@@ -988,6 +997,15 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
         p.taps = o.ksize * o.ksize;
         p.slope = act_slope(o.act);
         p.out_f32 = to.pred && h->bf;
+        if (L.rid == -2) {                                     // int8 1x1: pointwise kernel (convr.hip)
+            ConvGParams q = p;
+            q.w = L.wr_dev;
+            q.nblk = L.cout_pad / 64;
+            if (y355_launch_pw_i8(q, s)) {
+                HIPCHK(hipGetLastError());
+                return 0;
+            }
+        }
         if (L.rid >= 0) {                                      // 3x3: weights through an LDS ring (convr.hip)
             ConvGParams q = p;
             q.w = L.wr_dev;

@@ -339,6 +339,7 @@ int y355_prepare_convr(int device);
 const Y355ConvRInfo *y355_convr_info(int rid);
 int y355_convr_select(int bf, int in_pb, int cout_pad, int pool, int H, int W);
 bool y355_launch_convr(int rid, const ConvGParams &p, int device, hipStream_t s);
+bool y355_launch_pw_i8(const ConvGParams &p, hipStream_t s);        // 1x1, int8, 32-bit epilogue; weights packed for (bn 64, wn 1, nt 4)
 void y355_conv1f_tiles(int H, int W, int *tx, int *ty);
 void y355_launch_conv1f(const Conv1FParams &p, hipStream_t s);
 void y355_pack_conv1f(const float *w, char *dst);
