@@ -486,12 +486,14 @@ using R4 = ConvRInst<true, 256, 128, 13, 26, false, 4, 2>;   // 128 -> 256      
 using R5 = ConvRInst<true, 512, 128, 13, 26, false, 4, 2>;   // 256 -> 256                    conv6, conv7
 using R6 = ConvRInst<true, 512, 64, 13, 13, false, 8, 1>;    // 256 -> <= 64 (fp32 out)       pred
 //                                                              YOLOv3tiny int8 (1 byte per channel)
-// (measured and dropped: 128 -> 256 and 384 -> 256 on 13 x 26 tiles, 512 -> 1024 on 13 x 13: not faster than convg8)
+// (the 64-bit-epilogue layers conv_6 / conv_7 stay on convg8: in this kernel 96 accumulators + 64-bit temporaries spill)
 using I0 = ConvRInst<false, 64, 64, 26, 26, true, 8, 1>;     // 64 -> 128, pooled             conv_4
 using I1 = ConvRInst<false, 256, 256, 13, 13, false, 2, 4>;  // 256 -> 512 on 13 x 13 maps    extra_conv_2 (conv_6 when it fits 32 bits)
 using I2 = ConvRInst<false, 128, 128, 13, 26, false, 4, 2>;  // 128 -> 256                    conv_5 (when it fits 32 bits)
-constexpr int NR = 10;
-constexpr Y355ConvRInfo g_info[NR] = {R0::info(), R1::info(), R2::info(), R3::info(), R4::info(), R5::info(), I0::info(), I1::info(), R6::info(), I2::info()};
+using I3 = ConvRInst<false, 384, 128, 13, 26, false, 4, 2>;  // 384 -> 256                    conv_set_1
+constexpr int NR = 11;
+constexpr Y355ConvRInfo g_info[NR] = {R0::info(), R1::info(), R2::info(), R3::info(), R4::info(), R5::info(), I0::info(), I1::info(), R6::info(), I2::info(),
+                                      I3::info()};
 }  // namespace
 
 int y355_prepare_convr(int device) {
@@ -509,6 +511,7 @@ int y355_prepare_convr(int device) {
     if (!e) e = I1::prepare();
     if (!e) e = R6::prepare();
     if (!e) e = I2::prepare();
+    if (!e) e = I3::prepare();
     return e;
 }
 
@@ -541,6 +544,7 @@ bool y355_launch_convr(int rid, const ConvGParams &p, int device, hipStream_t s)
     case 7: return I1::launch(p, device, s);
     case 8: return R6::launch(p, device, s);
     case 9: return I2::launch(p, device, s);
+    case 10: return I3::launch(p, device, s);
     default: return false;
     }
 }
