@@ -82,3 +82,25 @@ def test_range_tracker_state_machine():
     e = t.update(np.float32(0.5), False)                  # EMA (:31)
     s = torch.tensor([127 / np.float32(2.64)], dtype=torch.float32) * (1 - 0.1) + (127 / torch.tensor(0.5)) * 0.1
     assert e == int(torch.floor(torch.log2(s)).item())
+
+
+def test_split_product_requant_is_exact():
+    """y355_requant_gen32 with Requant::split (csrc/y355_common.h): the negative branch's t * neg_mul taken as 256 A + rem with
+    A = (t >> 8) * neg_mul + ((t & 255) * neg_mul >> 8) and the remainder as a sticky bit equals RNE(t * neg_mul / 2^sh) computed
+    in 64 bits -- for the slope 205 / 2048 of the int8 YOLOv3tiny and every shift the host admits (9 .. 31), around the ties."""
+    rng = np.random.default_rng(5)
+    for nm in (205, 1, 3, 2047):
+        for sh in range(9, 32):
+            base = rng.integers(-2 ** 30 + 1, 1, 200000)
+            k = rng.integers(-2 ** 30 // (1 << sh) * 0, 2 ** 12, 4000)
+            ties = -(((2 * k + 1) << (sh - 1)) // nm)[:, None] + np.arange(-3, 4)[None, :]      # t * nm near odd multiples of 2^(sh-1)
+            t = np.concatenate([base, ties.ravel(), -np.arange(0, 70000)]).astype(np.int64)
+            t = t[(t <= 0) & (t > -2 ** 30)]
+            P = t * nm
+            ref = (P + (1 << (sh - 1)) - 1 + ((P >> sh) & 1)) >> sh                                # 64-bit RNE shift
+            hi, m2 = t >> 8, (t & 255) * nm
+            A = hi * nm + (m2 >> 8)
+            s = sh - 8
+            got = (A + (1 << (s - 1)) - 1 + ((((m2 & 255) + 255) >> 8) | ((A >> s) & 1))) >> s
+            assert np.abs(A).max() < 2 ** 31 or nm == 2047                                         # the host's bound for 205 / 2048
+            assert np.array_equal(got, ref), (nm, sh)

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void convg_kernel(const ConvGParams p) {
     const float slope = p.slope;
     const RequantG rq = p.rq;
     Requant rqn{};
-    rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul;
+    rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul; rqn.split = rq.split;
 
     auto finish = [&](const float (&vf)[NT], const int (&vi)[NT], bool valid, int oy, int ox) {
         char *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.out_pb;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(WM * WN * 64) void convg8_kernel(const ConvGParams 
 #pragma unroll
         for (int t = 0; t < NT; ++t) biasn[t] = (int)biasw[t];
         Requant rqn{};
-        rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul;
+        rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul; rqn.split = rq.split;
 
         auto finish = [&](const float (&vf)[NT], const int (&vi)[NT], bool valid, int oy, int ox) {
             char *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.out_pb;

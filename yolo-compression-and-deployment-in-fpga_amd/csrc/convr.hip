@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
                 biasn[t] = (int)biasw[t];
             }
             Requant rqn{};
-            rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul;
+            rqn.shl = rq.shl; rqn.sh = rq.sh; rqn.lk = rq.lk; rqn.neg_mul = rq.neg_mul; rqn.split = rq.split;
             auto finish = [&](const float (&vf)[NT], const int (&vi)[NT], bool valid, int oy, int ox) {
                 char *dst = outb + ((size_t)(oy + halo) * (Wo + 2 * halo) + ox + halo) * p.out_pb;
                 if constexpr (BF) {
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void pw_i8_kernel(const ConvGParams p, const i
 #pragma unroll
     for (int t = 0; t < 4; ++t) biasn[t] = (int)p.bias_w[nb * 64 + li * 4 + t];
     Requant rqn{};
-    rqn.shl = p.rq.shl; rqn.sh = p.rq.sh; rqn.lk = p.rq.lk; rqn.neg_mul = p.rq.neg_mul;
+    rqn.shl = p.rq.shl; rqn.sh = p.rq.sh; rqn.lk = p.rq.lk; rqn.neg_mul = p.rq.neg_mul; rqn.split = p.rq.split;
     unsigned int nsat = 0;
     const int ngroups = (npix + 15) / 16;
     for (int grp = wg * 4 + wave; grp < ngroups; grp += nwg * 4) {
@@ -486,14 +486,15 @@ using R4 = ConvRInst<true, 256, 128, 13, 26, false, 4, 2>;   // 128 -> 256      
 using R5 = ConvRInst<true, 512, 128, 13, 26, false, 4, 2>;   // 256 -> 256                    conv6, conv7
 using R6 = ConvRInst<true, 512, 64, 13, 13, false, 8, 1>;    // 256 -> <= 64 (fp32 out)       pred
 //                                                              YOLOv3tiny int8 (1 byte per channel)
-// (the 64-bit-epilogue layers conv_6 / conv_7 stay on convg8: in this kernel 96 accumulators + 64-bit temporaries spill)
+// (a layer that needs the 64-bit epilogue stays on convg8: in this kernel 96 accumulators + 64-bit temporaries spill)
 using I0 = ConvRInst<false, 64, 64, 26, 26, true, 8, 1>;     // 64 -> 128, pooled             conv_4
 using I1 = ConvRInst<false, 256, 256, 13, 13, false, 2, 4>;  // 256 -> 512 on 13 x 13 maps    extra_conv_2 (conv_6 when it fits 32 bits)
 using I2 = ConvRInst<false, 128, 128, 13, 26, false, 4, 2>;  // 128 -> 256                    conv_5 (when it fits 32 bits)
 using I3 = ConvRInst<false, 384, 128, 13, 26, false, 4, 2>;  // 384 -> 256                    conv_set_1
-constexpr int NR = 11;
+using I4 = ConvRInst<false, 512, 256, 13, 13, false, 2, 4>;  // 512 -> 1024 on 13 x 13 maps   conv_7
+constexpr int NR = 12;
 constexpr Y355ConvRInfo g_info[NR] = {R0::info(), R1::info(), R2::info(), R3::info(), R4::info(), R5::info(), I0::info(), I1::info(), R6::info(), I2::info(),
-                                      I3::info()};
+                                      I3::info(), I4::info()};
 }  // namespace
 
 int y355_prepare_convr(int device) {
@@ -512,6 +513,7 @@ int y355_prepare_convr(int device) {
     if (!e) e = R6::prepare();
     if (!e) e = I2::prepare();
     if (!e) e = I3::prepare();
+    if (!e) e = I4::prepare();
     return e;
 }
 
@@ -545,6 +547,7 @@ bool y355_launch_convr(int rid, const ConvGParams &p, int device, hipStream_t s)
     case 8: return R6::launch(p, device, s);
     case 9: return I2::launch(p, device, s);
     case 10: return I3::launch(p, device, s);
+    case 11: return I4::launch(p, device, s);
     default: return false;
     }
 }

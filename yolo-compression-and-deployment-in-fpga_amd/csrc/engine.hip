@@ -138,6 +138,7 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     rq->sh_r = sh > 0 ? sh : 0;
     rq->hm1 = sh > 0 ? (int)((1ll << (sh - 1)) - 1) : 0;
     rq->bw = sh > 0 ? 1 : 0;
+    rq->split = 0;
     int g = 15 + Fp - retune;
     rq->guard_log2 = g < 0 ? 0 : (g > 63 ? 63 : g);
     *frac_bits = Fp;

@@ -805,6 +805,15 @@ static int refresh_i8(y355_net *h) {
             const long double fpos = std::ldexp(1.0L, std::max(0, lk - sh)), fneg = (long double)nm * std::ldexp(1.0L, std::max(0, -sh));
             t32 = t32 * std::max(fpos, fneg) + std::ldexp(1.0L, std::max(sh, 0));
             L.rq.narrow = (t32 < std::ldexp(1.0L, 31) && bmax < std::ldexp(1.0L, 31)) ? 1 : 0;
+            L.rq.split = 0;
+            if (!L.rq.narrow && sh >= 9 && sh <= 31 && nm >= 1 && nm < 4096) {
+                // t itself and the positive branch fit 32 bits, only t * neg_mul does not: the negative branch goes in two halves
+                const long double tb = accmax * std::ldexp(1.0L, shl) + bmax;
+                const long double pos = tb * fpos + std::ldexp(1.0L, std::max(sh - lk, 0));
+                const long double neg = (tb / 256 + 1) * nm + 256 + std::ldexp(1.0L, sh - 9);
+                if (tb < std::ldexp(1.0L, 30) && pos < std::ldexp(1.0L, 31) && neg < std::ldexp(1.0L, 31) && bmax < std::ldexp(1.0L, 31))
+                    L.rq.narrow = L.rq.split = 1;
+            }
         }
         L.rq1 = Requant{};
         L.rq1.shl = shl;

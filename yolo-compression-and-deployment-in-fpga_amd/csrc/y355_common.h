@@ -40,6 +40,9 @@ struct Requant {
     int gen32;
     // |t| = |(acc << shl) + bias_t| < 2^tmax_log2 for worst-case operands (<= 24: t is exact in fp32, front.hip's epilogue)
     int tmax_log2;
+    // gen32 only: 1 = the negative branch's product t * neg_mul does not fit 32 bits but t does; it is taken in two halves
+    // (y355_requant_gen32): needs sh >= 9 and (|t| / 256 + 1) * neg_mul + 256 < 2^31 (host-checked)
+    int split;
 };
 
 __device__ __forceinline__ int y355_rne_shift32(int x, int s) {            // s wave-uniform
@@ -49,7 +52,19 @@ __device__ __forceinline__ int y355_rne_shift32(int x, int s) {            // s 
 // q before clamping for a LeakyReLU slope neg_mul / 2^lk that is not a power of two, 32-bit (Requant::gen32)
 __device__ __forceinline__ int y355_requant_gen32(int acc, int bias, const Requant &rq) {
     const int t = (acc << rq.shl) + bias;
-    const int qp = y355_rne_shift32(t, rq.sh - rq.lk), qn = y355_rne_shift32(t * rq.neg_mul, rq.sh);
+    const int qp = y355_rne_shift32(t, rq.sh - rq.lk);
+    int qn;
+    if (rq.split) {                                    // wave-uniform
+        // t = 256 hi + lo (0 <= lo < 256):  t * neg_mul = 256 A + rem  with  A = hi * neg_mul + (lo * neg_mul >> 8),
+        // rem = lo * neg_mul & 255.  RNE((256 A + rem) / 2^sh) = RNE of A / 2^(sh - 8) in which a non-zero rem turns an exact
+        // tie into "above the tie": the usual half - 1 + lsb rounding add with lsb forced to 1
+        const int hi = t >> 8, m2 = (t & 255) * rq.neg_mul;
+        const int A = hi * rq.neg_mul + (m2 >> 8);
+        const int s = rq.sh - 8;
+        qn = (A + ((1 << (s - 1)) - 1) + ((((m2 & 255) + 255) >> 8) | ((A >> s) & 1))) >> s;
+    } else {
+        qn = y355_rne_shift32(t * rq.neg_mul, rq.sh);
+    }
     return t >= 0 ? qp : qn;
 }
 
@@ -286,6 +301,7 @@ struct RequantG {
     int lk;        // t' = t >= 0 ? t * 2^lk : t * neg_mul     (LeakyReLU slope neg_mul / 2^lk)
     int neg_mul;
     int narrow;    // 1: the whole epilogue fits 32 bits (host-checked bound): the 8-wave kernels take their 32-bit instantiation
+    int split;     // narrow only: Requant::split (the negative branch's product in two halves)
 };
 
 struct ConvGParams {
