@@ -492,9 +492,10 @@ using I1 = ConvRInst<false, 256, 256, 13, 13, false, 2, 4>;  // 256 -> 512 on 13
 using I2 = ConvRInst<false, 128, 128, 13, 26, false, 4, 2>;  // 128 -> 256                    conv_5 (when it fits 32 bits)
 using I3 = ConvRInst<false, 384, 128, 13, 26, false, 4, 2>;  // 384 -> 256                    conv_set_1
 using I4 = ConvRInst<false, 512, 256, 13, 13, false, 2, 4>;  // 512 -> 1024 on 13 x 13 maps   conv_7
-constexpr int NR = 12;
+using I5 = ConvRInst<false, 1024, 128, 13, 13, false, 4, 2>; // 1024 -> 256 on 13 x 13 maps   conv_set_2
+constexpr int NR = 13;
 constexpr Y355ConvRInfo g_info[NR] = {R0::info(), R1::info(), R2::info(), R3::info(), R4::info(), R5::info(), I0::info(), I1::info(), R6::info(), I2::info(),
-                                      I3::info(), I4::info()};
+                                      I3::info(), I4::info(), I5::info()};
 }  // namespace
 
 int y355_prepare_convr(int device) {
@@ -514,6 +515,7 @@ int y355_prepare_convr(int device) {
     if (!e) e = I2::prepare();
     if (!e) e = I3::prepare();
     if (!e) e = I4::prepare();
+    if (!e) e = I5::prepare();
     return e;
 }
 
@@ -548,6 +550,7 @@ bool y355_launch_convr(int rid, const ConvGParams &p, int device, hipStream_t s)
     case 9: return I2::launch(p, device, s);
     case 10: return I3::launch(p, device, s);
     case 11: return I4::launch(p, device, s);
+    case 12: return I5::launch(p, device, s);
     default: return false;
     }
 }
