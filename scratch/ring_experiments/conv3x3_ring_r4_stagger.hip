@@ -19,26 +19,17 @@
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #ifndef Y355_DIAG
-#define Y355_DIAG 0
+#define Y355_DIAG 0                 // 1 / 2: s_memtime stamps per workgroup / per wave, 3: six phase stamps per wave (y355_debug_stamps); never in the production build
 #endif
-#ifndef Y355_RING_AORDER
-#define Y355_RING_AORDER 0       // 0: compiler-placed LDS reads/waits; 1: hand-placed step (volatile asm)
-#endif
-#ifndef Y355_ABL
-#define Y355_ABL 0               // timing ablations (WRONG RESULTS): 1 no A reads, 2 no B reads, 4 no refill DMAs, 8 no barriers
-#endif
-#ifndef Y355_RING_YSWZ
-#define Y355_RING_YSWZ 0         // 1: row-dependent chunk swizzle for the pooled (window-ordered) tiles: measured, no gain (profiles/r02_notes.md)
+#ifndef Y355_DIAG12
+#define Y355_DIAG12 (Y355_DIAG == 1 || Y355_DIAG == 2)
 #endif
 #ifndef Y355_RING_PF
-#define Y355_RING_PF 5            // k-steps of weights in flight (ring of PF + 2 slots)
+#define Y355_RING_PF 5              // k-steps of weights in flight (ring of PF + 2 slots); 4..7 measured equal (profiles/r02_notes.md)
 #endif
-#ifndef Y355_RING_DMA_AT2
-#define Y355_RING_DMA_AT2 -2     // >= 0: the younger half of the workgroup (waves NW/2..) refills after this m-tile instead
-#endif
-#ifndef Y355_RING_DMA_AT
-#define Y355_RING_DMA_AT -1      // m-tile after whose MFMAs a step's refill DMAs go out (-1: right after the barrier)
-#endif
+// The timing ablations, the hand-placed (volatile asm) k-step, the row-dependent chunk swizzle, the refill-position and
+// half-tile variants of round 2 live in scratch/ring_experiments/conv3x3_ring_r2_experiments.hip; none of them paid
+// (profiles/r02_notes.md) and the production kernel keeps ONE body.
 
 __device__ __forceinline__ void rglds16(const void *g, void *lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -48,6 +39,19 @@ template <int N>
 __device__ __forceinline__ void rwait_vmcnt() {
     static_assert(N >= 0, "vmcnt");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
+}
+
+// fp32 epilogue on exact integers (FPE): 1.5 * 2^23 and the clamp bounds around it
+constexpr float RMAGIC = 12582912.0f, RQLO = 12582785.0f, RQHI = 12583039.0f;
+__device__ __forceinline__ float rvmax(float a, float b) {       // v_max_f32 without the canonicalising multiply
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned int rpack4(float a, float b, float c, float d) {   // low bytes of four floats M + q
+    const unsigned int ab = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x0c0c0400u);
+    const unsigned int cd = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x04000c0cu);
+    return ab | cd;
 }
 
 // s_waitcnt needs an immediate; callers pass values that are constants after unrolling, so the switch
@@ -66,53 +70,6 @@ __device__ __forceinline__ void rwait_vmcnt_dyn(int n) {
 #undef RW_CASE
 }
 
-// LDS reads and waits the compiler does not see (Y355_RING_AORDER): the reads carry no latency
-// information for it, the waits are tied to the registers they publish so no MFMA moves above them
-__device__ __forceinline__ void rds128(v4i &d, unsigned addr) {
-#if defined(Y355_ABL) && (Y355_ABL & 32)
-    return;
-#endif
-    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void rds128_o(v4i &d, unsigned addr) {
-#if defined(Y355_ABL) && (Y355_ABL & 32)
-    return;
-#endif
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-#ifndef Y355_RING_BUILTIN_MFMA
-#define Y355_RING_BUILTIN_MFMA 0
-#endif
-#ifndef Y355_RING_SAFEWAIT
-#define Y355_RING_SAFEWAIT 0
-#endif
-__device__ __forceinline__ void rwait_lgkm(int n) {
-    if (Y355_RING_SAFEWAIT) n = 0;
-#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" ::: "memory"); break;
-    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
-        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
-        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
-    }
-#undef RL_CASE
-}
-__device__ __forceinline__ void rwait_lgkm2(int n, v4i &a, v4i &b) {
-#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(a), "+v"(b) :: "memory"); break;
-    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
-        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
-        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
-    }
-#undef RL_CASE
-}
-__device__ __forceinline__ void rwait_lgkm4(int n, v4i &a, v4i &b, v4i &c, v4i &d) {
-#define RL_CASE(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); break;
-    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
-        RL_CASE(0) RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7) RL_CASE(8)
-        RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13) RL_CASE(14) RL_CASE(15)
-    }
-#undef RL_CASE
-}
-
 // slab pieces issued in steps lo..hi (step u issues one when 1 <= (u mod 9) <= ppw); negative steps
 // are the previous tile's (none before the first tile: its slab went out whole in the prologue)
 constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
@@ -125,8 +82,12 @@ constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
     return n;
 }
 
-template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
+// FPE: the requantisation runs in fp32 on exact integers (launcher-proved: accumulator shift 0, no left requant shift, right
+// shift <= 17, so every t = acc + bias that does not saturate is below 2^24 and converts exactly; a larger one converts to
+// something at least as large and saturates either way).  The biases come from a 1 KiB LDS copy that the prologue's first
+// LDS-DMA makes (oldest in the vmcnt stream: every later wait covers it; no global load in the epilogue).
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ, bool FPE = false, int PBN = BN, bool STAG = false>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
     constexpr int NW = WM * WN;
     constexpr int NTHR = NW * 64;
     constexpr int NCH = CIN / 64, SPC = 9, KS = NCH * SPC;
@@ -146,6 +107,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
     constexpr int WSLOTS = PF + 2;
     constexpr int OFF_W = 2 * SLABB;
     constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;
+    constexpr int OFF_BIAS = OFF_DUMMY + 1024;                     // FPE: the layer's biases (<= 256 int32)
     constexpr int SROWS = POOL ? MT * WM * 4 : MT * WM * 16;
     constexpr int SSTR = BN + 16;
     constexpr int OROWS = POOL ? BM / 4 : BM;
@@ -160,6 +122,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
     constexpr int NIT = DIRECT ? (POOL ? MT : MT * 4) : NPASS * NITP;   // output stores per thread per tile (static)
     static_assert(CIN % 64 == 0 && NT == 4, "64-channel chunks, four n-tiles per wave");
     static_assert(PPW <= 8 && PF >= 2 && PF <= 8, "slab pieces go out at t = 1..PPW");
+    static_assert(!(FPE && (DIRECT_REQ || ROLL)), "the fp32 epilogue is written for the staged path and the unrolled chunk loop");
+    static_assert(!(STAG && (ROLL || PPW > 6 || NW != 8)), "the staggered k-loop: unrolled chunk loop, eight waves, slab pieces out by t = 6");
     static_assert(DIRECT || (RP * SSTR <= SLABB && MT % NPASS == 0), "staging fits the dead slot");
     constexpr int UNRC = ROLL ? 1 : NCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,13 +142,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
     constexpr int PSTEP = NW * 16 / PWL;
     const int pix0 = wave * 16 + (lane >> 2);
     const int ppy0 = pix0 / PWL, ppx0 = min(pix0 % PWL, PW - 1);     // pitch padding re-reads column PW-1
-    // Pooled (2x2-window ordered) tiles: chunk ^ (((x >> 1) + 2 y) & 3).  With the x-only swizzle an A-fragment read of a
-    // window-ordered m-tile costs 8.56 LDS cycles (4 = conflict-free; scratch/bank_sim_ring.py reproduces the measured
-    // 39 % conflict share); adding 2 y brings it to 4.84.  Rows one apart then differ in address bit 5: the three taps of
-    // the middle filter row read at (base ^ 32), everything else is unchanged.
-    constexpr bool YSWZ = POOL && Y355_RING_YSWZ;
-    static_assert(!YSWZ || (PWL % 16 == 0 && PSTEP % 2 == 0), "a 16-pixel DMA piece stays inside one patch row; pieces step an even number of rows");
-    const int pwithin = ((lane & 3) ^ ((((lane >> 3) & 3) + (YSWZ ? 2 * ppy0 : 0)) & 3)) << 4;
+    const int pwithin = ((lane & 3) ^ ((lane >> 3) & 3)) << 4;
     auto decode = [&](int tile, int &b, int &y0, int &x0, int &nb) {
         nb = tile % p.nblk;
         tile /= p.nblk;
@@ -206,7 +164,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
         for (int j = 0; j < WPW; ++j) {
             const int f = wave + NW * j;
             const bool ok = f < NFR;
-            const int8_t *src = p.w + ((size_t)(nb * KS + ks) * NFR + (ok ? f : 0)) * 1024 + lane * 16;
+            constexpr int PR = PBN / BN;                           // the weights are packed for n-blocks of PBN channels
+            const int8_t *src = p.w + ((size_t)((nb / PR) * KS + ks) * (NFR * PR) + (nb % PR) * NFR + (ok ? f : 0)) * 1024 + lane * 16;
             char *dst = ok ? smem + OFF_W + slot * WB + f * 1024 : smem + OFF_DUMMY;
             rglds16(src, dst);
         }
@@ -217,7 +176,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
     if (tile >= total_tiles) return;
     int nstamp = 0;
     auto stamp = [&]() {
-        if constexpr (Y355_DIAG) {
+        if constexpr (Y355_DIAG12) {
 #if Y355_DIAG == 2
             if (p.stamps && lane == 0 && blockIdx.x < 1024 / NW && nstamp < 32)
                 p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
@@ -228,16 +187,29 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
     };
     stamp();
     stamp();
-    // two workgroups per CU (half-size tiles): the second half of the grid starts late, so that one workgroup's prologue and
-    // epilogue run under the other's k-loop instead of both doing the same phase at the same time
-    if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1)) {
-        for (int i = 0; i < p.stagger; i += 16) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles per trip
-    }
+    // Y355_DIAG == 3: six phase stamps per wave on the 100 MHz clock (s_memrealtime): 0 entry, 1 prologue issued, 2 first data
+    // landed (past the first barrier), 3 k-loop done, 4 epilogue's stores issued, 5 stores retired
+    auto pstamp = [&](int i) {
+#if Y355_DIAG == 3
+        if (p.stamps && lane == 0 && blockIdx.x < Y355_STAMP_ROWS / NW) {
+            p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
+            // shader-clock twin of stamps 2 / 3 (k-loop start / end): cycles of the k-loop and, with the 100 MHz stamps, the clock it ran at
+            if (i == 2 || i == 3) p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + 10 + i] = __builtin_amdgcn_s_memtime();
+            if (i == 0) {                                       // where the wave runs: HW_ID (wave, SIMD, CU, SE) and the XCC
+                p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + 11] = blockIdx.x * 16 + wave;
+            }
+        }
+#endif
+    };
+    pstamp(0);
     int b, y0, x0, nb;
     decode(tile, b, y0, x0, nb);
     int sl = 0;                                                // slab slot of the current chunk
     int wq = 0;                                                // ring slot of W(s) at step s
-    // ---- prologue: slab 0 whole, then W(0) .. W(PF)
+    // ---- prologue: (FPE: the biases,) slab 0 whole, then W(0) .. W(PF)
+    if constexpr (FPE) rglds16(p.bias_t + min(lane * 4, p.cstride - 4), wave == 0 ? smem + OFF_BIAS : smem + OFF_DUMMY);
 #pragma unroll
     for (int j = 0; j < PPW; ++j) issue_slab_piece(b, y0, x0, 0, 0, j);
 #pragma unroll
@@ -245,31 +217,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
         if (k < KS) issue_w(nb, k, k);
         else issue_w(nb, k - KS, k);                           // KS > PF for every layer here; keeps counts static
     }
-    // per-lane A-fragment bases (integer divisions): computed while the prologue's DMAs are in flight
-    int abase[MT][3];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        int row = (wm * MT + m) * 16 + li;
-        row = min(row, BM - 1);
-        int oy, ox;
-        if constexpr (POOL) {
-            const int w = row >> 2, r = row & 3;
-            oy = 2 * (w / (TW / 2)) + (r >> 1);
-            ox = 2 * (w % (TW / 2)) + (r & 1);
-        } else {
-            oy = row / TW;
-            ox = row % TW;
-        }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-            abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g ^ ((((ox + dx) >> 1) + (YSWZ ? 2 * oy : 0)) & 3)) << 4);
-    }
+    pstamp(1);
     const Requant rq = p.rq;
     unsigned int nsat = 0;
     bool first = true;
-#if defined(Y355_RING_PRIO)
-    if (Y355_RING_PRIO == 1 ? wave >= NW / 2 : wave < NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
 
     for (;;) {
         int ntile = tile + gridDim.x;
@@ -277,6 +228,30 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
         if (!more) ntile = tile;                               // keep the operation counts static
         int b2, y2, x2, nb2;
         decode(ntile, b2, y2, x2, nb2);
+        // per-lane A-fragment bases (integer divisions): computed while the prologue's (or the previous tile's prefetch) DMAs
+        // are in flight, per tile from an opaque copy of the lane id so that they are not live across the epilogue
+        int abase[MT][3];
+        {
+            int li_a = li, g_a = g;
+            asm volatile("" : "+v"(li_a), "+v"(g_a));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                int row = (wm * MT + m) * 16 + li_a;
+                row = min(row, BM - 1);
+                int oy, ox;
+                if constexpr (POOL) {
+                    const int w = row >> 2, r = row & 3;
+                    oy = 2 * (w / (TW / 2)) + (r >> 1);
+                    ox = 2 * (w % (TW / 2)) + (r & 1);
+                } else {
+                    oy = row / TW;
+                    ox = row % TW;
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    abase[m][dx] = (oy * PWL + ox + dx) * 64 + ((g_a ^ (((ox + dx) >> 1) & 3)) << 4);
+            }
+        }
 
         v4i acc[MT][NT];
 #pragma unroll
@@ -284,6 +259,91 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){0, 0, 0, 0};
 
+        if constexpr (STAG) {
+        // ---- staggered k-loop (round 4; MI355X_MICROARCH.md "Two waves per SIMD" item 9, scratch/ubench/mfma_pingpong.hip MODE 5).
+        // The two waves of a SIMD are waves w and w + 4.  Every wave runs the same body per k-step s,
+        //     [MFMAs of step s] [refill DMAs of step s] [LDS reads of step s + 1's fragments] [counted wait for W(s + 2)]
+        // but waves 4..7 have the step's ONE s_barrier in front of the MFMAs and waves 0..3 behind them: between two barriers
+        // one partner computes then loads while the other loads then computes, so the matrix pipe and the LDS / DMA path
+        // of a SIMD are busy together instead of in turns.  Same instruction stream for all waves apart from the barrier's
+        // position, so the counted waits are the same constants for both groups.
+        //   RAW  the reads of step s + 1 come after bar_s in both groups; every wave has waited for its own W(s + 1) pieces
+        //        (and, before a chunk's last step, for its pieces of the next slab) ahead of ITS bar_s
+        //   WAR  ISSUE(s) refills the slot of W(s - 1) and (t >= 1) the slab slot of the previous chunk: their last reads
+        //        were consumed by MFMAs that every wave issued before it reached bar_s
+        const bool grp = wave >= NW / 2;
+        v4i fa[MT], fb[NT];
+#ifndef Y355_STAG_ABL
+#define Y355_STAG_ABL 0             // timing-only ablations (wrong results): 1 no refill DMAs / waits, 2 conflict-free A addresses, 4 no LDS reads in the loop, 8 no barriers
+#endif
+        if (Y355_STAG_ABL & 4) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) fa[m] = (v4i){lane, m, 1, 2};
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) fb[tt] = (v4i){tt, lane, 3, 1};
+        }
+        auto read_frags = [&](int s_n, int slot_w, int soff_n) {          // fragments of step s_n (its chunk's slab at soff_n)
+            const int tn = s_n % SPC;
+            const int ko = (tn / 3) * PWL * 64, acol = tn % 3;
+            const char *wbn = smem + OFF_W + slot_w * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) fb[tt] = *(const v4i *)(wbn + tt * 1024);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (Y355_STAG_ABL & 2) fa[m] = *(const v4i *)(smem + ((lane * 16 + m * 1024 + tn * 64) & 16383) + soff_n);
+                else fa[m] = *(const v4i *)(smem + abase[m][acol] + soff_n + ko);
+            }
+        };
+        // pre-phase: W(0), W(1) and slab 0 have landed (own pieces) -> barrier -> everybody's have
+        {
+            constexpr int n_w = (PF - 1) * WPW, n_slab = (9 - PPW) * WPW;
+            if (first) rwait_vmcnt<n_w>();                                 // prologue order: bias, slab 0, W(0) .. W(PF)
+            else rwait_vmcnt<(n_w + ring_sp(-(PF - 1), -1, PPW, true) < n_slab ? n_w + ring_sp(-(PF - 1), -1, PPW, true) : n_slab) + NIT>();
+        }
+        __builtin_amdgcn_s_barrier();
+        pstamp(first ? 2 : 6);
+        read_frags(0, wq, sl * SLABB);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool lastc = (c + 1 == NCH);
+#pragma unroll
+            for (int t = 0; t < SPC; ++t) {
+                const int s_idx = c * SPC + t;
+                if (grp && !(Y355_STAG_ABL & 8)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[tt], acc[m][tt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!grp && !(Y355_STAG_ABL & 8)) __builtin_amdgcn_s_barrier();
+                // ---- refill: one slab piece (t = 1..PPW), W(s+1+PF) into the ring slot of W(s-1)
+                if (!(Y355_STAG_ABL & 1) && t >= 1 && t <= PPW) issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
+                if (!(Y355_STAG_ABL & 1)) {
+                    const int ksn = s_idx + 1 + PF;
+                    const bool nxt = ksn >= KS;
+                    issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wq + PF + 1));
+                }
+                wq = wrap(wq + 1);                                          // ring slot of W(s + 1)
+                if (!(Y355_STAG_ABL & 4) && s_idx + 1 < KS) read_frags(s_idx + 1, wq, (t + 1 == SPC ? (sl ^ 1) : sl) * SLABB);
+                // ---- own pieces of W(s+2) (issued in step s+1-PF) have landed; at t = 7 the next slab's too
+                if (!(Y355_STAG_ABL & 1) && s_idx + 2 < KS) {
+                    const int lo = s_idx + 2 - PF, hi = s_idx;
+                    int n_first = (PF - 1) * WPW + ring_sp(lo, hi, PPW, false);
+                    int n_later = (PF - 1) * WPW + ring_sp(lo, hi, PPW, true) + (lo - 1 < 0 ? NIT : 0);
+                    if (t == SPC - 2) {
+                        constexpr int n_slab = (SPC - 1 - PPW) * WPW;
+                        if (n_slab < n_first) n_first = n_slab;
+                        if (n_slab < n_later) n_later = n_slab;
+                    }
+                    if (n_first == n_later) rwait_vmcnt_dyn(n_later);
+                    else if (first) rwait_vmcnt_dyn(n_first);
+                    else rwait_vmcnt_dyn(n_later);
+                }
+            }
+            sl ^= 1;
+        }
+        } else {
         // ---- pre-phase: publish W(0) (and slab 0) and read W(0)'s B fragments.
         // vmcnt is in issue order: "at most N younger operations may still fly".  Younger than W(0):
         // W(1..PF), the slab pieces issued with them, and the previous tile's NIT output stores.
@@ -292,6 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
         if (first) rwait_vmcnt<PF * WPW>();
         else rwait_vmcnt<PF * WPW + ring_sp(-PF, -1, PPW, true) + NIT>();
         __builtin_amdgcn_s_barrier();
+        pstamp(first ? 2 : 6);
         {
             const char *wb0 = smem + OFF_W + wq * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
@@ -314,7 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                 // by 9-PPW steps of W pieces (and the stores, at a tile's first chunk).
                 {
                     constexpr int n_slab = (9 - PPW) * WPW;
-                    const bool fine = Y355_DIAG && first && c == (NCH > 1 ? 1 : 0);
+                    const bool fine = Y355_DIAG12 && first && c == (NCH > 1 ? 1 : 0);
                     if (fine) stamp();
                     if constexpr (ROLL) {
                         // chunk 0 of the first tile / of a later tile; any later chunk (s >= 9 > PF)
@@ -348,156 +409,50 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                     }
                     if (fine) stamp();
                 }
-                if constexpr (!(Y355_ABL & 8)) __builtin_amdgcn_s_barrier();
-                if (Y355_DIAG && first && c == (NCH > 1 ? 1 : 0)) stamp();
+                __builtin_amdgcn_s_barrier();
+                if (Y355_DIAG12 && first && c == (NCH > 1 ? 1 : 0)) stamp();
                 // ---- refill: one slab piece (t = 1..PPW) into the slot that died two barriers ago,
                 // W(s+1+PF) into the ring slot read in step s-2
                 const int wqs = wq;
-                auto refill = [&]() {
-                    if constexpr (Y355_ABL & 4) return;
+                {
                     if (t >= 1 && t <= PPW) {
                         issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
                     }
                     const int ksn = s_idx + 1 + PF;
                     const bool nxt = ksn >= KS;
                     issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wqs + PF + 1));
-                };
-                if constexpr (Y355_RING_DMA_AT < 0 && !(Y355_ABL & 4)) refill();
+                }
                 const int ko = (t / 3) * PWL * 64;
                 const int acol = t % 3;
-                constexpr int dummy3 = 0;
-                (void)dummy3;
                 const int cur = ROLL ? (t & 1) : (s_idx & 1);     // rolled: every chunk starts with its B fragments in bfb[0]
-                v4i af[MT];
                 wq = wrap(wq + 1);
-                if constexpr (Y355_RING_AORDER == 0) {
-                    const int yx = (YSWZ && t / 3 == 1) ? 32 : 0;              // middle filter row of a y-swizzled slab
-                    const int yx2 = (YSWZ && (t + 1) / 3 == 1) ? 32 : 0;
-                    if (t == 0 && (!(Y355_ABL & 1) || c == 0)) {
-                        af[0] = *(const v4i *)(smem + (abase[0][acol] ^ yx) + soff + ko);
-                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + (abase[1][acol] ^ yx) + soff + ko);
+                v4i af[MT];
+                {
+                    if (t == 0) {
+                        af[0] = *(const v4i *)(smem + abase[0][acol] + soff + ko);
+                        if constexpr (MT > 1) af[1] = *(const v4i *)(smem + abase[1][acol] + soff + ko);
                     } else {
                         af[0] = afp[0];
                         if constexpr (MT > 1) af[1] = afp[1];
                     }
-                    if constexpr (Y355_ABL & 1) {
-#pragma unroll
-                        for (int m = 2; m < MT; ++m) af[m] = af[m & 1];
-                        afp[0] = af[0];
-                        if constexpr (MT > 1) afp[1] = af[1];
-                    }
-                    if ((Y355_ABL & 2) && s_idx + 1 < KS) {
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = bfb[cur][tt];
-                    }
-                    if (!(Y355_ABL & 2) && s_idx + 1 < KS) {     // B fragments of step s+1, under this step's MFMAs
+                    if (s_idx + 1 < KS) {                            // B fragments of step s+1, under this step's MFMAs
                         const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        if (!(Y355_ABL & 1) && m + 2 < MT) af[m + 2] = *(const v4i *)(smem + (abase[m + 2][acol] ^ yx) + soff + ko);
-                        if (!(Y355_ABL & 1) && m == MT - 1 && t + 1 < SPC) {   // next step's first A fragments (same slab)
+                        if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
+                        if (m == MT - 1 && t + 1 < SPC) {            // next step's first A fragments (same slab)
                             const int ko2 = ((t + 1) / 3) * PWL * 64;
                             const int acol2 = (t + 1) % 3;
-                            afp[0] = *(const v4i *)(smem + (abase[0][acol2] ^ yx2) + soff + ko2);
-                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + (abase[1][acol2] ^ yx2) + soff + ko2);
+                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
                         }
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
                             acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
-                        if constexpr (Y355_RING_DMA_AT >= 0) {
-                            if constexpr (Y355_RING_DMA_AT2 >= 0) {
-                                const int at = wave >= NW / 2 ? Y355_RING_DMA_AT2 : Y355_RING_DMA_AT;
-                                if (m == 0 || m == Y355_RING_DMA_AT2 || m == Y355_RING_DMA_AT) {
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    if (m == (at < MT ? at : MT - 1)) refill();
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-                            } else if (m == (Y355_RING_DMA_AT < MT ? Y355_RING_DMA_AT : MT - 1)) {
-                                __builtin_amdgcn_sched_barrier(0);
-                                refill();
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
                     }
-                } else {
-                    // Hand-placed step (all of it volatile asm, so it executes in the order written).  Measured
-                    // with scratch/ubench/mfma_clean.hip on this part: a ds_read_b128 issued beside MFMAs costs
-                    // the SIMD ~9 cycles when the reads are spread one per MFMA and 17-28 when they go out in a
-                    // bunch (24 MFMAs + 10 reads + barrier: 917-932 cycles spread, 1082 bunched, 804 without
-                    // reads), and hipcc waits lgkmcnt(0) before the first MFMA that uses any of them.  Here one
-                    // read follows each of the step's first MFMAs -- this step's later A fragments, then B(s+1),
-                    // then the next step's first two A fragments -- and every m-tile waits (counted, LDS returns
-                    // in order) only for its own fragment.
-                    static_assert(Y355_RING_AORDER == 0 || MT == 6 || MT == 2, "hand-placed step: 6 or 2 m-tiles");
-                    static_assert(Y355_RING_AORDER == 0 || !YSWZ, "the hand-placed step does not implement the row swizzle");
-                    const bool has_b = s_idx + 1 < KS;
-                    const bool has_a = t + 1 < SPC;
-                    unsigned abs_off = (unsigned)(soff + ko);
-                    asm volatile("" : "+s"(abs_off));             // opaque: keeps the per-read address adds next to the reads
-                    unsigned off2 = (unsigned)(soff + ((t + 1) / 3) * PWL * 64);
-                    asm volatile("" : "+s"(off2));
-                    const int acol2 = (t + 1) % 3;
-                    const unsigned wbn = (unsigned)(OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024) + lane * 16;
-                    // read queue of the step: af[G0..MT-1], then B(s+1)[0..3], then afp[0..G0-1]; entry k goes out
-                    // right after the step's k-th MFMA.  Everything below is constant after unrolling.
-                    constexpr int G0 = MT < 2 ? MT : 2;
-                    constexpr int NA = MT - G0;
-                    const int nbq = has_b ? NT : 0;
-                    const int Q = NA + nbq + (has_a ? G0 : 0);
-                    const int pre = (t == 0) ? G0 : 0;          // new slab: af[0..G0-1] were not prefetched
-                    if (t == 0) {
-#pragma unroll
-                        for (int m = 0; m < G0; ++m) rds128(af[m], (unsigned)abase[m][acol] + abs_off);
-                    } else {
-                        af[0] = afp[0];
-                        if constexpr (MT > 1) af[1] = afp[1];
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        if (t == 0 || m >= G0) {
-                            const int done = NT * m < Q ? NT * m : Q;          // queue entries issued before this m-tile
-                            const int posm = (t == 0) ? m : m - G0;            // issue index of af[m]
-                            rwait_lgkm(pre + done - posm - 1);                // no register tie: a tie makes hipcc copy the
-                                                                              // fragment BEFORE the wait (stale data)
-                        }
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) {
-#if Y355_RING_BUILTIN_MFMA
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (!(Y355_ABL & 16)) acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
-                            else asm volatile("" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bfb[cur][tt]));
-                            __builtin_amdgcn_sched_barrier(0);
-#else
-                            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bfb[cur][tt]));
-#endif
-                            const int k = m * NT + tt;
-                            if (k < Q) {
-                                if (k < NA) {
-                                    rds128(af[G0 + (k < NA ? k : 0)], (unsigned)abase[G0 + (k < NA ? k : 0)][acol] + abs_off);
-                                } else if (has_b && k - NA < NT) {
-                                    const int k2 = k - NA;
-                                    if (k2 == 0) rds128_o<0>(bfb[cur ^ 1][0], wbn);
-                                    else if (k2 == 1) rds128_o<1024>(bfb[cur ^ 1][1], wbn);
-                                    else if (k2 == 2) rds128_o<2048>(bfb[cur ^ 1][2], wbn);
-                                    else rds128_o<3072>(bfb[cur ^ 1][3], wbn);
-                                } else {
-                                    const int k3 = (k - NA - nbq) & (G0 - 1);
-                                    rds128(afp[k3], (unsigned)abase[k3][acol2] + off2);
-                                }
-                            }
-                        }
-                        if constexpr (Y355_RING_DMA_AT >= 0) {
-                            if constexpr (Y355_RING_DMA_AT2 >= 0) {
-                                const int at = wave >= NW / 2 ? Y355_RING_DMA_AT2 : Y355_RING_DMA_AT;
-                                if (m == (at < MT ? at : MT - 1)) refill();
-                            } else if (m == (Y355_RING_DMA_AT < MT ? Y355_RING_DMA_AT : MT - 1)) refill();
-                        }
-                    }
-                    // B(s+1) and the next step's first A fragments are in registers before the barrier
-                    if (has_b || has_a) rwait_lgkm(0);
                 }
             }
             // 9 steps: the last one (cur = 0) read the next chunk's first fragments into bfb[1]
@@ -508,14 +463,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
             sl ^= 1;
         }
 
-        if (Y355_DIAG && first) { nstamp = 24; stamp(); }
+        }
+        if (Y355_DIAG12 && first) { nstamp = 24; stamp(); }
+        pstamp(first ? 3 : 7);
         // ---- epilogue: integer pipeline (32-bit path of conv3x3.hip) into registers, then through the
         // slab slot that just died (slot sl ^ 1: `sl` already points at the next tile's chunk 0)
         {
+            // the epilogue's lane-dependent addresses are re-derived here from an opaque copy of the thread id: computed once
+            // per launch they would be live (or spilled) across the whole k-loop
+            int tid_e = threadIdx.x;
+            asm volatile("" : "+v"(tid_e));
+            const int tid = tid_e, lane = tid_e & 63, li = lane & 15, g = lane >> 4;
+            (void)lane;
             const int ncol = wn * (NT * 16) + li * NT;
             int bias[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bias[t] = p.bias_t[nb * BN + ncol + t];
+            for (int t = 0; t < NT; ++t) bias[t] = FPE ? 0 : p.bias_t[nb * BN + ncol + t];
             constexpr int RPM = POOL ? 1 : 4;                   // staged rows per m-tile and lane
             // sh_l (a left requant shift; sh_r = 0 then) folded into the accumulator shift and the bias:
             // ((t' << sh_l) + hm1 + rb) >> sh_r with t' = max(t, t << lk) equals the same form on T = t << sh_l
@@ -529,8 +492,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                 const int rb = (int)__builtin_amdgcn_ubfe((unsigned int)x, (unsigned int)rq.sh_r, (unsigned int)rq.bw);
                 return (x + rq.hm1 + rb) >> rq.sh_r;
             };
+            // FPE: t = acc + bias in integers (exact), then fp32; the two scales are powers of two built in scalar registers
+            const float s_pos = __int_as_float((127 + rq.lk - rq.sh_r) << 23), s_neg = __int_as_float((127 - rq.sh_r) << 23);
+            int biasf[NT];
+            if constexpr (FPE) {
+                const v4i bv = *(const v4i *)(smem + OFF_BIAS + (nb * BN + ncol) * 4);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) biasf[t] = bv[t];
+            }
+            auto requantf = [&](int v, int t) {
+                const float tf = (float)(v + biasf[t]);
+                return rvmax(fmaf(tf, s_pos, RMAGIC), fmaf(tf, s_neg, RMAGIC));
+            };
             unsigned int satx = 0;                              // sum of (clamped ^ unclamped): non-zero iff something saturated
-            if (Y355_DIAG && first) stamp();
+            if (Y355_DIAG12 && first) stamp();
             char *stg = smem + (sl ^ 1) * SLABB;
             const int halo = p.out_halo;
             constexpr int OTW = POOL ? TW / 2 : TW;
@@ -584,6 +559,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                     for (int r = 0; r < RPM; ++r) {
                         const int lrow = POOL ? (wm * MH + mm) * 4 + g : (wm * MH + mm) * 16 + 4 * g + r;
                         unsigned int w = 0;
+                        float yq[NT];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
                             int v;
@@ -593,18 +569,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                             } else {
                                 v = acc[m][t][r];
                             }
-                            const int qq = requant(v, t);
-                            const int q = y355_clamp8<int>(qq);
-                            satx += (unsigned int)(q ^ qq);         // v_xad_u32; the exact count is taken below, rarely
-                            w |= (unsigned int)(q & 0xff) << (8 * t);
+                            if constexpr (FPE) {
+                                yq[t] = requantf(v, t);
+                            } else {
+                                const int qq = requant(v, t);
+                                const int q = y355_clamp8<int>(qq);
+                                satx += (unsigned int)(q ^ qq);     // v_xad_u32; the exact count is taken below, rarely
+                                w |= (unsigned int)(q & 0xff) << (8 * t);
+                            }
+                        }
+                        if constexpr (FPE) {
+                            float yc[NT];
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                yc[t] = __builtin_amdgcn_fmed3f(yq[t], RQLO, RQHI);
+                                satx += __float_as_uint(yc[t]) ^ __float_as_uint(yq[t]);
+                            }
+                            w = rpack4(yc[0], yc[1], yc[2], yc[3]);
                         }
                         *(unsigned int *)(stg + lrow * SSTR + ncol) = w;
+                        if constexpr (FPE) __builtin_amdgcn_sched_barrier(0);   // one row at a time: short live ranges (no spill)
                     }
                 }
-                if (Y355_DIAG && first) stamp();                   // requantised and staged (this wave)
+                if (Y355_DIAG12 && first) stamp();                   // requantised and staged (this wave)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (Y355_DIAG && first) stamp();                   // everybody's rows are staged
+                if (Y355_DIAG12 && first) stamp();                   // everybody's rows are staged
 #pragma unroll
                 for (int j = 0; j < NITP; ++j) {
                     const int it = min(tid + j * NTHR, RP * CG - 1);      // tail clamps: duplicates rewrite the same bytes
@@ -632,68 +622,88 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv3x3_
                             } else {
                                 v = acc[m][t][r];
                             }
-                            const int qq = requant(v, t);
-                            nsat += (srow < OROWS && y355_clamp8<int>(qq) != qq) ? 1u : 0u;
+                            if constexpr (FPE) {
+                                asm volatile("" : "+v"(v));        // recompute here: do not keep the hot pass's 96 values alive for this branch
+                                const float y = requantf(v, t);
+                                nsat += (srow < OROWS && (y > RQHI || y < RQLO)) ? 1u : 0u;
+                            } else {
+                                const int qq = requant(v, t);
+                                nsat += (srow < OROWS && y355_clamp8<int>(qq) != qq) ? 1u : 0u;
+                            }
                         }
                     }
             }
         }
         }
-        if (Y355_DIAG && first) stamp();
+        if (Y355_DIAG12 && first) stamp();
+        pstamp(first ? 4 : 8);
         first = false;
         if (!more) break;
         tile = ntile;
         b = b2; y0 = y2; x0 = x2; nb = nb2;
     }
     rwait_vmcnt<0>();       // retire the prefetches before the wave ends
-    if (Y355_DIAG) { nstamp = 28; stamp(); }
+    pstamp(5);
+    if (Y355_DIAG12) { nstamp = 28; stamp(); }
     if (nsat) atomicAdd(&p.ctr->sat, (unsigned long long)nsat);
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT>
+template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT, bool FPE, int PBN = BN, bool STAG = false>
 struct ConvInstR {
     static constexpr int PWL = (TW + 2 + 7) / 8 * 8;
     static constexpr int SLABB = ((TH + 2) * PWL * 64 + 1023) / 1024 * 1024;
     static constexpr int WB = (BN / 16) * 1024;
-    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(PF + 2) * WB + 1024;
+    static constexpr size_t LDS = 2 * (size_t)SLABB + (size_t)(PF + 2) * WB + 1024 + (FPE ? 1024 : 0);
+    static constexpr int WGS_PER_CU = (WM * WN <= 4 && 2 * LDS <= 163840) ? 2 : 1;     // 4-wave workgroups: two per CU
+    static constexpr auto kern = conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT, FPE, PBN, STAG>;
     static int prepare() {
-        return (int)hipFuncSetAttribute((const void *)conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        return (int)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
-    static bool launch(const ConvParams &p_in, hipStream_t s, int grid_max = 256, int stagger = 0) {
+    static bool launch(const ConvParams &p_in, hipStream_t s) {
         ConvParams p = p_in;
         p.tiles_x = (p.W + TW - 1) / TW;
         p.tiles_y = (p.H + TH - 1) / TH;
-        p.stagger = stagger;
+        p.nblk = p.nblk * (PBN / BN);                          // the caller counts n-blocks of the packing
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
-        int grid = grid_max;                                   // one persistent workgroup per CU (two for the half tiles)
-        if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;   // fewer, each walking more tiles (throughput mode)
+        int grid = 256 * WGS_PER_CU;                           // persistent workgroups
+        if (p.grid_limit > 0 && p.grid_limit * WGS_PER_CU < grid) grid = p.grid_limit * WGS_PER_CU;   // fewer, each walking more tiles (throughput mode)
         if (grid > total) grid = total;
         if (p.ev_start && p.ev_stop) {
             hipEvent_t e0 = (hipEvent_t)p.ev_start, e1 = (hipEvent_t)p.ev_stop;
             p.ev_start = p.ev_stop = nullptr;
-            hipExtLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s,
-                                  e0, e1, 0, p, total);
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, s, e0, e1, 0, p, total);
         } else {
-            hipLaunchKernelGGL((conv3x3_i8_ring_kernel<CIN, BN, TH, TW, POOL, WM, WN, PF, ROLL, DIRECT>), dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, s, p, total);
         }
         return true;
     }
 };
 
 // must mirror the tile table of conv3x3.hip (same packing: BN, WN and NT are shared)
-template <bool ROLL, bool DIRECT>
+#ifndef Y355_RING_STAG
+#define Y355_RING_STAG 1            // 1: the staggered k-loop (waves 4..7 compute-then-load, waves 0..3 load-then-compute between two barriers)
+#endif
+#ifndef Y355_RING_STAG_PF
+#define Y355_RING_STAG_PF 6         // the staggered loop waits one k-step earlier: one more ring slot keeps five k-steps in flight
+#endif
+template <bool ROLL, bool DIRECT, bool FPE>
 struct RSet {
-    using C3_2 = ConvInstR<64, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
-    using C4_1 = ConvInstR<64, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
-    using C4_2 = ConvInstR<128, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
-    using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
-    using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT>;
-    using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, Y355_RING_PF, ROLL, DIRECT>;
-    // experiment (Y355_RING_HALF): half-size tiles, two 4-wave workgroups per CU, staggered start
-    using C67H = ConvInstR<256, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
-    using C5H = ConvInstR<128, 128, 13, 13, false, 2, 2, 3, ROLL, DIRECT>;
+    static constexpr bool SG = Y355_RING_STAG && !ROLL;
+    static constexpr int PFS = SG ? Y355_RING_STAG_PF : Y355_RING_PF;
+    // the pooled 26 x 26 tiles send seven slab pieces per wave and chunk (t = 1..7): no room for the staggered loop's earlier slab wait;
+    // they are the fallbacks of convpx.hip's layers
+    using C3_2 = ConvInstR<64, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
+    using C4_1 = ConvInstR<64, 128, 13, 26, false, 4, 2, PFS, ROLL, DIRECT, FPE, 128, SG>;
+    using C4_2 = ConvInstR<128, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
+#ifdef Y355_RING4          // experiment: 4-wave workgroups, 13 x 26 x 64 tiles, two per CU (weights read from the 128-channel packing)
+    using C5 = ConvInstR<128, 64, 13, 26, false, 4, 1, Y355_RING4, ROLL, DIRECT, FPE, 128>;
+    using C67 = ConvInstR<256, 64, 13, 26, false, 4, 1, Y355_RING4, ROLL, DIRECT, FPE, 128>;
+#else
+    using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, PFS, ROLL, DIRECT, FPE, 128, SG>;
+    using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, PFS, ROLL, DIRECT, FPE, 128, SG>;
+#endif
+    using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, PFS, ROLL, DIRECT, FPE, 64, SG>;
     static int prepare() {
         int e = C3_2::prepare();
         if (!e) e = C4_1::prepare();
@@ -701,10 +711,6 @@ struct RSet {
         if (!e) e = C5::prepare();
         if (!e) e = C67::prepare();
         if (!e) e = PRED::prepare();
-#ifdef Y355_EXPERIMENTS
-        if (!e) e = C67H::prepare();
-        if (!e) e = C5H::prepare();
-#endif
         return e;
     }
     static bool launch(int kid, const ConvParams &p, hipStream_t s) {
@@ -712,31 +718,29 @@ struct RSet {
         case Y355_K_CONV3_2: return C3_2::launch(p, s);
         case Y355_K_CONV4_1: return C4_1::launch(p, s);
         case Y355_K_CONV4_2: return C4_2::launch(p, s);
-        case Y355_K_CONV5: {
-#ifdef Y355_EXPERIMENTS
-            static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
-            if (half & 2) return C5H::launch(p, s, 512, half >> 8);
-#endif
-            return C5::launch(p, s);
-        }
-        case Y355_K_CONV67: {
-#ifdef Y355_EXPERIMENTS
-            static const int half = getenv("Y355_RING_HALF") ? atoi(getenv("Y355_RING_HALF")) : 0;
-            if (half & 1) return C67H::launch(p, s, 512, half >> 8);
-#endif
-            return C67::launch(p, s);
-        }
+        case Y355_K_CONV5: return C5::launch(p, s);
+        case Y355_K_CONV67: return C67::launch(p, s);
         case Y355_K_PRED: return PRED::launch(p, s);
         default: return false;
         }
     }
 };
 
-int y355_prepare_conv_ring(void) { return RSet<false, false>::prepare(); }
+int y355_prepare_conv_ring(void) {
+    const int e = RSet<false, false, false>::prepare();
+    return e ? e : RSet<false, false, true>::prepare();
+}
 
 bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s) {
     if ((p.mode & 0xff) != 0 || p.rq.wide || p.guard) return false;   // those go to conv3x3.hip
-    // ROLL = false (chunk loop unrolled) and staged epilogue: measured best of the four combinations
-    // (144.5 k img/s vs 140-142 k, one stream, B = 64)
-    return RSet<false, false>::launch(kid, p, s);
+    // ROLL = false (chunk loop unrolled) and staged epilogue: measured best of the four combinations (144.5 k img/s vs 140-142 k,
+    // one stream, B = 64, round 1); round 3's operand-swapped form with 16-byte stores straight from the accumulators
+    // (scratch/ring_experiments/conv3x3_ring_r3_swap.hip) shortens the epilogue by 0.9 us and changes nothing end to end
+    // fp32 epilogue where the host can prove it exact (header of the kernel): no accumulator / left requant shift, a right shift
+    // of at most 17 bits, the reference's slope
+#ifndef Y355_RING_NO_FPE
+    if (p.rq.shl == 0 && p.rq.sh_l == 0 && p.rq.sh_r <= 17 && p.rq.neg_mul == 1 && p.cstride >= 4 && p.cstride <= 256)
+        return RSet<false, false, true>::launch(kid, p, s);
+#endif
+    return RSet<false, false, false>::launch(kid, p, s);
 }

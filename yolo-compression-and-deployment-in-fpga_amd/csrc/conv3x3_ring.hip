@@ -19,7 +19,7 @@
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #ifndef Y355_DIAG
-#define Y355_DIAG 0                 // 1 / 2: s_memtime stamps per workgroup / per wave, 3: six phase stamps per wave (y355_debug_stamps); never in the production build
+#define Y355_DIAG 0                 // 1 / 2: s_memtime stamps per workgroup / per wave, 3: six phase stamps per wave + where it ran (y355_debug_stamps, scratch/stamps_ring_pairs.py); never in the production build
 #endif
 #ifndef Y355_DIAG12
 #define Y355_DIAG12 (Y355_DIAG == 1 || Y355_DIAG == 2)
@@ -189,7 +189,17 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     // landed (past the first barrier), 3 k-loop done, 4 epilogue's stores issued, 5 stores retired
     auto pstamp = [&](int i) {
 #if Y355_DIAG == 3
-        if (p.stamps && lane == 0 && blockIdx.x < 1024 / NW) p.stamps[(size_t)(blockIdx.x * NW + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
+        if (p.stamps && lane == 0 && blockIdx.x < Y355_STAMP_ROWS / NW) {
+            unsigned long long *row = p.stamps + (size_t)(blockIdx.x * NW + wave) * 32;
+            row[i] = __builtin_amdgcn_s_memrealtime();
+            // shader-clock twins of stamps 2 / 3 (k-loop start / end): cycles of the k-loop and, with the 100 MHz stamps, the clock it ran at
+            if (i == 2 || i == 3) row[10 + i] = __builtin_amdgcn_s_memtime();
+            if (i == 0) {                                       // where the wave runs: HW_ID (wave, SIMD, CU, SE), XCC_ID, (workgroup, wave)
+                row[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                row[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                row[11] = blockIdx.x * 16 + wave;
+            }
+        }
 #endif
     };
     pstamp(0);

@@ -982,14 +982,14 @@ extern "C" int y355_debug_stamps(y355_engine *h, int layer, unsigned long long *
     if (!h) return fail(Y355_EINVAL, "null engine");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     if (!h->stamps_dev) {
-        if (int rc = dmalloc(h, (void **)&h->stamps_dev, 8 * 32 * 1024, true)) return rc;
+        if (int rc = dmalloc(h, (void **)&h->stamps_dev, 8 * 32 * Y355_STAMP_ROWS, true)) return rc;
     }
     if (out_host) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(out_host, h->stamps_dev, 8 * 32 * (size_t)(nwg > 1024 ? 1024 : nwg), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_host, h->stamps_dev, 8 * 32 * (size_t)(nwg > Y355_STAMP_ROWS ? Y355_STAMP_ROWS : nwg), hipMemcpyDeviceToHost));
     }
     h->stamp_layer = layer;
-    HIPCHK(hipMemset(h->stamps_dev, 0, 8 * 32 * 1024));
+    HIPCHK(hipMemset(h->stamps_dev, 0, 8 * 32 * Y355_STAMP_ROWS));
     return 0;
 }
 

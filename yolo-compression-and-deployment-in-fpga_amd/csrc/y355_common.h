@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+#define Y355_STAMP_ROWS 4096      // rows of 32 stamps in the diagnostic builds' stamp buffer (y355_debug_stamps)
 
 // launch; with both events given the launch records its own start / end timestamps into them (profile mode 2: the
 // duration rocprofv3 reports for the kernel, without the gap to the neighbouring launches)
