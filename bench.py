@@ -41,23 +41,26 @@ LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "co
 DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, false, false"   # prefix: the last template argument selects the epilogue (true = fp32)
 
 
-TRAFFIC_FILES = ["r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
+TRAFFIC_FILES = ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
 N_INPUTS = 4          # distinct input batches rotated through the timed loop: 4 x 133 MB > the 256 MB Infinity Cache
 
 
 def pmc_traffic(kernel):
-    """(HBM bytes per launch of `kernel`, source file) from the committed PMC passes (profiles/, collected with
-    rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE runs at this workload, scratch/pmc_traffic.sh); (None, None)
-    if absent.  The number is read from the committed file, not measured in this run."""
+    """(HBM bytes per launch of `kernel`, source file, full kernel name) from the committed PMC passes (profiles/, collected with
+    rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE runs at this workload, scratch/pmc_traffic.sh); (None, None, None)
+    if absent.  `kernel` is a name prefix (the last template argument selects the epilogue): of the instantiations a file
+    holds, the one with the most launches is the one the profiled run executed.  The number is read from the committed
+    file, not measured in this run."""
     for fn in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
-                for name, v in json.load(f)["kernels"].items():
-                    if kernel in name:
-                        return v["hbm_bytes_per_launch"], "profiles/" + fn
+                hits = [(v.get("launches", 0), name, v) for name, v in json.load(f)["kernels"].items() if kernel in name]
+            if hits:
+                _, name, v = max(hits, key=lambda h: h[0])
+                return v["hbm_bytes_per_launch"], "profiles/" + fn, name
         except (OSError, ValueError, KeyError):
             pass
-    return None, None
+    return None, None, None
 
 
 def quantized_layers(seed=2, **kw):
@@ -129,16 +132,21 @@ def cpu_baseline(n_images=128):
     c_oracle.detect(synth.make_images(0, 1, H, W), ql, sa, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES)   # warm-up
     ncores = os.cpu_count()
 
-    def run(batch, calls, threads):
+    def run(batch, calls, threads, min_seconds=0.0):
+        """`calls` calls of `batch` images (more until `min_seconds` have passed, at most 64 calls)"""
         _omp_threads(threads)
         x = synth.make_images(1000, batch, H, W)
         t0 = time.perf_counter()
-        for _ in range(calls):
+        done = 0
+        while done < calls or (time.perf_counter() - t0 < min_seconds and done < 64):
             c_oracle.detect(x, ql, sa, [H, W], synth.ANCHOR_SIZE_MASK, NUM_CLASSES, 0.01, 0.5)
+            done += 1
         dt = time.perf_counter() - t0
-        return dict(value=round(batch * calls / dt, 3), unit="images/sec", cores=threads, batch=batch,
-                    sample="%d call(s) of %d image(s), %.1f s" % (calls, batch, dt))
-    main = run(64, max(1, n_images // 64), ncores)
+        return dict(value=round(batch * done / dt, 3), unit="images/sec", cores=threads, batch=batch,
+                    sample="%d call(s) of %d image(s), %.1f s" % (done, batch, dt))
+    # the headline entry: batches of 64 on every core until about 10 s of CPU work (every layer of a batch is one OpenMP loop
+    # over image x output channel: oracle/yolo_oracle.c)
+    main = run(64, max(1, n_images // 64), ncores, 10.0)
     grid = {"c_b64_all_cores": main, "c_b1_all_cores": run(1, 4, ncores), "c_b1_1_core": run(1, 1, 1),
             # one core at batch 64 would take minutes: a 4-image call on one thread measures the same per-image rate
             "c_b64_1_core": dict(run(4, 1, 1), note="4-image sample of the batch-64 case (one thread: the rate per image is batch-independent)")}
@@ -215,6 +223,10 @@ def measure_net(args):
         nets.append(net)
     net = nets[0]
     x = torch.from_numpy(synth.make_images(1000, B, H, W)).to(dev)
+    # the headline's standard: N_INPUTS distinct input batches rotate through the timed loop (the batch and its three flips:
+    # more than the Infinity Cache holds at these batch sizes), regions of exactly `steps` steps repeated until >= 15 regions
+    # and >= 1 s of timed work, value = the median region, min / max reported
+    xs = [x, torch.flip(x, (3,)).contiguous(), torch.flip(x, (2,)).contiguous(), torch.flip(x, (2, 3)).contiguous()][:N_INPUTS]
     bufs = [tuple(torch.empty_like(t) for t in net._buffers(B)) for _ in range(2 * ns)]
     torch.cuda.synchronize()
 
@@ -222,21 +234,24 @@ def measure_net(args):
         out = None
         for i in range(n):
             with torch.cuda.stream(streams[i % k]):
-                out = nets[i % k].forward_device(x, 0, bufs[i % (2 * k)])
+                out = nets[i % k].forward_device(xs[i % len(xs)], 0, bufs[i % (2 * k)])
         return out
 
-    run(max(args.warmup, ns))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = run(args.steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    run(2, 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps, 1)
-    torch.cuda.synchronize()
-    dt1 = time.perf_counter() - t0
+    def regions(k, min_regions, min_seconds):
+        run(max(args.warmup, k), k)
+        ts, out = [], None
+        while len(ts) < min_regions or (sum(ts) < min_seconds and len(ts) < 2000):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = run(args.steps, k)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return ts, out
+    reps = getattr(args, "net_regions", 15)
+    ts, out = regions(ns, reps, 1.0 if reps >= 15 else 0.0)
+    dt = float(np.median(ts))
+    ts1, _ = regions(1, min(reps, 5), 0.0)
+    dt1 = float(np.median(ts1))
     with torch.cuda.stream(streams[0]):
         net.profile(True)
         acc = None
@@ -256,8 +271,16 @@ def measure_net(args):
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%s %s, batch %d, 416x416, %d classes, conf 0.01" % (arch, dtype, B, classes),
-                   "streams_per_gpu": ns, "detections_per_step": int(out[3][:B].sum().item())},
-        "one_stream": {"value": round(B * args.steps / dt1, 1), "unit": "images/sec", "ms_per_step": round(dt1 / args.steps * 1e3, 4)},
+                   "streams_per_gpu": ns, "input_batches_rotated": len(xs), "detections_per_step": int(out[3][:B].sum().item())},
+        "timing": {"repeats": len(ts), "timed_seconds": round(float(sum(ts)), 3),
+                   "value_min": round(B * args.steps / max(ts), 1), "value_max": round(B * args.steps / min(ts), 1),
+                   "ms_per_step_min": round(min(ts) / args.steps * 1e3, 4), "ms_per_step_max": round(max(ts) / args.steps * 1e3, 4)},
+        "parity": ("build-defined int8 form of YOLOv3tiny: bit-exact vs oracle/net_int8_oracle.py, which NOTHING in the reference can pin "
+                   "(the reference has no int8 form of this model): parity unpinned; held to the reference's fp32 maps within 8e-2 rel. L2"
+                   if dtype == "int8" and arch == "tiny_yolo_v3" else
+                   "bf16 operands, fp32 accumulate: pinned to the reference's fp32 forward (tests/golden/fp32.npz) within the stated tolerances"),
+        "one_stream": {"value": round(B * args.steps / dt1, 1), "unit": "images/sec", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                       "repeats": len(ts1)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                      "frac": round(achieved * 1e12 / peak, 4), "traffic": None,
                      "kernel": "convg_kernel, all conv launches of the graph (%.1f MMAC/image)" % mmac,
@@ -439,6 +462,9 @@ def main():
                     help="the timed region of EXACTLY --steps steps is run this many times; value = median (min / max reported). "
                          "0 (default) = as many as it takes to time at least 2 s of GPU work, and at least 15")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
+    ap.add_argument("--net-regions", type=int, default=15,
+                    help="--workload other than slim_int8 (and the other_configs entries): minimum number of timed regions "
+                         "(at 15 or more the regions also have to add up to 1 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the extra 'sparse fixture' measurement (SURVEY.md 8d)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[2] / configs[3] measurements")
@@ -447,7 +473,15 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
     ap.add_argument("--gather-max-det", type=int, default=256,
                     help="multi-GPU: detections per image in the all-gather records (SURVEY.md 8e: fixed-cap records, 6.1 KB per image "
-                         "at 256); the per-GPU forward and its outputs are unchanged")
+                         "at 256; 0 = the engine's max_det, i.e. full records); the per-GPU forward and its outputs are unchanged. "
+                         "Full records are timed and verified beside the capped ones either way (gather_full_records)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI, the production transport) or gloo: the packed records are staged to the host "
+                         "for the gather (gloo moves no device tensors), everything else is the production path -- the way to "
+                         "execute the world > 1 logic on a box with one GPU (with --share-gpu); its rate is not a performance number")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank uses cuda:0 (self-test on a one-GPU box; needs --dist-backend gloo: RCCL refuses two ranks "
+                         "on one device, so the C ABI route y355_allgather_dets is skipped)")
     ap.add_argument("--force-dist", action="store_true",
                     help="self-test: run the multi-GPU code path (process group, exponent broadcast, packed all-gather per step, "
                          "barriers, max over ranks) with a world of ONE rank -- the build boxes have one GPU each")
@@ -472,16 +506,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or args.force_dist
+    gloo = args.dist_backend == "gloo"
+    if args.share_gpu and world > 1 and not gloo:
+        sys.exit("bench.py: --share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    dev_index = 0 if args.share_gpu else local_rank
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        kw = dict(rank=0, world_size=1) if world == 1 else {}
+        if gloo:
+            dist.init_process_group("gloo", **kw)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if gloo else dev          # where the small control tensors of the collectives live
     B = args.batch
 
     # Engine handles per GPU, each on its own HIP stream; steps alternate between them, so the
@@ -507,7 +548,7 @@ def main():
     if rank == 0:
         with torch.cuda.stream(streams[0]):
             sa = eng.calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
-    sa = shard.broadcast_exponents(sa, 0, dev)
+    sa = shard.broadcast_exponents(sa, 0, cdev)
     for e in engines:
         e.set_act_exponents(sa)
 
@@ -530,15 +571,35 @@ def main():
     x, frames = xs[0], (fs[0] if fs is not None else None)
     nbuf = 2 * nstreams
     bufs = [tuple(torch.empty_like(t) for t in eng._buffers(B)) for _ in range(nbuf)]
-    gsend = grecv = None
-    gather_md = max(1, min(args.gather_max_det, eng.max_det))
-    if dist_on:
-        rb = shard.record_bytes(gather_md)
-        gsend = [torch.empty((B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        grecv = [torch.empty((world * B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    gather_md = eng.max_det if args.gather_max_det <= 0 else max(1, min(args.gather_max_det, eng.max_det))
+
+    def gather_bufs(md):
+        """send / receive buffers of one record cap: device (the pack kernel's output, RCCL's operands) and, for gloo, host"""
+        rb = shard.record_bytes(md)
+        g = {"md": md, "rb": rb,
+             "send": [torch.empty((B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)],
+             "recv": [torch.empty((world * B, rb), dtype=torch.uint8, device=dev) for _ in range(nbuf)]}
+        if gloo:
+            g["hsend"] = torch.empty((B, rb), dtype=torch.uint8).pin_memory()
+            g["hrecv"] = torch.empty((world * B, rb), dtype=torch.uint8).pin_memory()
+        return g
+    G = gather_bufs(gather_md) if dist_on else None
+
+    def gather(g, k, async_op):
+        """ONE collective for the batch packed in g["send"][k] (current stream): RCCL on device buffers, or -- gloo -- staged
+        through the host, blocking.  Returns the work handles still to wait for."""
+        if gloo:
+            g["hsend"].copy_(g["send"][k], non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            dist.all_gather_into_tensor(g["hrecv"], g["hsend"])
+            g["recv"][k].copy_(g["hrecv"], non_blocking=True)
+            return []
+        w = dist.all_gather_into_tensor(g["recv"][k], g["send"][k], async_op=async_op)
+        return [w] if async_op else []
     torch.cuda.synchronize()
 
-    def step(i, pending, ns, rotate=True):
+    def step(i, pending, ns, rotate=True, g=None):
+        g = G if g is None else g
         k = i % nbuf
         j = i % N_INPUTS if rotate else 0
         with torch.cuda.stream(streams[i % ns]):      # the engine's own stream: no cross-stream waits are inserted
@@ -553,18 +614,18 @@ def main():
                 # ONE packed all-gather per batch: one pack launch on the engine's stream, then the collective,
                 # which orders itself after that stream and runs on RCCL's own -- asynchronous, no other stream involved
                 # (packing with torch ops on the default stream and waiting across streams halved the per-GPU rate)
-                shard.pack_detections_kernel(*[t[:B] for t in out], B, gsend[k], gather_md)
-                pending[k] = [dist.all_gather_into_tensor(grecv[k], gsend[k], async_op=True)]
+                shard.pack_detections_kernel(*[t[:B] for t in out], B, g["send"][k], g["md"])
+                pending[k] = gather(g, k, True)
         return out
 
-    def timed(ns, steps, warmup, repeats, rotate=True, min_seconds=0.0):
+    def timed(ns, steps, warmup, repeats, rotate=True, min_seconds=0.0, g=None):
         """`repeats` timed regions of EXACTLY `steps` steps each (repeats = 0: until `min_seconds` of timed work and 15 regions),
         every one bracketed by barrier + synchronize on both sides; per region the MAX over ranks.
         Returns (list of seconds, last outputs)."""
         pending = [None] * nbuf
         out = None
         for i in range(warmup):
-            out = step(i, pending, ns, rotate)
+            out = step(i, pending, ns, rotate, g)
         times = []
         while len(times) < (repeats if repeats > 0 else 15) or (repeats <= 0 and sum(times) < min_seconds and len(times) < 2000):
             torch.cuda.synchronize()
@@ -573,7 +634,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(steps):
-                out = step(i, pending, ns, rotate)
+                out = step(i, pending, ns, rotate, g)
             for p in pending:
                 if p is not None:
                     for w in p:
@@ -584,7 +645,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if dist_on:
-                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                t = torch.tensor([dt], dtype=torch.float64, device=cdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             times.append(dt)
@@ -609,45 +670,71 @@ def main():
         one = float(np.median(t1))
 
     # ---- multi-GPU: verify what the gather delivers ("gathered detections equal the single-GPU run bit for
-    # bit").  Every rank runs one more step on its shard's first batch and gathers (torch.distributed, blocking, the timed
-    # path's records; then the C ABI route y355_pack_dets / y355_allgather_dets / y355_unpack_dets with full records);
-    # rank 0 rebuilds every rank's shard on its own GPU, runs it through its own engine and compares every byte.
+    # bit").  Every rank runs one more step on its shard's first batch and gathers: (a) torch.distributed, blocking, records of
+    # the timed path's cap; (b) the same with FULL records (the engine's max_det); (c) unless the ranks share one GPU, the C ABI
+    # route y355_pack_dets / y355_allgather_dets / y355_unpack_dets with full records.  Rank 0 rebuilds every rank's shard on
+    # its own GPU, runs it through its own engine and compares every byte.  Full records are also TIMED (a short region).
     gather_info = None
     if dist_on:
+        G_full = G if gather_md == eng.max_det else gather_bufs(eng.max_det)
+        for e in engines:
+            e.set_option(2, ring_wgs)
+        t_full, _ = timed(nstreams, args.steps, min(args.warmup, 5), 5, True, 0.0, G_full)
+        for e in engines:
+            e.set_option(2, 0)
+        dt_full = float(np.median(t_full))
         with torch.cuda.stream(streams[0]):
             inp0 = fs[0] if fs is not None else xs[0]
             fwd = (lambda e, t, bf: e.forward_frames_device(t, 0, bf)) if fs is not None else (lambda e, t, bf: e.forward_device(t, 0, bf))
             o_mine = fwd(eng, inp0, bufs[0])
-            shard.pack_detections_kernel(*[t[:B] for t in o_mine], B, gsend[0], gather_md)
-            dist.all_gather_into_tensor(grecv[0], gsend[0])
-            rg = shard.RcclGather(world, rank, dev)
-            comm_world = int(rg._lib.y355_comm_world(rg._h))
-            g_full = rg.allgather(*[t[:B] for t in o_mine])
+            for g in (G, G_full):
+                shard.pack_detections_kernel(*[t[:B] for t in o_mine], B, g["send"][0], g["md"])
+                gather(g, 0, False)
+            comm_world, g_full = None, None
+            if not args.share_gpu:
+                rg = shard.RcclGather(world, rank, dev)
+                comm_world = int(rg._lib.y355_comm_world(rg._h))
+                g_full = rg.allgather(*[t[:B] for t in o_mine])
             torch.cuda.synchronize()
-            bad_records, bad_full = 0, 0
+            bad = {"capped": 0, "full": 0}
+            bad_c_abi = 0 if g_full is not None else None
             if rank == 0:
-                ref = torch.empty_like(gsend[0])
                 for r in range(world):
                     xr, fr = shard_inputs(r)
                     o_r = fwd(eng, (fr[0] if fr is not None else xr[0]), bufs[1])
-                    shard.pack_detections_kernel(*[t[:B] for t in o_r], B, ref, gather_md)
-                    torch.cuda.synchronize()
-                    bad_records += int((ref != grecv[0][r * B:(r + 1) * B]).any(dim=1).sum().item())
-                    # the engine's padded outputs hold stale values past count[i]; the gathered arrays hold zeros there
-                    cnt = o_r[3][:B]
-                    keep = torch.arange(o_r[1].shape[1], device=dev)[None, :] < cnt[:, None]
-                    sl = slice(r * B, (r + 1) * B)
-                    bad_full += int((g_full[3][sl] != cnt).sum().item())
-                    bad_full += int(((o_r[0][:B] != g_full[0][sl]).any(dim=2) & keep).sum().item())
-                    bad_full += int(((o_r[1][:B] != g_full[1][sl]) & keep).sum().item())
-                    bad_full += int(((o_r[2][:B] != g_full[2][sl]) & keep).sum().item())
-            rg.close()
-        gather_info = {"gather_verified": bad_records == 0 and bad_full == 0, "dist_world_size": dist.get_world_size(),
-                       "y355_comm_world": comm_world, "records_compared": world * B, "mismatching_records": bad_records,
-                       "mismatching_values_c_abi_route": bad_full,
-                       "truncated_images": shard.truncated_images(grecv[0]),
+                    for key, g in (("capped", G), ("full", G_full)):
+                        ref = torch.empty_like(g["send"][0])
+                        shard.pack_detections_kernel(*[t[:B] for t in o_r], B, ref, g["md"])
+                        torch.cuda.synchronize()
+                        bad[key] += int((ref != g["recv"][0][r * B:(r + 1) * B]).any(dim=1).sum().item())
+                    if g_full is not None:
+                        # the engine's padded outputs hold stale values past count[i]; the gathered arrays hold zeros there
+                        cnt = o_r[3][:B]
+                        keep = torch.arange(o_r[1].shape[1], device=dev)[None, :] < cnt[:, None]
+                        sl = slice(r * B, (r + 1) * B)
+                        bad_c_abi += int((g_full[3][sl] != cnt).sum().item())
+                        bad_c_abi += int(((o_r[0][:B] != g_full[0][sl]).any(dim=2) & keep).sum().item())
+                        bad_c_abi += int(((o_r[1][:B] != g_full[1][sl]) & keep).sum().item())
+                        bad_c_abi += int(((o_r[2][:B] != g_full[2][sl]) & keep).sum().item())
+            if not args.share_gpu:
+                rg.close()
+        gather_info = {"gather_verified": bad["capped"] == 0 and bad["full"] == 0 and not bad_c_abi,
+                       "dist_world_size": dist.get_world_size(), "dist_backend": args.dist_backend,
+                       **({"share_gpu": "all %d ranks on cuda:0; the records are staged through the host for gloo: the rate of "
+                                        "this run is a logic test, not a performance number" % world} if args.share_gpu else {}),
+                       "y355_comm_world": comm_world, "records_compared": world * B, "mismatching_records": bad["capped"],
+                       "mismatching_records_full": bad["full"],
+                       "mismatching_values_c_abi_route": bad_c_abi,
+                       "truncated_images": shard.truncated_images(G["recv"][0]),
+                       "gather_full_records": {
+                           "value": round(world * B * args.steps / dt_full, 1), "unit": "images/sec",
+                           "ms_per_step": round(dt_full / args.steps * 1e3, 4), "detections_per_image": eng.max_det,
+                           "record_bytes": shard.record_bytes(eng.max_det), "truncated_images": shard.truncated_images(G_full["recv"][0]),
+                           "note": "the timed region with the engine's full max_det per record instead of the %d-detection cap" % gather_md},
                        "how": "rank 0 re-ran every rank's shard on its own GPU and compared the gathered bytes (torch.distributed "
-                              "records of the timed path, and full records through y355_pack_dets / y355_allgather_dets / y355_unpack_dets)"}
+                              "records of the timed path's cap and full records" +
+                              ("; the C ABI route needs one GPU per rank: skipped)" if args.share_gpu else
+                               ", and full records through y355_pack_dets / y355_allgather_dets / y355_unpack_dets)")}
         dist.barrier()
 
     # per-kernel device time with HIP events on the engine's stream (separate profiled steps)
@@ -669,10 +756,32 @@ def main():
                 eng.forward_device(x, 0, bufs[0])
             kacc.append(eng.profile_kernels_ms())
     eng.profile(False)
+    # the launches' own durations INSIDE the throughput mode (every handle in profile mode 2, steps alternating as in the timed
+    # region; a handle's timestamps are read just before its next step, `streams` steps later, so the overlap is kept)
+    kreg = []
+    if nstreams > 1:
+        for e in engines:
+            e.profile(2)
+            e.set_option(2, ring_wgs)
+        nreg = max(4 * nstreams, min(args.steps, 30))
+        for i in range(nreg):
+            e = engines[i % nstreams]
+            with torch.cuda.stream(streams[i % nstreams]):
+                if i >= 2 * nstreams:
+                    kreg.append(e.profile_kernels_ms())
+                if fs is not None:
+                    e.forward_frames_device(fs[i % N_INPUTS], 0, bufs[i % nbuf])
+                else:
+                    e.forward_device(xs[i % N_INPUTS], 0, bufs[i % nbuf])
+        torch.cuda.synchronize()
+        for e in engines:
+            e.profile(False)
+            e.set_option(2, 0)
+    kernel_ms_region = np.median(np.array(kreg), axis=0) if kreg else None
     layer_ms = np.median(np.array(acc), axis=0)
     kernel_ms = np.median(np.array(kacc), axis=0)    # the launches' own start / end timestamps: 10 layers + the 4 head / NMS launches
     from yolo355.engine import mfma_peak_i8
-    peak_tops, peak_clock = mfma_peak_i8(local_rank, 50.0) if rank == 0 else (0.0, 0.0)
+    peak_tops, peak_clock = mfma_peak_i8(dev_index, 50.0) if rank == 0 else (0.0, 0.0)
     ndet = int(out[3][:B].sum().item())
 
     if rank == 0:
@@ -697,7 +806,7 @@ def main():
                 continue
             else:
                 layers[n] = dict(ms=round(float(layer_ms[i]), 4), tops=round(B * 2e6 * LAYER_MMAC[i] / (layer_ms[i] * 1e-3) / 1e12, 1))
-        traffic, traffic_src = pmc_traffic(DOMINANT_KERNEL)
+        traffic, traffic_src, traffic_kernel = pmc_traffic(DOMINANT_KERNEL)
         res = {
             "metric": "images/sec slim_yolo_v2 int8 416x416", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -706,8 +815,11 @@ def main():
             "config": {"workload": "slim_yolo_v2_q_bf int8, batch %d per GPU, 416x416, 2 classes, conf 0.01" % B,
                        "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
                        "streams_per_gpu": nstreams, "ring_workgroups_per_launch": ring_wgs if ring_wgs else "one per CU",
-                       **({"gather": "one all_gather_into_tensor per batch, %d detections per image (%d bytes per record)"
-                                     % (gather_md, shard.record_bytes(gather_md))} if dist_on else {}),
+                       **({"gather": "one all_gather_into_tensor per batch (%s), records capped at %d detections per image (%d bytes); "
+                                     "this fixture has %d detections per image on average, so %d of rank 0's %d images are cut at the cap "
+                                     "(header word 1 > word 0 tells the receiver); the same region with full records: gather_full_records"
+                                     % (args.dist_backend, gather_md, shard.record_bytes(gather_md), ndet // B,
+                                        gather_info["truncated_images"] // world if gather_info else -1, B)} if dist_on else {}),
                        "input": args.input, "input_batches_rotated": N_INPUTS,
                        "detections_per_step_rank0": ndet},
             # the timed region (exactly `steps` steps between barrier + synchronize) was run `repeats` times: value and
@@ -721,13 +833,18 @@ def main():
             "roofline": {"whole_path_frac": round(value / world * OPS_PER_IMAGE / PEAK_I8_DENSE, 4),
                          "bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": round(dom_tops * 1e12 / PEAK_I8_DENSE, 4),
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_kernel": traffic_kernel,
                          "kernel": DOMINANT_KERNEL + ", true> (conv6 and conv7: 2 launches/step, the largest share of "
                                    "the step of any kernel; int8 ops = 2 x 398.72e6 MAC x %d images per launch)" % B,
                          "launch_ms": round(dom_ms, 4),
                          "launch_ms_source": ("kernel start/end timestamps of the launch (hipExtLaunchKernelGGL events), mean of "
                                               "conv6 and conv7, median of %d profiled steps on the engine's stream" % nprof) if have_k
                          else "interval between hipEventRecord before / after the launch",
+                         # the same launches while `streams` handles share the GPU (the timed region's regime: `ring_workgroups`
+                         # persistent workgroups per launch, other handles' kernels beside them); `frac` describes the kernel alone
+                         # on an idle GPU, whole_path_frac the run
+                         "launch_ms_in_timed_region": (round(float(kernel_ms_region[7] + kernel_ms_region[8]) / 2, 4)
+                                                       if kernel_ms_region is not None and kernel_ms_region[7] > 0 else None),
                          "launch_ms_between_events": round(dom_between, 4),
                          "frac_between_events": round(B * 2e6 * LAYER_MMAC[7] / (dom_between * 1e-3) / PEAK_I8_DENSE, 4),
                          # every launch's own duration (ms): layers (the fused front end under "conv1"), then the head / NMS kernels
@@ -736,11 +853,16 @@ def main():
                                                  ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
                                        if kernel_ms[i] > 0},
                          "kernel_ms_sum": round(float(kernel_ms.sum()), 4),
+                         "kernel_ms_in_timed_region": ({n: round(float(kernel_ms_region[i]), 4) for i, n in
+                                                        enumerate((["conv1+conv2 (fused front end)"] if fused else ["conv1"]) + LAYER_NAMES[1:] +
+                                                                  ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
+                                                        if kernel_ms_region[i] > 0} if kernel_ms_region is not None else None),
                          # MFMA-only loop MEASURED IN THIS RUN (y355_mfma_peak_i8: v_mfma_i32_16x16x64_i8 back to back on register
                          # operands, two waves per SIMD on every CU, ~50 ms) and the in-kernel clock it held
                          "peak_measured": round(peak_tops, 1),
                          "peak_measured_implied_clock_ghz": round(peak_tops * 1e12 / (1024 * 32768 / 16) / 1e9, 3),   # 16 cycles per MFMA and SIMD
                          "frac_of_measured_peak": round(dom_tops / peak_tops, 4) if peak_tops else None,
+                         "whole_path_frac_of_measured_peak": round(value / world * OPS_PER_IMAGE / (peak_tops * 1e12), 4) if peak_tops else None,
                          "all_conv_achieved": round(achieved, 2),
                          "all_conv_frac": round(achieved * 1e12 / PEAK_I8_DENSE, 4),
                          "layers": layers,
@@ -769,7 +891,8 @@ def main():
                 r = measure_net(a2)
                 oc[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "images/sec",
                           "ms_per_step": r["ms_per_step"], "steps": r["steps"], "dtype": r["dtype"],
-                          "streams_per_gpu": r["config"]["streams_per_gpu"], "one_stream": r["one_stream"],
+                          "streams_per_gpu": r["config"]["streams_per_gpu"], "input_batches_rotated": r["config"]["input_batches_rotated"],
+                          "timing": r["timing"], "parity": r["parity"], "one_stream": r["one_stream"],
                           "conv_roofline_frac": r["roofline"]["frac"], "conv_achieved_tflops": r["roofline"]["achieved"],
                           "peak_tflops": r["roofline"]["peak"]}
             res["other_configs"] = oc
@@ -787,7 +910,7 @@ def main():
     failed = gather_info is not None and not gather_info["gather_verified"]
     if dist_on:
         if world > 1:
-            flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+            flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=cdev)
             dist.broadcast(flag, 0)
             failed = bool(flag.item())
         dist.destroy_process_group()

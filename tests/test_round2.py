@@ -298,6 +298,8 @@ def test_config3_full_batch_slim_fp32(r2):
     assert rel <= 1.5e-2, rel
     ref = tuple(gold["%s/0/det0.01/%s" % (tag, k)] for k in ("boxes", "scores", "cls"))
     fr, fg = dets_close(ref, dets[0], 0.8, 0.05)
+    print("config 3, image 0: pred rel. L2 %.4f; %.3f of the reference's and %.3f of the engine's detections matched "
+          "(same class, IoU >= 0.8, |score err| <= 0.05); %d vs %d detections" % (rel, fr, fg, len(ref[1]), len(dets[0][1])))
     assert fr >= 0.8 and fg >= 0.8
     net.close()
 

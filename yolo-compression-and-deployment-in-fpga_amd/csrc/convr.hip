@@ -16,6 +16,7 @@
 // integer pipeline (32-bit form where the host proved it fits, else 64-bit), 4-byte stores, saturation counted; 2x2 max first
 // on pooled tiles; the store count per tile is static (rows outside the map go to a sink) so that the next tile's counted waits hold.
 #include "y355_common.h"
+#include <mutex>
 #include <hip/hip_ext.h>
 #include <type_traits>
 
@@ -500,8 +501,16 @@ constexpr Y355ConvRInfo g_info[NR] = {R0::info(), R1::info(), R2::info(), R3::in
 
 int y355_prepare_convr(int device) {
     if (device < 0 || device >= 16) return 1;
-    if (!g_sink[device]) {
-        if (hipMalloc((void **)&g_sink[device], 16384) != hipSuccess) return 1;
+    {
+        // one sink per device for the life of the process, allocated once whichever handle gets here first (two
+        // threads creating nets on one device raced on the pointer; the buffer only ever receives masked rows' stores)
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!g_sink[device]) {
+            char *ptr = nullptr;
+            if (hipMalloc((void **)&ptr, 16384) != hipSuccess) return 1;
+            g_sink[device] = ptr;
+        }
     }
     int e = R0::prepare();
     if (!e) e = R1::prepare();

@@ -85,11 +85,11 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // 14 MB of maps, 148 us)
 #define DEC_THREADS 256
 __host__ __device__ static inline int dec_cells(int A) { return DEC_THREADS / A; }
-__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const HeadParams p, const HeadWork wk, const int pitch) {
+__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const HeadParams p, const HeadWork wk, const int pitch, const int ncell_wg) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];        // dec_cells(A) x pitch bytes (pitch = cell bytes + 4: no bank conflicts)
     const int b = blockIdx.y;
     const int A = p.A, C = p.C;
-    const int NCELL = dec_cells(A);
+    const int NCELL = ncell_wg;               // cells per workgroup: dec_cells(A), fewer when their staged vectors would not fit the LDS
     const int HW0 = p.lev[0].Hs * p.lev[0].Ws, N0 = HW0 * A;
     const int HW1 = p.nlev > 1 ? p.lev[1].Hs * p.lev[1].Ws : 0, N1 = N0 + HW1 * A;
     const int HW2 = p.nlev > 2 ? p.lev[2].Hs * p.lev[2].Ws : 0;
@@ -943,14 +943,16 @@ void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws
         wk.ovf = (int *)ws.ovf;
         wk.rstride = ws.rstride;
         // every level's map has the same element size and padded channel count
-        const int ncell = dec_cells(p.A);
-        int nblk = 0, cellb = 0;
-        for (int l = 0; l < p.nlev; ++l) {
-            nblk += (p.lev[l].Hs * p.lev[l].Ws + ncell - 1) / ncell;
-            cellb = std::max(cellb, p.lev[l].cstride * (p.lev[l].pred ? 1 : 4));
-        }
+        // every level's map has the same element size and padded channel count; a workgroup stages dec_cells(A) cells, fewer
+        // when a cell is wide (few anchors x an fp32 map of 256 channels would need 263 KB): at most DEC_LDS bytes
+        constexpr int DEC_LDS = 128 * 1024;
+        int cellb = 0;
+        for (int l = 0; l < p.nlev; ++l) cellb = std::max(cellb, p.lev[l].cstride * (p.lev[l].pred ? 1 : 4));
         const int pitch = cellb + 4;
-        Y355_LAUNCH(decode_kernel, dim3(nblk, batch), dim3(DEC_THREADS), (size_t)ncell * pitch, s, k0[0], k0[1], p, wk, pitch);
+        const int ncell = std::max(1, std::min(dec_cells(p.A), DEC_LDS / pitch));
+        int nblk = 0;
+        for (int l = 0; l < p.nlev; ++l) nblk += (p.lev[l].Hs * p.lev[l].Ws + ncell - 1) / ncell;
+        Y355_LAUNCH(decode_kernel, dim3(nblk, batch), dim3(DEC_THREADS), (size_t)ncell * pitch, s, k0[0], k0[1], p, wk, pitch, ncell);
         if (large) hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(1024), 0, s, p, wk);
     }
     Y355_LAUNCH(head_kernel, dim3(batch), dim3(1024), 0, s, k1[0], k1[1], p, wk);

@@ -550,8 +550,10 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
             }
             L.w_bytes = y355_convg_packed_bytes(ki, in_kbytes(h, o), o.ksize * o.ksize, L.cout_pad);
             rc = nmalloc(h, (void **)&L.w_dev, L.w_bytes, true);
-            if (!rc && !h->bf && o.ksize == 1 && !o.stride2 && !o.res1 && L.cout_pad % 64 == 0 && in_kbytes(h, o) % 64 == 0 && in_kbytes(h, o) <= 1024 &&
-                Y355_USE_CONVR) {                              // int8 1x1: pointwise kernel of convr.hip (when the epilogue fits 32 bits)
+            // (the pointwise launcher derives its k-steps from the input buffer's pixel pitch and has no pool: only an op that
+            // consumes the WHOLE buffer, unpooled, may take it -- ADVICE r3)
+            if (!rc && !h->bf && o.ksize == 1 && !o.stride2 && !o.res1 && !o.pool && ti.pb == in_kbytes(h, o) && L.cout_pad % 64 == 0 &&
+                in_kbytes(h, o) % 64 == 0 && in_kbytes(h, o) <= 1024 && Y355_USE_CONVR) {                              // int8 1x1: pointwise kernel of convr.hip (when the epilogue fits 32 bits)
                 L.rid = -2;
                 L.wr_bytes = (size_t)(in_kbytes(h, o) / 64) * (L.cout_pad / 16) * 1024;
                 rc = nmalloc(h, (void **)&L.wr_dev, L.wr_bytes, true);
