@@ -146,13 +146,22 @@ def cpu_baseline(n_images=128):
                     sample="%d call(s) of %d image(s), %.1f s" % (done, batch, dt))
     # the headline entry: batches of 64 on every core until about 10 s of CPU work (every layer of a batch is one OpenMP loop
     # over image x output channel: oracle/yolo_oracle.c)
-    main = run(64, max(1, n_images // 64), ncores, 10.0)
-    grid = {"c_b64_all_cores": main, "c_b1_all_cores": run(1, 4, ncores), "c_b1_1_core": run(1, 1, 1),
+    # the GPU box's host reports 256 hardware threads but this loop stops scaling at about 16 (43.7 / 40.6 / 38.0 images/s at
+    # 16 / 64 / 256 threads, scratch/cpu_baseline_scaling.py: memory-bound planes, or a CPU quota): one call at each of a few
+    # team sizes, the headline sample at the best of them
+    probes = {}
+    for th in sorted({min(16, ncores), min(64, ncores), ncores}):
+        probes[th] = run(64, 1, th)
+    best = max(probes, key=lambda th: probes[th]["value"])
+    main = run(64, max(1, n_images // 64), best, 10.0)
+    grid = {"c_b64_best_threads": main, **{"c_b64_%d_threads" % th: v for th, v in probes.items()},
+            "c_b1_all_cores": run(1, 4, ncores), "c_b1_1_core": run(1, 1, 1),
             # one core at batch 64 would take minutes: a 4-image call on one thread measures the same per-image rate
             "c_b64_1_core": dict(run(4, 1, 1), note="4-image sample of the batch-64 case (one thread: the rate per image is batch-independent)")}
     _omp_threads(ncores)
-    head = dict(value=main["value"], unit="images/sec", cores=ncores, kind="port",
-                sample="%s, 416x416, whole path (conv1..pred, decode, NMS) through oracle/yolo_oracle.c with OpenMP" % main["sample"])
+    head = dict(value=main["value"], unit="images/sec", cores=best, kind="port",
+                sample="%s, 416x416, whole path (conv1..pred, decode, NMS) through oracle/yolo_oracle.c on %d OpenMP threads "
+                       "(the best of %s; the host reports %d)" % (main["sample"], best, sorted(probes), ncores))
     return head, grid
 
 

@@ -259,6 +259,16 @@ def test_int8_tiny_bit_exact(case, gold):
         g = gold["%s/%s" % (tag, n)].astype(np.float64)
         rel = np.sqrt(((ref["preds"][k] - g) ** 2).sum() / (g ** 2).sum())
         assert rel <= 8e-2, "%s %s: int8 vs fp32 reference, relative L2 error %.3g" % (tag, n, rel)
+    # round 4: a forward without the tap runs conv_1 + pool and conv_2 + pool in ONE launch (front.hip, the q_bf engine's fused
+    # front end with the 205 / 2048 slope): every tensor from conv_2's on, the counters and the detections are the same
+    # (conv_1's own map is not written by that launch: it still holds the tap forward's)
+    tap_t = [net.get_tensor(t, B) for t in range(net.num_tensors)]
+    out2 = net.forward(x)
+    for t in range(1, net.num_tensors):
+        assert np.array_equal(net.get_tensor(t, B), tap_t[t]), "tensor %d differs between the fused and the layer-by-layer front end" % t
+    assert net.counters() == ref["sat"]
+    for bi in range(B):
+        assert all(np.array_equal(a, b) for a, b in zip(out[bi], out2[bi]))
     net.close()
 
 

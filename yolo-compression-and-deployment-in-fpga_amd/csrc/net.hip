@@ -437,6 +437,13 @@ struct y355_net {
     bool sa_ok = false;
     std::vector<int> sa;
     Counters *ctr_dev = nullptr;      // [nops + 1]
+    // int8 nets whose graph starts with conv(3 -> 16) + pool, conv(16 -> 32) + pool (SlimYOLOv2, YOLOv3tiny:
+    // models/slim_yolo_v2.py:549-575, backbone/darknet.py:216-220): both layers in ONE launch of the q_bf engine's fused front
+    // end (front.hip) when their epilogues are exact in fp32 (y355_front_eligible); tap forwards run the layers one by one
+    bool front_graph = false, front_ok = false, front_dirty = true;
+    int8_t *wf_dev = nullptr;         // 16 KiB of front-end weight fragments (y355_pack_front)
+    int *fb1_dev = nullptr, *fb2_dev = nullptr;   // pre-shifted int32 biases of the two layers
+    Requant frq1{}, frq2{};
     int profile = 0;
     std::vector<hipEvent_t> ev;
     std::vector<void *> allocs;
@@ -568,6 +575,20 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
         }
         if (!rc) rc = nmalloc(h, (void **)&L.bias_dev, sizeof(float) * L.cout_pad, true);
         if (!rc) rc = nmalloc(h, (void **)&L.bias_w_dev, sizeof(long long) * L.cout_pad, true);
+    }
+    if (!rc && !h->bf && A.nops >= 2) {
+        const OpDef &o0 = A.ops[0], &o1 = A.ops[1];
+        bool fg = o0.type == OP_CONV1 && o0.cout == 16 && o0.pool == 1 && o1.type == OP_CONV && o1.in == o0.out && o1.cin == 16 &&
+                  o1.cout == 32 && o1.ksize == 3 && o1.pool == 1 && !o1.stride2 && !o1.res1 && o1.choff == 0 &&
+                  h->T[o1.out].pb == 32 && h->T[o1.out].halo == 1 && !h->T[o1.out].pred && cfg->height % 4 == 0 && cfg->width % 4 == 0;
+        for (int i = 2; fg && i < A.nops; ++i)                     // nobody else reads conv1's map
+            if (A.ops[i].in == o0.out || A.ops[i].res1 - 1 == o0.out) fg = false;
+        if (fg) {
+            h->front_graph = true;
+            rc = nmalloc(h, (void **)&h->wf_dev, 16384, true);
+            if (!rc) rc = nmalloc(h, (void **)&h->fb1_dev, sizeof(int) * 16, true);
+            if (!rc) rc = nmalloc(h, (void **)&h->fb2_dev, sizeof(int) * 32, true);
+        }
     }
     const size_t cap = Y355_NMS_CAP;
     if (!rc) rc = nmalloc(h, (void **)&h->absmax_dev, 16, true);
@@ -716,6 +737,13 @@ extern "C" int y355_net_load_layer_i8(y355_net *h, int idx, const int8_t *q_w, c
             HIPCHK(hipMemcpy(L.wr_dev, pr.data(), pr.size(), hipMemcpyHostToDevice));
         }
     }
+    if (h->front_graph && (L.op == 0 || L.op == 1)) {
+        std::vector<int8_t> wf(16384);
+        y355_pack_front(L.op == 0 ? q_w : nullptr, L.op == 1 ? q_w : nullptr, wf.data());
+        if (L.op == 0) HIPCHK(hipMemcpy(h->wf_dev, wf.data(), 4096, hipMemcpyHostToDevice));
+        else HIPCHK(hipMemcpy(h->wf_dev + 4096, wf.data() + 4096, 16384 - 4096, hipMemcpyHostToDevice));
+        h->front_dirty = true;
+    }
     L.q_b.assign(q_b, q_b + cout);
     L.e_w = e_w;
     L.e_b = e_b;
@@ -840,9 +868,29 @@ static int refresh_i8(y355_net *h) {
             // int8 nets have no float bias: the layer's bias_dev (4 bytes per channel) holds the 32-bit copy
             HIPCHK(hipMemcpyAsync(L.bias_dev, bt.data(), sizeof(int32_t) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
         }
+        if (h->front_graph && (i == 0 || i == 1)) {
+            // the same epilogue for front.hip: t = acc * 2^shl + bias below 2^24 (exact in fp32) on the layer's own weights
+            Requant &fr = i == 0 ? h->frq1 : h->frq2;
+            fr = Requant{};
+            fr.shl = shl; fr.sh = sh; fr.lk = lk; fr.neg_mul = nm; fr.leaky = (lk || nm != 1) ? 1 : 0; fr.guard_log2 = 63;
+            const long double accmax = L.wabs > 0 ? (long double)127 * L.wabs : (long double)127 * 127 * o.ksize * o.ksize * o.cin;
+            const long double tb = accmax * std::ldexp(1.0L, shl) + bmax;
+            fr.tmax_log2 = 0;
+            while (fr.tmax_log2 < 62 && std::ldexp(1.0L, fr.tmax_log2) <= tb) ++fr.tmax_log2;
+            // the magic-number rounding needs |t * slope| < 2^22 only where it does not saturate, and |sh| moderate
+            fr.wide = (fr.tmax_log2 > 24 || bmax >= std::ldexp(1.0L, 24) || sh > 30 || sh - lk < -8 || nm < 1 || nm > (1 << lk)) ? 1 : 0;
+            std::vector<int32_t> fb(i == 0 ? 16 : 32, 0);
+            if (!fr.wide) for (int c = 0; c < L.cout; ++c) fb[c] = (int32_t)bw[c];
+            HIPCHK(hipMemcpyAsync(i == 0 ? h->fb1_dev : h->fb2_dev, fb.data(), sizeof(int32_t) * fb.size(), hipMemcpyHostToDevice, h->stream));
+            h->front_dirty = true;
+        }
         HIPCHK(hipMemcpyAsync(L.bias_w_dev, bw.data(), sizeof(long long) * L.cout_pad, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         L.dirty = false;
+    }
+    if (h->front_graph && h->front_dirty) {
+        h->front_ok = y355_front_eligible(h->frq1, h->frq2);
+        h->front_dirty = false;
     }
     return 0;
 }
@@ -1125,8 +1173,33 @@ extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int 
         if (int rc = refresh_i8(h)) return rc;
         HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * (nops + 1), h->stream));
     }
+    // tap forwards (parity tests read every tensor) run the first two layers one by one: the fused launch does not write conv1's map
+    const bool fuse_front = !h->bf && h->front_graph && h->front_ok && !(flags & Y355_F_TAP);
     for (int i = 0; i < nops; ++i) {
         if (prof) HIPCHK(hipEventRecord(h->ev[i], h->stream));
+        if (fuse_front && i < 2) {
+            if (i == 0) {
+                if (!h->L[h->arch->ops[0].layer].loaded || !h->L[h->arch->ops[1].layer].loaded)
+                    return y355_fail(Y355_ENOTREADY, "layer weights not loaded");
+                FrontParams fp{};
+                fp.x = x_dev;
+                fp.out = (int8_t *)h->T[h->arch->ops[1].out].dev;
+                fp.wf = h->wf_dev;
+                fp.bias1 = h->fb1_dev;
+                fp.bias2 = h->fb2_dev;
+                fp.ctr = h->ctr_dev;                                // [0] conv1 (+ input), [1] conv2: the two ops' own counters
+                fp.B = batch;
+                fp.H = h->cfg.height;
+                fp.W = h->cfg.width;
+                y355_front_tiles(fp.H, fp.W, &fp.tiles_x, &fp.tiles_y);
+                fp.in_scale = std::ldexp(1.0f, h->sa_in);
+                fp.rq1 = h->frq1;
+                fp.rq2 = h->frq2;
+                y355_launch_front(fp, h->stream);
+                HIPCHK(hipGetLastError());
+            }
+            continue;
+        }
         if (int rc = run_op(h, i, batch, x_dev)) return rc;
     }
     if (prof) HIPCHK(hipEventRecord(h->ev[nops], h->stream));
