@@ -344,6 +344,9 @@ int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *out_max);
 int y355_net_max_det(y355_net *h);
 int y355_net_num_anchors_total(y355_net *h);
 int y355_net_sync(y355_net *h);
+/* Diagnostics (no reference counterpart): the last forward's NMS work per image -- count[batch] candidates at or above
+ * conf_thresh, nedges[2 * batch] = (suppressing pairs listed, 1 when the list was abandoned for the sorted walk).  Synchronous. */
+int y355_net_debug_nms(y355_net *h, int batch, int32_t *count, int32_t *nedges);
 /* heads with more than 4096 anchors per image (yolo_v3 at 416 x 416): *overflow = 1 if, in a forward since the last call, more
  * than 4096 anchors of an image passed conf_thresh (the excess was dropped: raise the threshold); synchronous; clears the flag */
 int y355_net_overflow(y355_net *h, int *overflow);

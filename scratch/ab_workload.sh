@@ -7,7 +7,7 @@ for round in $(seq 1 ${2:-3}); do
 for f in scratch/variants/lib_*.so; do
   n=$(basename $f .so); n=${n#lib_}
   cp $f $PKG/yolo355/libyolo355.so
-  python bench.py --workload $1 --steps 10 --warmup 3 --streams 1 2>/dev/null | python -c "
+  python bench.py --workload $1 --steps 10 --warmup 3 --streams ${STREAMS:-1} 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
 print('$n round $round: %.0f img/s  conv frac %.4f  head_ms %s nms_ms %s' % (d['value'], r['frac'], r.get('head_ms'), r.get('nms_ms')))"

@@ -32,6 +32,7 @@
 #define NMS_CAP Y355_NMS_CAP   // max anchors per image handled by this head (416x416: 3380)
 #define NBLK (NMS_CAP / 64)
 #define MAXA Y355_HEAD_MAXA
+#define MAXG Y355_HEAD_MAXG
 #define NGROUP 16                 // candidate groups (area octaves) of the sort; NGROUP * Hb * Wb <= NMS_CAP
 #define EDGE_CAP (NMS_CAP * 64)   // suppressing pairs per image the global list holds
 #define WG_EDGE_CAP 8192         // edges one pairs workgroup buffers in LDS
@@ -45,7 +46,7 @@ struct HeadWork {
     unsigned int *edges;  // [B][EDGE_CAP] suppressing pairs (p << 12) | q with p < q (compact positions)
     int *nedges;          // [B][2]        number of edges; overflow flag (a list did not fit)
     int *binstart;        // [B][CAP+8]   first compact position of bin (a*HW + by*Ws + bx)
-    float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
+    float *astat;         // [B][MAXG][4] per candidate group: wmax, hmax, amin, amax (clamped boxes)
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
     int *ntiny;           // [B]
     int *ctype;           // [B][CAP]     candidate group of compact position p
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const HeadParams p, const
 __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const HeadWork wk) {
     __shared__ int hist[NMS_CAP];          // bin counts -> bin starts
     __shared__ int wsum[16];
-    __shared__ unsigned int sstat[MAXA][4];
+    __shared__ unsigned int sstat[MAXG][4];
     __shared__ int ntiny_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     NSTAMP(0, blockIdx.x, 0);
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     const int N = compacted ? wk.rcount[b] : N1 + HW2 * A;
     const int HWb = p.Hb * p.Wb;
     for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
-    if (tid < MAXA) {
+    if (tid < MAXG) {
         sstat[tid][0] = 0u;                 // wmax
         sstat[tid][1] = 0u;                 // hmax
         sstat[tid][2] = 0x7f7fffffu;        // amin
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     __syncthreads();
     NSTAMP(0, blockIdx.x, 1);
 
+    const int G0 = p.group_by_area ? NGROUP : A * p.nlev;      // groups per class
     float box[4][4], score[4];
-    int cls[4], orig[4], key[4], rk[4], ktu[4];
+    int cls[4], orig[4], key[4], rk[4], ktu[4], kb[4] = {0, 0, 0, 0};
     bool valid[4];
     int tkt = -1;                                          // group of this thread's candidates (mixed: more than one)
     bool mixed = false;
@@ -288,7 +290,10 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 // size.  Per-group extents, bin of the clamped centre inside the group.
                 const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
                 const int ex = (int)((__float_as_uint(ar) >> 23) & 0xffu) - 127;     // floor(log2 area), area <= 1
-                const int kt = p.group_by_area ? min(NGROUP - 1, max(0, -ex - 1)) : lv * A + a;
+                // class-major (p.cls_groups = C > 1): per-class NMS never pairs two classes, so a class's candidates form their
+                // own set of groups and the pair walk only visits its own class (round 4: half the pair tests of a two-class head)
+                const int kt0 = p.group_by_area ? min(NGROUP - 1, max(0, -ex - 1)) : lv * A + a;
+                const int kt = p.cls_groups > 1 ? min(max(cls[u], 0), p.cls_groups - 1) * G0 + kt0 : kt0;
                 const float ccx = 0.5f * (box[u][0] + box[u][2]), ccy = 0.5f * (box[u][1] + box[u][3]);
                 const int bx = min(p.Wb - 1, max(0, (int)(ccx * (float)p.Wb)));
                 const int by = min(p.Hb - 1, max(0, (int)(ccy * (float)p.Hb)));
@@ -297,8 +302,11 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 rk[u] = atomicAdd(&hist[key[u]], 1);
                 // per-group extents: accumulated per thread, merged per wave below (four same-address LDS atomics per
                 // candidate serialised the whole workgroup: 29 k cycles, bank-conflict share 0.89)
-                if (tkt >= 0 && tkt != kt) mixed = true;
-                tkt = kt;
+                // the extents are kept per BASE group (over all classes: a valid, slightly wider pruning bound), so that a wave
+                // of one anchor type still reduces them with one butterfly whatever the classes of its candidates
+                if (tkt >= 0 && tkt != kt0) mixed = true;
+                tkt = kt0;
+                kb[u] = kt0;
                 tst[0] = max(tst[0], __float_as_uint(w));
                 tst[1] = max(tst[1], __float_as_uint(h));
                 tst[2] = min(tst[2], __float_as_uint(ar));
@@ -333,10 +341,10 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 for (int u = 0; u < 4; ++u) {
                     if (valid[u]) {
                         const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
-                        atomicMax(&sstat[ktu[u]][0], __float_as_uint(w));
-                        atomicMax(&sstat[ktu[u]][1], __float_as_uint(h));
-                        atomicMin(&sstat[ktu[u]][2], __float_as_uint(ar));
-                        atomicMax(&sstat[ktu[u]][3], __float_as_uint(ar));
+                        atomicMax(&sstat[kb[u]][0], __float_as_uint(w));
+                        atomicMax(&sstat[kb[u]][1], __float_as_uint(h));
+                        atomicMin(&sstat[kb[u]][2], __float_as_uint(ar));
+                        atomicMax(&sstat[kb[u]][3], __float_as_uint(ar));
                     }
                 }
             }
@@ -397,10 +405,11 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             if ((box[u][2] - box[u][0]) * (box[u][3] - box[u][1]) < AREA_MIN) tl[atomicAdd(&ntiny_s, 1)] = pos;
         }
     }
-    if (tid < MAXA) {
-        float *as = wk.astat + ((size_t)b * MAXA + tid) * 4;
+    if (tid < MAXG) {                                       // group c * G0 + g of class c takes base group g's extents
+        float *as = wk.astat + ((size_t)b * MAXG + tid) * 4;
+        const int src = tid < G0 * p.cls_groups ? tid % G0 : tid;       // (entries >= G0 keep their initial "empty" values)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) as[k] = __uint_as_float(sstat[tid][k]);
+        for (int k = 0; k < 4; ++k) as[k] = __uint_as_float(sstat[src][k]);
     }
     __syncthreads();
     NSTAMP(0, blockIdx.x, 6);
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     int2 *scls = (int2 *)(plds + NMS_CAP * 16);                      // [CAP] (class | group << 16, area of the box as computed here)
     int *sbin = (int *)(plds + NMS_CAP * 24);                        // [CAP + 8]
     unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 24 + (NMS_CAP + 8) * 4);   // [16][WAVE_EDGE_CAP]
-    __shared__ float as[MAXA * 4];                         // per-group extents
+    __shared__ float as[MAXG * 4];                         // per-group extents
     const int b = blockIdx.y;
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 0);
     const int M = wk.count[b];
@@ -488,7 +497,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     const int nruns = (M * L + 63) >> 6;                    // 64-lane runs of the image
     if ((int)blockIdx.x >= nruns) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int A = p.group_by_area ? NGROUP : p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // candidate groups, bin grid
+    const int G0 = p.group_by_area ? NGROUP : p.A * p.nlev;                   // groups per class
+    const int A = G0 * p.cls_groups, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;      // candidate groups, bin grid
     {
         const float4 *cbx4 = (const float4 *)(wk.cbox + (size_t)b * NMS_CAP * 4);
         const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
@@ -522,13 +532,13 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
             const int q = tid + u * 1024;
             if (q <= A * HW) sbin[q] = vs[u];
         }
-        if (tid < MAXA * 4) as[tid] = wk.astat[(size_t)b * MAXA * 4 + tid];
+        if (tid < MAXG * 4) as[tid] = wk.astat[(size_t)b * MAXG * 4 + tid];
     }
     __syncthreads();
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool fast = FAST;                            // 1e-4 <= thr < 1e4: the pruning bounds hold (host-checked)
-    const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f, inv_thr_lo = 1.0f / thr_lo;
+    const float kr = (1.0f - thr) * 0.5f * PRUNE_MARGIN, thr_lo = thr * 0.999f;
     const float q_hi = thr * (1.0f + 8e-6f), q_lo = thr * (1.0f - 8e-6f);
     bool lost = false;
     unsigned int *wedge = sedge + wave * WAVE_EDGE_CAP;
@@ -626,20 +636,17 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         const int by_i = min(Hs - 1, max(0, (int)(cyi * (float)Hs)));
         // candidates are sorted by group: lane 0 holds the run's lowest one, and lower groups only hold positions < i
         const int a_lo = __builtin_amdgcn_readfirstlane(a_i);
+        const int a_end = vi ? (a_i / G0 + 1) * G0 : 0;        // class-major groups: my class's groups end here (one class: A)
         for (int a2 = a_lo; a2 < A && !aborted; ++a2) {
             const float amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
             if (amax < amin) continue;                         // no candidate of this group (uniform)
             const bool prune = fast && (ai + amin >= AREA_MIN);
-            bool act = a2 >= a_i;
+            bool act = a2 >= a_i && a2 < a_end;
             if (prune && (ai <= thr_lo * amin || amax <= thr_lo * ai)) act = false;    // area ratio rules the group out
             if (!__any(act)) continue;
             int bx0 = 0, bx1 = Ws - 1, by0 = 0, by1 = Hs - 1;
             if (prune) {
-                // a partner j with IoU > thr has w_j <= w_i / thr and h_j <= h_i / thr (the intersection is at most w_i h_j, the
-                // union at least w_j h_j): the group's widest / tallest box bounds the window only up to that (round 4: an area
-                // octave of the fp32 heads holds 1.0 x 0.06 boxes beside 0.25 x 0.25 ones, and every narrow candidate walked the
-                // whole width of the bin grid)
-                const float wmax = fminf(as[a2 * 4 + 0], wi * inv_thr_lo), hmax = fminf(as[a2 * 4 + 1], hi * inv_thr_lo);
+                const float wmax = as[a2 * 4 + 0], hmax = as[a2 * 4 + 1];
                 const float rx = kr * (wi + wmax) + PRUNE_EPS, ry = kr * (hi + hmax) + PRUNE_EPS;
                 bx0 = max(0, (int)floorf((cxi - rx) * (float)Ws));
                 bx1 = min(Ws - 1, (int)floorf((cxi + rx) * (float)Ws));
@@ -916,8 +923,24 @@ int y355_prepare_head(void) {
     return (int)hipFuncSetAttribute((const void *)pairs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
 }
 
-void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid,
+void y355_launch_head_nms(const HeadParams &p_in, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid,
                           hipEvent_t (*kev)[2]) {
+    // Class-major candidate groups (round 4).  NMS is per class (models/slim_yolo_v2.py:196-203): with few classes every class
+    // gets its own copy of the groups (anchor types / area octaves), the sort orders candidates (class, group, bin) and the pair
+    // walk only visits the candidate's own class -- half the pair tests of a two-class head.  Needs C * groups <= MAXG and all
+    // groups' bins inside the CAP-entry tables: the bin grid (any grid over the clamped centres works) shrinks until they do.
+    HeadParams p = p_in;
+    p.cls_groups = 1;
+    {
+        const int G0 = p.group_by_area ? NGROUP : p.A * p.nlev;
+        if (p.C >= 2 && G0 * p.C <= MAXG) {
+            int hb = p.Hb, wb = p.Wb;
+            while (G0 * p.C * hb * wb > NMS_CAP && (hb > 4 || wb > 4)) {
+                if (hb >= wb) --hb; else --wb;
+            }
+            if (G0 * p.C * hb * wb <= NMS_CAP) { p.cls_groups = p.C; p.Hb = hb; p.Wb = wb; }
+        }
+    }
     hipEvent_t none[2] = {nullptr, nullptr};
     hipEvent_t *k0 = kev ? kev[0] : none, *k1 = kev ? kev[1] : none, *k2 = kev ? kev[2] : none, *k3 = kev ? kev[3] : none;
     HeadWork wk;

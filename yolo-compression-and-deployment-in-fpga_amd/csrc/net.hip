@@ -1300,6 +1300,17 @@ extern "C" int y355_net_overflow(y355_net *h, int *overflow) {
     return 0;
 }
 
+// diagnostics: candidates and suppressing pairs per image of the last forward's NMS (count[batch], nedges[2 * batch]: list
+// length, overflow / abort flag); synchronous
+extern "C" int y355_net_debug_nms(y355_net *h, int batch, int32_t *count, int32_t *nedges) {
+    if (!h || !count || !nedges || batch < 1 || batch > h->cfg.max_batch) return y355_fail(Y355_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(count, h->ws.count, sizeof(int) * batch, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nedges, h->ws.nedges, sizeof(int) * 2 * batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int y355_net_sync(y355_net *h) {
     if (!h) return y355_fail(Y355_EINVAL, "null net");
     HIPCHK(hipSetDevice(h->cfg.device_id));

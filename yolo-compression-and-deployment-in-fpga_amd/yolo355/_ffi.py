@@ -138,6 +138,7 @@ _SIGS = {
     "y355_net_max_det": (C.c_int, [C.c_void_p]),
     "y355_net_num_anchors_total": (C.c_int, [C.c_void_p]),
     "y355_net_sync": (C.c_int, [C.c_void_p]),
+    "y355_net_debug_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "y355_net_overflow": (C.c_int, [C.c_void_p, P(C.c_int)]),
     "y355_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "y355_net_num_timers": (C.c_int, [C.c_void_p]),
