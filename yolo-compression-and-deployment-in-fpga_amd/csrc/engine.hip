@@ -297,7 +297,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.edges, sizeof(unsigned int) * 64 * cap * B, false);      // EDGE_CAP pairs per image
     if (!rc) rc = dmalloc(h, &h->ws.nedges, sizeof(int) * 2 * (size_t)B, true);
     if (!rc) rc = dmalloc(h, &h->ws.binstart, sizeof(int) * (cap + 8) * B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
+    if (!rc) rc = dmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXG * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.tiny, sizeof(int) * cap * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.ntiny, sizeof(int) * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.dbox, sizeof(float) * 4 * cap * B, true);

@@ -32,6 +32,7 @@
 #define NMS_CAP Y355_NMS_CAP   // max anchors per image handled by this head (416x416: 3380)
 #define NBLK (NMS_CAP / 64)
 #define MAXA Y355_HEAD_MAXA
+#define MAXG Y355_HEAD_MAXG
 #define NGROUP 16                 // candidate groups (area octaves) of the sort; NGROUP * Hb * Wb <= NMS_CAP
 #define EDGE_CAP (NMS_CAP * 64)   // suppressing pairs per image the global list holds
 #define WG_EDGE_CAP 8192         // edges one pairs workgroup buffers in LDS
@@ -45,7 +46,7 @@ struct HeadWork {
     unsigned int *edges;  // [B][EDGE_CAP] suppressing pairs (p << 12) | q with p < q (compact positions)
     int *nedges;          // [B][2]        number of edges; overflow flag (a list did not fit)
     int *binstart;        // [B][CAP+8]   first compact position of bin (a*HW + by*Ws + bx)
-    float *astat;         // [B][MAXA][4] per anchor: wmax, hmax, amin, amax (clamped boxes)
+    float *astat;         // [B][MAXG][4] per candidate group: wmax, hmax, amin, amax (clamped boxes)
     int *tiny;            // [B][CAP]     positions of candidates with area < AREA_MIN
     int *ntiny;           // [B]
     int *ctype;           // [B][CAP]     candidate group of compact position p
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const HeadParams p, const
 __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const HeadWork wk) {
     __shared__ int hist[NMS_CAP];          // bin counts -> bin starts
     __shared__ int wsum[16];
-    __shared__ unsigned int sstat[MAXA][4];
+    __shared__ unsigned int sstat[MAXG][4];
     __shared__ int ntiny_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     NSTAMP(0, blockIdx.x, 0);
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     const int N = compacted ? wk.rcount[b] : N1 + HW2 * A;
     const int HWb = p.Hb * p.Wb;
     for (int i = tid; i < NMS_CAP; i += 1024) hist[i] = 0;
-    if (tid < MAXA) {
+    if (tid < MAXG) {
         sstat[tid][0] = 0u;                 // wmax
         sstat[tid][1] = 0u;                 // hmax
         sstat[tid][2] = 0x7f7fffffu;        // amin
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
     NSTAMP(0, blockIdx.x, 1);
 
     float box[4][4], score[4];
-    int cls[4], orig[4], key[4], rk[4], ktu[4];
+    int cls[4], orig[4], key[4], rk[4], ktu[4], kb[4] = {0, 0, 0, 0};
     bool valid[4];
     int tkt = -1;                                          // group of this thread's candidates (mixed: more than one)
     bool mixed = false;
@@ -288,7 +289,12 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 // size.  Per-group extents, bin of the clamped centre inside the group.
                 const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
                 const int ex = (int)((__float_as_uint(ar) >> 23) & 0xffu) - 127;     // floor(log2 area), area <= 1
-                const int kt = p.group_by_area ? min(NGROUP - 1, max(0, -ex - 1)) : lv * A + a;
+                // p.cls_groups (heads with 3 .. 32 classes, round 4): the group IS the class -- per-class NMS never pairs two
+                // classes, so the pair walk of a candidate only visits its own class's bins (1 / C of the partners); the extents are
+                // then kept over ALL candidates (slot 0: one butterfly per wave): the window is bounded by the candidate's own
+                // size through w_j <= w_i / thr anyway
+                const int kt = p.cls_groups ? min(max(cls[u], 0), p.C - 1) : (p.group_by_area ? min(NGROUP - 1, max(0, -ex - 1)) : lv * A + a);
+                const int ks = p.cls_groups ? 0 : kt;                 // where its extents are accumulated
                 const float ccx = 0.5f * (box[u][0] + box[u][2]), ccy = 0.5f * (box[u][1] + box[u][3]);
                 const int bx = min(p.Wb - 1, max(0, (int)(ccx * (float)p.Wb)));
                 const int by = min(p.Hb - 1, max(0, (int)(ccy * (float)p.Hb)));
@@ -297,8 +303,9 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 rk[u] = atomicAdd(&hist[key[u]], 1);
                 // per-group extents: accumulated per thread, merged per wave below (four same-address LDS atomics per
                 // candidate serialised the whole workgroup: 29 k cycles, bank-conflict share 0.89)
-                if (tkt >= 0 && tkt != kt) mixed = true;
-                tkt = kt;
+                if (tkt >= 0 && tkt != ks) mixed = true;
+                tkt = ks;
+                kb[u] = ks;
                 tst[0] = max(tst[0], __float_as_uint(w));
                 tst[1] = max(tst[1], __float_as_uint(h));
                 tst[2] = min(tst[2], __float_as_uint(ar));
@@ -333,10 +340,10 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
                 for (int u = 0; u < 4; ++u) {
                     if (valid[u]) {
                         const float w = box[u][2] - box[u][0], h = box[u][3] - box[u][1], ar = w * h;
-                        atomicMax(&sstat[ktu[u]][0], __float_as_uint(w));
-                        atomicMax(&sstat[ktu[u]][1], __float_as_uint(h));
-                        atomicMin(&sstat[ktu[u]][2], __float_as_uint(ar));
-                        atomicMax(&sstat[ktu[u]][3], __float_as_uint(ar));
+                        atomicMax(&sstat[kb[u]][0], __float_as_uint(w));
+                        atomicMax(&sstat[kb[u]][1], __float_as_uint(h));
+                        atomicMin(&sstat[kb[u]][2], __float_as_uint(ar));
+                        atomicMax(&sstat[kb[u]][3], __float_as_uint(ar));
                     }
                 }
             }
@@ -397,10 +404,11 @@ __global__ __launch_bounds__(1024) void head_kernel(const HeadParams p, const He
             if ((box[u][2] - box[u][0]) * (box[u][3] - box[u][1]) < AREA_MIN) tl[atomicAdd(&ntiny_s, 1)] = pos;
         }
     }
-    if (tid < MAXA) {
-        float *as = wk.astat + ((size_t)b * MAXA + tid) * 4;
+    if (tid < MAXG) {                                       // class groups all take slot 0's (global) extents
+        float *as = wk.astat + ((size_t)b * MAXG + tid) * 4;
+        const int src = p.cls_groups ? (tid < p.C ? 0 : MAXG - 1) : tid;       // (slot MAXG - 1 is never written: "empty")
 #pragma unroll
-        for (int k = 0; k < 4; ++k) as[k] = __uint_as_float(sstat[tid][k]);
+        for (int k = 0; k < 4; ++k) as[k] = __uint_as_float(sstat[src][k]);
     }
     __syncthreads();
     NSTAMP(0, blockIdx.x, 6);
@@ -476,19 +484,25 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
     int2 *scls = (int2 *)(plds + NMS_CAP * 16);                      // [CAP] (class | group << 16, area of the box as computed here)
     int *sbin = (int *)(plds + NMS_CAP * 24);                        // [CAP + 8]
     unsigned int *sedge = (unsigned int *)(plds + NMS_CAP * 24 + (NMS_CAP + 8) * 4);   // [16][WAVE_EDGE_CAP]
-    __shared__ float as[MAXA * 4];                         // per-group extents
+    __shared__ float as[MAXG * 4];                         // per-group extents
     const int b = blockIdx.y;
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 0);
     const int M = wk.count[b];
     // L lanes share a candidate (each takes every L-th group of four partners of a bin row) when the image has few
     // candidates: 845 of them are 14 waves, 3-4 per workgroup, one per SIMD -- with L = 4 every SIMD gets four
     const int G = (int)gridDim.x;
+    // round 4: the walk is VALU-bound and a wave's time is its trips (stamps: 2-4 k cycles per trip of four partners with the
+    // workgroup's 16 waves active); the 64-candidate runs differ by 10x in trips (YOLOv3tiny: median 8, maximum 142), so an image
+    // with few candidates is cut into more, lighter runs: L lanes per candidate as long as M * L stays within PAIRS_LANES_BUDGET
+#ifndef PAIRS_LANES_BUDGET
+#define PAIRS_LANES_BUDGET 8192            // measured: 2048 / 4096 / 8192 / 16384 -> YOLOv3tiny NMS 146 / 91 / 86 / 94 us, SlimYOLOv2 fp32 147 / 148 / 114 / 127, q_bf headline 74.5 / 74.2 / 74.6 / 97.3
+#endif
     int L = 1;
-    while (L < 8 && M * 2 * L <= 16 * G * 64) L *= 2;
+    while (L < 8 && M * 2 * L <= PAIRS_LANES_BUDGET * G / 2) L *= 2;
     const int nruns = (M * L + 63) >> 6;                    // 64-lane runs of the image
     if ((int)blockIdx.x >= nruns) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int A = p.group_by_area ? NGROUP : p.A * p.nlev, Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // candidate groups, bin grid
+    const int A = p.cls_groups ? p.C : (p.group_by_area ? NGROUP : p.A * p.nlev), Ws = p.Wb, Hs = p.Hb, HW = Hs * Ws;   // candidate groups, bin grid
     {
         const float4 *cbx4 = (const float4 *)(wk.cbox + (size_t)b * NMS_CAP * 4);
         const int *ccl = wk.ccls + (size_t)b * NMS_CAP;
@@ -522,7 +536,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
             const int q = tid + u * 1024;
             if (q <= A * HW) sbin[q] = vs[u];
         }
-        if (tid < MAXA * 4) as[tid] = wk.astat[(size_t)b * MAXA * 4 + tid];
+        if (tid < MAXG * 4) as[tid] = wk.astat[(size_t)b * MAXG * 4 + tid];
     }
     __syncthreads();
     NSTAMP(1, (blockIdx.y * gridDim.x + blockIdx.x), 1);
@@ -630,7 +644,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
             const float amin = as[a2 * 4 + 2], amax = as[a2 * 4 + 3];
             if (amax < amin) continue;                         // no candidate of this group (uniform)
             const bool prune = fast && (ai + amin >= AREA_MIN);
-            bool act = a2 >= a_i;
+            bool act = p.cls_groups ? a2 == a_i : a2 >= a_i;       // class groups: only my own class
             if (prune && (ai <= thr_lo * amin || amax <= thr_lo * ai)) act = false;    // area ratio rules the group out
             if (!__any(act)) continue;
             int bx0 = 0, bx1 = Ws - 1, by0 = 0, by1 = Hs - 1;
@@ -916,8 +930,21 @@ int y355_prepare_head(void) {
     return (int)hipFuncSetAttribute((const void *)pairs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIRS_LDS);
 }
 
-void y355_launch_head_nms(const HeadParams &p, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid,
+void y355_launch_head_nms(const HeadParams &p_in, int batch, const y355_head_ws &ws, hipStream_t s, hipEvent_t mid,
                           hipEvent_t (*kev)[2]) {
+    // Heads with 3 .. MAXG classes sort their candidates (class, bin): NMS is per class (models/slim_yolo_v2.py:196-203,
+    // models/tiny_yolo_v3.py:129-136), so a candidate's partners all sit in its class's bins.  The bin grid (any grid over the
+    // clamped centres works) shrinks until C grids fit the CAP-entry tables.  Two-class heads keep the size groups: there the
+    // class split was measured slower (profiles/r04_notes.md).
+    HeadParams p = p_in;
+    p.cls_groups = 0;
+    if (p.C >= 3 && p.C <= MAXG) {
+        int hb = p.Hb, wb = p.Wb;
+        while (p.C * hb * wb > NMS_CAP && (hb > 4 || wb > 4)) {
+            if (hb >= wb) --hb; else --wb;
+        }
+        if (p.C * hb * wb <= NMS_CAP) { p.cls_groups = 1; p.Hb = hb; p.Wb = wb; }
+    }
     hipEvent_t none[2] = {nullptr, nullptr};
     hipEvent_t *k0 = kev ? kev[0] : none, *k1 = kev ? kev[1] : none, *k2 = kev ? kev[2] : none, *k3 = kev ? kev[3] : none;
     HeadWork wk;

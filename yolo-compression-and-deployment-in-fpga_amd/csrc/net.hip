@@ -601,7 +601,7 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (!rc) rc = nmalloc(h, &h->ws.edges, sizeof(unsigned int) * 64 * cap * B, false);      // EDGE_CAP pairs per image
     if (!rc) rc = nmalloc(h, &h->ws.nedges, sizeof(int) * 2 * (size_t)B, true);
     if (!rc) rc = nmalloc(h, &h->ws.binstart, sizeof(int) * (cap + 8) * B, true);
-    if (!rc) rc = nmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
+    if (!rc) rc = nmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXG * B, true);
     if (!rc) rc = nmalloc(h, &h->ws.tiny, sizeof(int) * cap * B, true);
     if (!rc) rc = nmalloc(h, &h->ws.ntiny, sizeof(int) * B, true);
     if (!rc) rc = nmalloc(h, &h->ws.dbox, sizeof(float) * 4 * cap * B, true);
@@ -1397,7 +1397,7 @@ extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, 
     if (!rc) rc = alloc(&w.edges, sizeof(unsigned int) * 64 * cap * B, false);
     if (!rc) rc = alloc(&w.nedges, sizeof(int) * 2 * (size_t)B, true);
     if (!rc) rc = alloc(&w.binstart, sizeof(int) * (cap + 8) * B, true);
-    if (!rc) rc = alloc(&w.astat, sizeof(float) * 4 * Y355_HEAD_MAXA * B, true);
+    if (!rc) rc = alloc(&w.astat, sizeof(float) * 4 * Y355_HEAD_MAXG * B, true);
     if (!rc) rc = alloc(&w.tiny, sizeof(int) * cap * B, true);
     if (!rc) rc = alloc(&w.ntiny, sizeof(int) * B, true);
     if (!rc) rc = alloc(&w.dbox, sizeof(float) * 4 * cap * B, true);

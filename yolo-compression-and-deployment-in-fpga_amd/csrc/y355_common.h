@@ -262,6 +262,7 @@ struct HeadParams {
     float wh_mul;         // w = exp(tw) * aw * wh_mul   (16: anchors in grid units; 1: pixels)
     int Hb, Wb;           // bin grid of the candidate sort
     int group_by_area;    // 0: candidates grouped by anchor type (bins = level 0's grid); 1: by area octave (<= 16 x 16 bins)
+    int cls_groups;       // set by y355_launch_head_nms: 1 = the groups are the CLASSES (per-class NMS never pairs two classes), else 0
     float in_w, in_h;     // network input size in pixels
     float conf_thresh, nms_thresh;
     float *cand_box;      // [B][N][4]
@@ -275,9 +276,10 @@ struct HeadParams {
 };
 #define Y355_NMS_CAP 4096   // anchors per image the NMS workspace is sized for
 #define Y355_HEAD_MAXA 16
+#define Y355_HEAD_MAXG 32   // candidate groups of the NMS sort: anchor types, area octaves, or -- heads with 3 .. 32 classes -- the classes
 // head_nms.hip workspace, per image: cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP], corig i32[CAP],
 // count i32, edges u32[64*CAP] (suppressing pairs), nedges i32[2] (count, overflow flag),
-// binstart i32[CAP+8], astat f32[16][4], tiny i32[CAP], ntiny i32, ctype i32[CAP] (candidate group),
+// binstart i32[CAP+8], astat f32[Y355_HEAD_MAXG][4], tiny i32[CAP], ntiny i32, ctype i32[CAP] (candidate group),
 // dbox f32[CAP][4] / dscore f32[CAP] / dcls i32[CAP] (decode of every anchor).
 // Heads with more than Y355_NMS_CAP anchors per image also need rbox f32[rstride][4], rscore f32[rstride], rcls i32[rstride]
 // (raw decode, rstride >= anchors per image), rcount i32, ovf i32 (more than CAP anchors passed conf_thresh: zero it before
