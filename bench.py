@@ -890,6 +890,41 @@ def main():
                                  "note": "one engine handle on one stream: ms_per_step is the latency of a batch"}
         if world == 1 and not args.no_sparse:
             res["sparse_fixture"] = sparse_fixture(args, dev, streams, x)
+        if world == 1 and not args.no_sparse and args.input == "f32":
+            # the same workload fed as uint8 HWC BGR frames (BaseTransform fused into the first layer): a quarter of
+            # the input bytes, same kernels behind the front end, same detections (tests/test_gpu_parity.py)
+            fr4 = torch.from_numpy(synth.make_frames_u8(1000, B, H, W)).to(dev)
+            frs = [fr4, torch.flip(fr4, (2,)).contiguous(), torch.flip(fr4, (1,)).contiguous(), torch.flip(fr4, (1, 2)).contiguous()][:N_INPUTS]
+            for e in engines:
+                e.set_option(2, ring_wgs)
+
+            def run_u8(n):
+                for i in range(n):
+                    with torch.cuda.stream(streams[i % nstreams]):
+                        engines[i % nstreams].forward_frames_device(frs[i % N_INPUTS], 0, bufs[i % nbuf])
+            run_u8(max(5, nstreams))
+            tu = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_u8(args.steps)
+                torch.cuda.synchronize()
+                tu.append(time.perf_counter() - t0)
+            for e in engines:
+                e.set_option(2, 0)
+            eng.profile(2)
+            with torch.cuda.stream(streams[0]):
+                ku = []
+                for _ in range(5):
+                    eng.forward_frames_device(frs[0], 0, bufs[0])
+                    ku.append(eng.profile_kernels_ms()[0])
+            eng.profile(False)
+            res["u8_input"] = {"value": round(B * args.steps / float(np.median(tu)), 1), "unit": "images/sec",
+                               "ms_per_step": round(float(np.median(tu)) / args.steps * 1e3, 4), "repeats": len(tu),
+                               "front_end_launch_ms": round(float(np.median(ku)), 4),
+                               "front_end_launch_ms_f32": round(float(kernel_ms[0]), 4),
+                               "note": "uint8 HWC BGR frames (33 MB per batch instead of 133 MB of fp32 planes); the front end is not "
+                                       "bound by its input bytes (profiles/r04_notes.md), so the two routes run at the same rate"}
         if world == 1 and not args.no_other_configs:
             # BASELINE.json configs[2] / configs[3], a few steps each: a driver-visible number for them
             import copy

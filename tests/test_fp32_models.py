@@ -295,3 +295,35 @@ def test_tiny_dropin_quantized():
         fr, fg = dets_close(f0[bi], q0[bi], 0.5, 0.2)
         assert fr >= 0.6 and fg >= 0.6
         assert abs(len(f0[bi][1]) - len(q0[bi][1])) <= 0.15 * len(f0[bi][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [FP32_CASES[0], TINY[0]], ids=["slim", "tiny"])
+def test_bf16_fused_front_matches_layer_launches(case):
+    """round 4: a forward without the tap runs conv(3->16)+pool and conv(16->32)+pool of the bf16 nets in ONE launch
+    (csrc/frontb.hip); the tap forward runs them as two.  Same operands, same rounding points, only the order of the fp32
+    accumulation differs: conv2's pooled map differs in 0.005-0.007 % of its values (one bf16 ulp; rel. L2 2-4e-5, measured), and the
+    few flipped ulps reach the prediction maps as 1.4e-3 .. 2.1e-3 rel. L2 (measured; the bf16 path's distance to the fp32
+    reference is 3e-3 .. 7e-3): bounds 1e-3 / 5e-3."""
+    fnet, layers, anchors, x = _load_net(case, len(case[5]))
+    B = x.shape[0]
+    fused = fnet.forward(x)
+    nt = fnet.num_tensors
+    npred = 2 if case[1] == "tiny_yolo_v3" else 1
+    t1_f = fnet.get_tensor(1, B).astype(np.float64)
+    pred_f = [fnet.get_tensor(nt - npred + k, B).astype(np.float64) for k in range(npred)]
+    tap = fnet.forward(x, tap=True)
+    t1_t = fnet.get_tensor(1, B).astype(np.float64)
+    pred_t = [fnet.get_tensor(nt - npred + k, B).astype(np.float64) for k in range(npred)]
+    rel1 = np.sqrt(((t1_f - t1_t) ** 2).sum() / (t1_t ** 2).sum())
+    differing = float((t1_f != t1_t).mean())
+    print("conv2 map: rel. L2 %.2e, %.3f %% of the values differ; pred rel. L2 %s" % (
+        rel1, 100 * differing, ["%.2e" % np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()) for a, b in zip(pred_f, pred_t)]))
+    assert rel1 <= 1e-3 and differing <= 0.05
+    assert np.abs(t1_f - t1_t).max() <= 2 ** -6 * max(1.0, np.abs(t1_t).max())
+    for a, b in zip(pred_f, pred_t):
+        assert np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()) <= 5e-3
+    for bi in range(B):
+        fr, fg = dets_close(tap[bi], fused[bi], 0.9, 0.02)
+        assert fr >= 0.9 and fg >= 0.9
+    fnet.close()

@@ -300,7 +300,9 @@ def test_config3_full_batch_slim_fp32(r2):
     fr, fg = dets_close(ref, dets[0], 0.8, 0.05)
     print("config 3, image 0: pred rel. L2 %.4f; %.3f of the reference's and %.3f of the engine's detections matched "
           "(same class, IoU >= 0.8, |score err| <= 0.05); %d vs %d detections" % (rel, fr, fg, len(ref[1]), len(dets[0][1])))
-    assert fr >= 0.8 and fg >= 0.8
+    # measured on the MI355X (round 4, printed above with -s): rel. L2 0.0068, 0.840 / 0.841 matched, 2333 vs 2329 detections;
+    # the assertions sit a few points under the measurement
+    assert fr >= 0.82 and fg >= 0.82 and abs(len(ref[1]) - len(dets[0][1])) <= 0.02 * len(ref[1])
     net.close()
 
 

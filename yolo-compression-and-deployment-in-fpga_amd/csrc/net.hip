@@ -576,18 +576,19 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
         if (!rc) rc = nmalloc(h, (void **)&L.bias_dev, sizeof(float) * L.cout_pad, true);
         if (!rc) rc = nmalloc(h, (void **)&L.bias_w_dev, sizeof(long long) * L.cout_pad, true);
     }
-    if (!rc && !h->bf && A.nops >= 2) {
+    if (!rc && A.nops >= 2) {
         const OpDef &o0 = A.ops[0], &o1 = A.ops[1];
         bool fg = o0.type == OP_CONV1 && o0.cout == 16 && o0.pool == 1 && o1.type == OP_CONV && o1.in == o0.out && o1.cin == 16 &&
                   o1.cout == 32 && o1.ksize == 3 && o1.pool == 1 && !o1.stride2 && !o1.res1 && o1.choff == 0 &&
-                  h->T[o1.out].pb == 32 && h->T[o1.out].halo == 1 && !h->T[o1.out].pred && cfg->height % 4 == 0 && cfg->width % 4 == 0;
+                  h->T[o1.out].pb == (size_t)(32 * h->es) && h->T[o1.out].halo == 1 && !h->T[o1.out].pred && cfg->height % 4 == 0 &&
+                  cfg->width % 4 == 0;
         for (int i = 2; fg && i < A.nops; ++i)                     // nobody else reads conv1's map
             if (A.ops[i].in == o0.out || A.ops[i].res1 - 1 == o0.out) fg = false;
         if (fg) {
             h->front_graph = true;
-            rc = nmalloc(h, (void **)&h->wf_dev, 16384, true);
-            if (!rc) rc = nmalloc(h, (void **)&h->fb1_dev, sizeof(int) * 16, true);
-            if (!rc) rc = nmalloc(h, (void **)&h->fb2_dev, sizeof(int) * 32, true);
+            rc = nmalloc(h, (void **)&h->wf_dev, h->bf ? 32768 : 16384, true);      // y355_pack_frontb / y355_pack_front
+            if (!rc && !h->bf) rc = nmalloc(h, (void **)&h->fb1_dev, sizeof(int) * 16, true);
+            if (!rc && !h->bf) rc = nmalloc(h, (void **)&h->fb2_dev, sizeof(int) * 32, true);
         }
     }
     const size_t cap = Y355_NMS_CAP;
@@ -691,6 +692,12 @@ extern "C" int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, con
             y355_convg_pack(kr, w, nullptr, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, pr.data());
             HIPCHK(hipMemcpy(L.wr_dev, pr.data(), pr.size(), hipMemcpyHostToDevice));
         }
+    }
+    if (h->front_graph && (L.op == 0 || L.op == 1)) {         // the same weights as the bf16 front end's fragments (frontb.hip)
+        std::vector<char> wf(32768);
+        y355_pack_frontb(L.op == 0 ? w : nullptr, L.op == 1 ? w : nullptr, wf.data());
+        if (L.op == 0) HIPCHK(hipMemcpy(h->wf_dev, wf.data(), 8192, hipMemcpyHostToDevice));
+        else HIPCHK(hipMemcpy(h->wf_dev + 8192, wf.data() + 8192, 32768 - 8192, hipMemcpyHostToDevice));
     }
     std::vector<float> bias(L.cout_pad, 0.f);
     if (b) memcpy(bias.data(), b, sizeof(float) * cout);
@@ -1174,13 +1181,32 @@ extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int 
         HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * (nops + 1), h->stream));
     }
     // tap forwards (parity tests read every tensor) run the first two layers one by one: the fused launch does not write conv1's map
-    const bool fuse_front = !h->bf && h->front_graph && h->front_ok && !(flags & Y355_F_TAP);
+    const bool fuse_front = h->front_graph && (h->bf || h->front_ok) && !(flags & Y355_F_TAP);
     for (int i = 0; i < nops; ++i) {
         if (prof) HIPCHK(hipEventRecord(h->ev[i], h->stream));
         if (fuse_front && i < 2) {
             if (i == 0) {
                 if (!h->L[h->arch->ops[0].layer].loaded || !h->L[h->arch->ops[1].layer].loaded)
                     return y355_fail(Y355_ENOTREADY, "layer weights not loaded");
+                if (h->bf) {
+                    const OpDef &o0 = h->arch->ops[0], &o1 = h->arch->ops[1];
+                    FrontBParams fb{};
+                    fb.x = x_dev;
+                    fb.out = h->T[o1.out].dev;
+                    fb.out_pb = (int)h->T[o1.out].pb;
+                    fb.wf = (const char *)h->wf_dev;
+                    fb.bias1 = h->L[o0.layer].bias_dev;
+                    fb.bias2 = h->L[o1.layer].bias_dev;
+                    fb.B = batch;
+                    fb.H = h->cfg.height;
+                    fb.W = h->cfg.width;
+                    y355_frontb_tiles(fb.H, fb.W, &fb.tiles_x, &fb.tiles_y);
+                    fb.slope1 = act_slope(o0.act);
+                    fb.slope2 = act_slope(o1.act);
+                    y355_launch_frontb(fb, h->stream);
+                    HIPCHK(hipGetLastError());
+                    continue;
+                }
                 FrontParams fp{};
                 fp.x = x_dev;
                 fp.out = (int8_t *)h->T[h->arch->ops[1].out].dev;

@@ -142,6 +142,21 @@ struct FrontParams {
     unsigned long long *stamps;   // diagnostic builds only (-DFRONT_DIAG=1)
     void *ev_start, *ev_stop;     // host side only: see ConvParams
 };
+// fused front end of the bf16 nets (frontb.hip): fp32 NCHW -> conv(3 -> 16) + pool -> conv(16 -> 32) + pool -> bf16 NHWC
+struct FrontBParams {
+    const float *x;       // fp32 NCHW [B][3][H][W]
+    char *out;            // conv2's pooled output: bf16 NHWC with halo [B][H/4+2][W/4+2][out_pb bytes], channels 0..31
+    int out_pb;           // bytes per output pixel (64)
+    const char *wf;       // 32 KiB of weight fragments (y355_pack_frontb)
+    const float *bias1;   // [16]
+    const float *bias2;   // [32]
+    int B, H, W;
+    int tiles_x, tiles_y;
+    float slope1, slope2; // LeakyReLU slopes of the two layers
+};
+void y355_frontb_tiles(int H, int W, int *tx, int *ty);
+void y355_pack_frontb(const float *w1 /*[16][3][3][3] or null*/, const float *w2 /*[32][16][3][3] or null*/, char *dst /*32768*/);
+void y355_launch_frontb(const FrontBParams &p, hipStream_t s);
 void y355_front_tiles(int H, int W, int *tx, int *ty);
 void y355_pack_front(const int8_t *q_w1, const int8_t *q_w2, int8_t *dst /*16384; a null tensor leaves its part zero*/);
 bool y355_front_eligible(const Requant &rq1, const Requant &rq2);

@@ -190,7 +190,7 @@ class Net:
         from .prep import RangeTracker
         xd = self._dev_input(x)
         B = xd.shape[0]
-        self.forward_device(xd)
+        self.forward_device(xd, _ffi.F_TAP)      # tap forward: every tensor is written (the fused front end skips conv1's map)
         sa_in = RangeTracker().update(float(xd.abs().max().item()), True)
         sa = []
         for t in range(self.num_tensors):
