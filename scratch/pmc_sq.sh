@@ -3,8 +3,8 @@
 # usage: pmc_sq.sh <tag> [kernel-name substring filter]
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=${1:-sq}; filt=${2:-}
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-sparse --streams 1 $BENCH_ARGS > gpurun_out/pmc_$tag.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/pmc2_$tag -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-sparse --streams 1 $BENCH_ARGS > gpurun_out/pmc2_$tag.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-sparse --no-other-configs --streams 1 $BENCH_ARGS > gpurun_out/pmc_$tag.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/pmc2_$tag -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-sparse --no-other-configs --streams 1 $BENCH_ARGS > gpurun_out/pmc2_$tag.log 2>&1
 python3 - "$tag" "$filt" <<'PY'
 import csv,glob,collections,sys
 tag,filt=sys.argv[1],sys.argv[2]

@@ -2,7 +2,7 @@
 # GPU box: HBM traffic per launch (separate FETCH_SIZE / WRITE_SIZE passes, kernel-trace only) -> gpurun_out/pmc_traffic.json
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmct_$c -- python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-sparse --streams 1 > gpurun_out/pmct_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmct_$c -- python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-sparse --no-other-configs --streams 1 > gpurun_out/pmct_$c.log 2>&1
   cp gpurun_out/pmct_$c/*/*_counter_collection.csv gpurun_out/pmc_${c}_counter_collection.csv
 done
 python3 - <<'PY'
