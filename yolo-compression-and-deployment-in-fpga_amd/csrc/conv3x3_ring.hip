@@ -601,6 +601,10 @@ struct RSet {
     using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
     using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
     using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
+    // pred in the throughput mode (several handles share the GPU: p.grid_limit > 0): 13 x 26 tiles = 128 work items at B = 64, same
+    // weight packing.  A launch then holds 128 CUs for ~15 us instead of 256 for ~12 (the launch is mostly start-up and drain,
+    // profiles/r03_notes.md): three handles 278.3 k -> 280.9 k img/s over nine interleaved runs (whole maps, 64 items: no better)
+    using PRED_W = ConvInstR<256, 64, 13, 26, false, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
     static int prepare() {
         int e = C3_2::prepare();
         if (!e) e = C4_1::prepare();
@@ -608,6 +612,7 @@ struct RSet {
         if (!e) e = C5::prepare();
         if (!e) e = C67::prepare();
         if (!e) e = PRED::prepare();
+        if (!e) e = PRED_W::prepare();
         return e;
     }
     static bool launch(int kid, const ConvParams &p, hipStream_t s) {
@@ -617,7 +622,7 @@ struct RSet {
         case Y355_K_CONV4_2: return C4_2::launch(p, s);
         case Y355_K_CONV5: return C5::launch(p, s);
         case Y355_K_CONV67: return C67::launch(p, s);
-        case Y355_K_PRED: return PRED::launch(p, s);
+        case Y355_K_PRED: return p.grid_limit > 0 ? PRED_W::launch(p, s) : PRED::launch(p, s);
         default: return false;
         }
     }
