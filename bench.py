@@ -923,8 +923,9 @@ def main():
                                "ms_per_step": round(float(np.median(tu)) / args.steps * 1e3, 4), "repeats": len(tu),
                                "front_end_launch_ms": round(float(np.median(ku)), 4),
                                "front_end_launch_ms_f32": round(float(kernel_ms[0]), 4),
-                               "note": "uint8 HWC BGR frames (33 MB per batch instead of 133 MB of fp32 planes); the front end is not "
-                                       "bound by its input bytes (profiles/r04_notes.md), so the two routes run at the same rate"}
+                               "note": "uint8 HWC BGR frames (33 MB per batch instead of 133 MB of fp32 planes), BaseTransform fused into the "
+                                       "first layer; same detections (tests/test_gpu_parity.py).  front_end_launch_ms: the fused front end's own "
+                                       "duration on this route and on the fp32 route (one handle alone)"}
         if world == 1 and not args.no_other_configs:
             # BASELINE.json configs[2] / configs[3], a few steps each: a driver-visible number for them
             import copy

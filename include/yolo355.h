@@ -80,7 +80,10 @@ int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
 /* Y355_OPT_RING_WORKGROUPS (default 0 = one per CU): persistent workgroups per launch of the deep convolutions.  A handle that
  * has the GPU to itself wants them all; when several handles share it (bench.py: three), fewer workgroups that each walk more
  * tiles let launches of different handles run side by side and pay a workgroup's start-up once per several tiles
- * (192 of 256: +2.6 % images/s with three handles, -25 % for a handle running alone) */
+ * (192 of 256: +2.6 % images/s with three handles, -25 % for a handle running alone).  A non-zero value is the handle's
+ * "throughput mode": the prediction layer then also runs on 13 x 26 tiles (128 work items per 64 images instead of 256: +0.9 %)
+ * and the NMS pair walk on one workgroup per image instead of two (+1.3 %; a handle alone loses 3 % with it).  Results are
+ * identical bit for bit in either mode. */
 #define Y355_OPT_RING_WORKGROUPS 2
 int y355_set_option(y355_engine *h, int option, int value);
 

@@ -627,6 +627,7 @@ static HeadParams head_params(y355_engine *h, int sa_pred, float *ob, float *os,
     // int8 logits keep exp(tw) in a narrow range: the anchor is a good size class (measured: pairs 52 us
     // vs 80 us with area octaves on the benchmark batch)
     p.group_by_area = 0;
+    p.pairs_wgs = h->ring_wgs > 0 ? 1 : 0;    // throughput mode (Y355_OPT_RING_WORKGROUPS set): the pair walk holds one CU per image
     p.Hb = h->Hs;
     p.Wb = h->Ws;
     p.in_w = (float)h->cfg.width;

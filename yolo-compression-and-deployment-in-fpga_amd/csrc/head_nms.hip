@@ -475,7 +475,9 @@ __device__ __forceinline__ float raw_min(float a, float b) {
 }
 #ifndef Y355_PAIRS_G
 #define Y355_PAIRS_G 2             // workgroups per image: 4 finish a batch no sooner (the heavy waves set the time) but hold twice the CUs,
-                                   // which the convolutions of the other streams cannot use meanwhile (3-stream: 227 k -> 239 k img/s)
+                                   // which the convolutions of the other streams cannot use meanwhile (3-stream: 227 k -> 239 k img/s);
+                                   // round 4: ONE while several handles share the GPU (HeadParams::pairs_wgs, set by the engine in its
+                                   // throughput mode: 283.1 k -> 286.9 k img/s; a handle alone keeps two: 195 k vs 189 k one stream)
 #endif
 template <bool FAST>
 __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const HeadWork wk, float thr) {
@@ -1001,8 +1003,8 @@ void y355_launch_head_nms(const HeadParams &p_in, int batch, const y355_head_ws 
     Y355_LAUNCH(head_kernel, dim3(batch), dim3(1024), 0, s, k1[0], k1[1], p, wk);
     if (mid) (void)hipEventRecord(mid, s);
     if (p.nms_thresh >= 1e-4f && p.nms_thresh < 1e4f)
-        Y355_LAUNCH(pairs_kernel<true>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, k2[0], k2[1], p, wk, p.nms_thresh);
+        Y355_LAUNCH(pairs_kernel<true>, dim3(p.pairs_wgs > 0 ? p.pairs_wgs : Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, k2[0], k2[1], p, wk, p.nms_thresh);
     else
-        Y355_LAUNCH(pairs_kernel<false>, dim3(Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, k2[0], k2[1], p, wk, p.nms_thresh);
+        Y355_LAUNCH(pairs_kernel<false>, dim3(p.pairs_wgs > 0 ? p.pairs_wgs : Y355_PAIRS_G, batch), dim3(1024), PAIRS_LDS, s, k2[0], k2[1], p, wk, p.nms_thresh);
     Y355_LAUNCH(resolve_emit_kernel, dim3(batch), dim3(1024), 0, s, k3[0], k3[1], p, wk, p.nms_thresh);
 }

@@ -277,6 +277,7 @@ struct HeadParams {
     float wh_mul;         // w = exp(tw) * aw * wh_mul   (16: anchors in grid units; 1: pixels)
     int Hb, Wb;           // bin grid of the candidate sort
     int group_by_area;    // 0: candidates grouped by anchor type (bins = level 0's grid); 1: by area octave (<= 16 x 16 bins)
+    int pairs_wgs;        // workgroups per image of the NMS pair walk: 0 = default (2); 1 while several handles share the GPU
     int cls_groups;       // set by y355_launch_head_nms: 1 = the groups are the CLASSES (per-class NMS never pairs two classes), else 0
     float in_w, in_h;     // network input size in pixels
     float conf_thresh, nms_thresh;
