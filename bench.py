@@ -494,7 +494,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="self-test: run the multi-GPU code path (process group, exponent broadcast, packed all-gather per step, "
                          "barriers, max over ranks) with a world of ONE rank -- the build boxes have one GPU each")
-    ap.add_argument("--ring-workgroups", type=int, default=192,
+    ap.add_argument("--ring-workgroups", type=int, default=128,
                     help="persistent workgroups per launch of the deep convolutions while several handles share the GPU "
                          "(Y355_OPT_RING_WORKGROUPS; 0 = one per CU; a handle running alone always gets one per CU)")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
