@@ -257,6 +257,8 @@ def measure_net(args):
             ts.append(time.perf_counter() - t0)
         return ts, out
     reps = getattr(args, "net_regions", 15)
+    # (Y355_NET_OPT_WORKGROUPS, the nets' throughput mode, is left off: measured slower on both graphs -- SlimYOLOv2 fp32 148.3 k
+    # against 137.0 k / 138.0 k img/s at 128 / 192 workgroups, YOLOv3tiny int8 195.6 k against 192.0 k / 194.6 k: profiles/r04_notes.md)
     ts, out = regions(ns, reps, 1.0 if reps >= 15 else 0.0)
     dt = float(np.median(ts))
     ts1, _ = regions(1, min(reps, 5), 0.0)

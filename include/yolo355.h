@@ -315,6 +315,11 @@ typedef struct y355_net_config {
 int y355_net_create(const y355_net_config *cfg, y355_net **out);
 void y355_net_destroy(y355_net *h);
 int y355_net_set_thresholds(y355_net *h, float conf_thresh, float nms_thresh);
+/* Y355_NET_OPT_WORKGROUPS (default 0 = one per CU): the net's "throughput mode", as Y355_OPT_RING_WORKGROUPS of the q_bf engine:
+ * persistent workgroups per launch of the 3x3 ring kernels (convr.hip) while several handles share the GPU, and the NMS pair walk on
+ * one workgroup per image.  Results are identical bit for bit. */
+#define Y355_NET_OPT_WORKGROUPS 1
+int y355_net_set_option(y355_net *h, int option, int value);
 int y355_net_num_layers(y355_net *h);
 int y355_net_num_tensors(y355_net *h);
 int y355_net_layer_shape(y355_net *h, int idx, int32_t *shape /*[4] cout,cin,kh,kw*/);

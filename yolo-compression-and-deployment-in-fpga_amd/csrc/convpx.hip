@@ -437,6 +437,10 @@ struct PxInst {
         ConvParams p = p_in;
         p.ev_start = p.ev_stop = nullptr;
         int grid = 256;                                            // one NW-wave workgroup per CU
+        // throughput mode (Y355_OPT_RING_WORKGROUPS: several handles share the GPU): fewer workgroups, each walking a longer share of
+        // the groups -- the weights-into-registers prologue (up to 288 KB per workgroup) is paid half as often and the launch leaves
+        // CUs to the other handles' kernels: 64 / 96 / 128 / 160 / 256 workgroups -> 272.7 / 286.2 / 293.5 / 289.2 / 285.8 k img/s
+        if (p_in.grid_limit > 0 && p_in.grid_limit < grid) grid = p_in.grid_limit;
         if (grid > a.total_groups) grid = a.total_groups;
         Y355_LAUNCH((convpx_kernel<CIN, NTN, NCB, POOL, NW, FOLD>), dim3(grid), dim3(NW * 64), lds_bytes(a), s, p_in.ev_start, p_in.ev_stop, p, a);
     }

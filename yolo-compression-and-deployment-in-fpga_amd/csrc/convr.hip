@@ -470,7 +470,8 @@ struct ConvRInst {
         p.tiles_x = (p.W + TW - 1) / TW;
         p.tiles_y = (p.H + TH - 1) / TH;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
-        const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
+        int grid = total < 256 ? total : 256;                  // one persistent workgroup per CU
+        if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;     // fewer, each walking more tiles (throughput mode)
         // int8: only the 32-bit epilogue is built here; a layer that needs the 64-bit one (rq.narrow == 0: 96 accumulators plus
         // 64-bit temporaries spill 1.2 KB per lane and the launch is 2.4x slower than convg8's, profiles/r03_notes.md) stays on convg.hip
         if (!BF && !p.rq.narrow) return false;

@@ -444,6 +444,7 @@ struct y355_net {
     int8_t *wf_dev = nullptr;         // 16 KiB of front-end weight fragments (y355_pack_front)
     int *fb1_dev = nullptr, *fb2_dev = nullptr;   // pre-shifted int32 biases of the two layers
     Requant frq1{}, frq2{};
+    int tput_wgs = 0;                 // Y355_NET_OPT_WORKGROUPS: persistent workgroups per convr launch while several handles share the GPU (0 = one per CU)
     int profile = 0;
     std::vector<hipEvent_t> ev;
     std::vector<void *> allocs;
@@ -633,6 +634,16 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     }
     *out = h;
     return 0;
+}
+
+extern "C" int y355_net_set_option(y355_net *h, int option, int value) {
+    if (!h) return y355_fail(Y355_EINVAL, "null net");
+    if (option == Y355_NET_OPT_WORKGROUPS) {
+        if (value < 0 || value > 256) return y355_fail(Y355_EINVAL, "workgroups per launch: 0 .. 256");
+        h->tput_wgs = value;
+        return 0;
+    }
+    return y355_fail(Y355_EINVAL, "unknown option");
 }
 
 extern "C" int y355_net_set_thresholds(y355_net *h, float conf, float nms) {
@@ -1063,6 +1074,7 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
         p.taps = o.ksize * o.ksize;
         p.slope = act_slope(o.act);
         p.out_f32 = to.pred && h->bf;
+        p.grid_limit = h->tput_wgs;
         if (L.rid == -2) {                                     // int8 1x1: pointwise kernel (convr.hip)
             ConvGParams q = p;
             q.w = L.wr_dev;
@@ -1152,6 +1164,7 @@ static HeadParams net_head_params(y355_net *h, float *ob, float *os, int *oc, in
     // fp32 / multi-level heads: box sizes spread over many octaves per anchor -> group by area
     // (YOLOv3tiny int8, B = 128: NMS 1.08 -> 0.50 ms; SlimYOLOv2 bf16: 0.45 -> 0.32 ms)
     p.group_by_area = 1;
+    p.pairs_wgs = h->tput_wgs > 0 ? 1 : 0;        // throughput mode: the pair walk holds one CU per image
     p.Hb = std::min(16, h->T[A.pred_t[0]].H);
     p.Wb = std::min(16, h->T[A.pred_t[0]].W);
     p.in_w = (float)h->cfg.width;

@@ -342,6 +342,7 @@ struct ConvGParams {
     // `out` (halo, pixel pitch res_pb, byte offset res_off of channel 0); null = none
     const char *res;
     int res_pb, res_off;
+    int grid_limit;           // host side only: persistent workgroups of a convr.hip launch (0 = one per CU), Y355_NET_OPT_WORKGROUPS
 };
 
 struct Conv1FParams {

@@ -122,6 +122,7 @@ _SIGS = {
     "y355_net_create": (C.c_int, [P(NetConfig), P(C.c_void_p)]),
     "y355_net_destroy": (None, [C.c_void_p]),
     "y355_net_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "y355_net_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y355_net_num_layers": (C.c_int, [C.c_void_p]),
     "y355_net_num_tensors": (C.c_int, [C.c_void_p]),
     "y355_net_layer_shape": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32)]),

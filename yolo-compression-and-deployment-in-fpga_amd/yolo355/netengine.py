@@ -109,6 +109,10 @@ class Net:
         _ffi.check(self._lib.y355_net_counters(self._h, C.byref(s)))
         return s.value
 
+    def set_option(self, option, value):
+        """1 = Y355_NET_OPT_WORKGROUPS (throughput mode: persistent workgroups per ring launch, 0 = one per CU)"""
+        _ffi.check(self._lib.y355_net_set_option(self._h, int(option), int(value)))
+
     def set_thresholds(self, conf_thresh, nms_thresh):
         _ffi.check(self._lib.y355_net_set_thresholds(self._h, float(conf_thresh), float(nms_thresh)))
 
