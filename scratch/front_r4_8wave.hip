@@ -1,0 +1,987 @@
+// yolo355 -- fused front end of the q_bf path: input quantise -> conv1(3->16) -> bias -> LeakyReLU(0.125) ->
+// requantise -> 2x2 max-pool -> conv2(16->32) -> bias -> LeakyReLU -> requantise -> 2x2 max-pool, ONE kernel.
+//
+// Replaces models/slim_yolo_v2.py:218-244 (a_tracker_in, conv1, a_tracker1, pool1, conv2, a_tracker2, pool2)
+// and the FPGA driver's first_conv + second_conv (c_embedding/yolo_forward.c:269-572: the same fusion
+// boundary -- the camera frame goes in, the 32-channel quarter-resolution map comes out).
+//
+// Round 3 rewrite.  The round-2 kernel was instruction-issue-bound (profiles/r02_notes.md: 1 940 instructions per
+// wave and tile, 17 VALU per conv1 MFMA); this one spends about 0.6 of that:
+//   * the 2x2 pooling window is the unit of work.  A window of a 3x3 / pad-1 convolution followed by a 2x2 pool reads
+//     a 4x4 input neighbourhood; the FOUR conv outputs of the window are four MFMAs over the SAME neighbourhood
+//     operand with four weight fragments (the 3x3 filter placed at the four offsets inside the 4x4 neighbourhood,
+//     zeros elsewhere).  conv1: 4x4 px x 4 B = exactly one 64-deep k-step; conv2: four k-steps (neighbourhood rows)
+//     of 4 px x 16 ch.  One set of LDS reads feeds all four pool partners;
+//   * weights are the MFMA's A operand (rows = output channels), pixels the B operand (columns = 16 windows): a lane
+//     then holds FOUR CHANNELS of ONE window in an accumulator, the pool is an element-wise max over the four MFMA
+//     results (no cross-lane step), and the int8 results leave as one packed ds_write_b32 / b64 per lane;
+//   * the biases ride in as the MFMAs' C operand (when the layer's accumulator shift is zero: template FOLD);
+//   * the requantisation runs in fp32 on exact integers: t < 2^24 (host-checked, Requant::tmax_log2), so
+//         q = low byte of med3(max(fma(t, 2^(lk-sh), M), fma(t, 2^-sh, M)), M - 127, M + 127),   M = 1.5 * 2^23
+//     is RNE(t' * 2^-sh) clamped, bit for bit the integer pipeline of DESIGN.md section 2: the fma rounds the exact
+//     product once, to the integer grid of [2^23, 2^24), ties to even; five VALU operations instead of eight;
+//   * the input quantisation uses the same fma: q = low byte of fma(x, 2^sa0, M); three values are packed with two
+//     v_perm_b32; clamped inputs are detected from max |x| and handled (and counted exactly) in a cold pass.
+// Integer semantics are those of conv1.hip / conv3x3_v2.hip, bit for bit; saturation is detected with one op per output
+// and counted exactly (own pixels only) in a cold second pass.
+#include "y355_common.h"
+#include <type_traits>
+#include <cstring>
+#ifndef FRONT_OCC
+#define FRONT_OCC 4
+#endif
+#ifndef FRONT_P0
+#define FRONT_P0 64              // patch pitch in pixels (dwords): 32 mod 64 keeps the two filter rows of a half-wave's
+#endif                           // ds_read_b64 on disjoint banks
+#ifndef FRONT_HOTCOLD
+#define FRONT_HOTCOLD 1          // 1: the hot pass does not clamp (running max / min of the rounded values detect a clamp; a cold pass
+#endif                           //    then rewrites the wave's outputs clamped and counts); 0: clamp + detect per output in the hot pass
+#ifndef FRONT8
+#define FRONT8 0                  // 1: the 512-thread form of the kernel for the fp32-input, folded-epilogue case (round-4 experiment)
+#endif
+#ifndef FRONT_DIAG
+#define FRONT_DIAG 0             // 1: s_memtime stamps at the phase boundaries of each workgroup's first tiles (y355_debug_stamps)
+#endif
+
+namespace {
+constexpr int TOY = 13, TOX = 13;                    // pooled conv2 outputs per tile
+constexpr int P1H = 2 * TOY + 2, P1W = 2 * TOX + 2;  // pooled conv1 tile with its halo (windows of conv1)
+constexpr int PH0 = 2 * P1H + 2;                     // input patch rows (= columns used)
+constexpr int P0 = FRONT_P0;
+constexpr int P1P = P1W;                             // p1 pitch in 16-byte pixels (28: rows two apart differ by 8 mod 16 slots)
+constexpr int P1ROWS = P1H + 2;                      // slack rows: the clamped padding windows of C2 stay inside
+constexpr int NW1 = P1H * P1W;                       // 784 conv1 windows = 49 groups of 16
+constexpr int NG1 = NW1 / 16;
+constexpr int NW2 = TOY * TOX;                       // 169 conv2 windows = 11 groups of 16 (7 padding slots)
+constexpr int NG2 = (NW2 + 15) / 16;
+constexpr int QITEMS = 4;                            // input items (row, 4-pixel group) per thread: 16 wave-items of 4 rows
+constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23
+constexpr float QLO = 12582785.0f, QHI = 12583039.0f;   // MAGIC -+ 127
+static_assert(NW1 % 16 == 0 && PH0 <= 4 * 4 * QITEMS && P0 % 4 == 0 && P0 >= PH0 + 2, "front geometry");
+
+__device__ __forceinline__ void front_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// bare instructions: hipcc canonicalises (quiets) both operands of fmaxf / fabsf chains
+__device__ __forceinline__ float vmax(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float vmax3abs(float a, float b, float c) {      // max(a, |b|, |c|)
+    float d;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmaxabs(float a, float b) {               // max(a, |b|)
+    float d;
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// lane i of each row of 16 lanes receives lane i + 1's value (lane 15: zero)
+__device__ __forceinline__ unsigned int row_next(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+}
+// bytes 0 of four registers -> one dword
+__device__ __forceinline__ unsigned int pack4(float a, float b, float c, float d) {
+    const unsigned int ab = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x0c0c0400u);
+    const unsigned int cd = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x04000c0cu);
+    return ab | cd;
+}
+// (r, g, b) bytes 0 -> pixel word (r, g, b, 0)
+__device__ __forceinline__ unsigned int pack3(float r, float g, float b) {
+    const unsigned int rg = __builtin_amdgcn_perm(__float_as_uint(g), __float_as_uint(r), 0x0c0c0400u);
+    return __builtin_amdgcn_perm(__float_as_uint(b), rg, 0x0c040100u);
+}
+
+// fp32 form of the epilogue of one layer (see the header): q = low byte of yc
+// FOLD (accumulator shift 0, |t| < 2^22, |sh| small: y355_launch_front): the MFMAs' C operand is bias + 0x4B400000, so the
+// int32 accumulator IS the bit pattern of the float M + t (no v_cvt), and M + t * s = fma(M + t, s, M * (1 - s)) exactly
+// (M * (1 - s) is representable for 2^-22 <= s <= 2^8).
+struct RqF {
+    float s_pos, s_neg;      // 2^(lk - sh), neg_mul * 2^-sh
+    float c_pos, c_neg;      // FOLD: M * (1 - s); else M
+    float scl;               // !FOLD: 2^shl
+};
+template <bool FOLD>
+__device__ __forceinline__ RqF make_rqf(const Requant &rq) {
+    RqF r;
+    // wave-uniform: the two scales live in SGPRs (one constant-bus operand per fma), the addends in VGPRs
+    r.s_pos = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, rq.lk - rq.sh))));
+    r.s_neg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)rq.neg_mul * ldexpf(1.0f, -rq.sh))));
+    r.c_pos = FOLD ? MAGIC - MAGIC * r.s_pos : MAGIC;
+    r.c_neg = FOLD ? MAGIC - MAGIC * r.s_neg : MAGIC;
+    r.scl = ldexpf(1.0f, rq.shl);
+    return r;
+}
+// pooled accumulator -> M + rne(t' * 2^-sh), unclamped
+template <bool FOLD>
+__device__ __forceinline__ float rq_round(int m, float biasf, const RqF &r) {
+    const float tf = FOLD ? __int_as_float(m) : fmaf((float)m, r.scl, biasf);   // (float)m exact: |t| < 2^24
+    return vmax(fmaf(tf, r.s_pos, r.c_pos), fmaf(tf, r.s_neg, r.c_neg));         // RNE is monotone: round(max) = max(round)
+}
+}  // namespace
+
+template <bool U8, bool FOLD>
+__global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams p, const int total_tiles) {
+    // separate LDS objects: the compiler then knows that the writes of one phase do not alias the reads of the same phase
+    __shared__ __attribute__((aligned(16))) unsigned int patch[PH0 * P0];
+    __shared__ __attribute__((aligned(16))) char p1[P1ROWS * P1P * 16];
+    __shared__ __attribute__((aligned(16))) char stg[NG2 * 16 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned int lut[U8 ? 3 * 256 : 4];
+    __shared__ __attribute__((aligned(16))) char wl[U8 ? 16 : 4096 + 64];       // fp32 input: conv1's fragments and biases
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int H = p.H, W = p.W;
+    const int Hp = H >> 1, Wp = W >> 1, Ho = H >> 2, Wo = W >> 2;
+    const size_t plane = (size_t)H * W;
+    const float sc = p.in_scale;
+    const float in_thr = 127.5f / sc;                  // |x| >= thr  <=>  rne(|x| * 2^sa0) > 127 (sc is a power of two)
+
+    // ---- nothing but a few constants stays in registers across phases: the weight fragments and biases (16 KiB + 192 B,
+    // L2-resident) are re-read per tile just ahead of the phase that uses them (128 registers per lane at four workgroups per CU)
+    const Requant rq1 = p.rq1, rq2 = p.rq2;
+    const RqF f1 = make_rqf<FOLD>(rq1), f2 = make_rqf<FOLD>(rq2);
+    if constexpr (U8) {
+        // normalise + quantise is a function of the byte: per channel a 256-entry table built with the reference's
+        // fp32 operations in the reference's order ((u/255 - mean)/std, data/__init__.py:43-45; round(x * 2^sa),
+        // slim_yolo_v2.py:35); entry = the int8 value already in the pixel word's byte c, bit 24 = "was clamped"
+        // (byte 3 of a pixel multiplies zero weights)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = (float)tid;
+            t /= 255.0f;
+            t -= p.nmean[c];
+            t /= p.nstd[c];
+            const float r = rintf(t * sc);
+            const float rc = fminf(fmaxf(r, -127.f), 127.f);
+            lut[c * 256 + tid] = (((unsigned int)(int)rc & 0xffu) << (8 * c)) | (rc != r ? (1u << 24) : 0u);
+        }
+    }
+
+    // ---- tile-independent per-thread geometry
+    // Q: wave-item q = wave + 4 k covers patch rows 4 q .. 4 q + 3; lane = 16 * (row in the item) + 4-pixel group j
+    // (j = 15 is an idle slot: 15 groups = 60 pixels per row are loaded)
+    int qr0 = 4 * wave + g;                            // row of item k: qr0 + 16 k
+    const int qj = li;
+    const int G_ = gridDim.x;
+    int tile = y355_xcd_remap(blockIdx.x, G_);
+    if (tile >= total_tiles) return;
+    int nstamp = 0;
+    auto stamp = [&]() {
+#if FRONT_DIAG
+        if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
+#endif
+    };
+    (void)nstamp;
+    if constexpr (!U8) {
+        *(v4i *)(wl + tid * 16) = *(const v4i *)(p.wf + tid * 16);
+        if (tid < 4) *(v4i *)(wl + 4096 + 16 * tid) = *(const v4i *)(p.bias1 + 4 * tid);
+    }
+    front_lds_barrier();                                // the table / the fragments are complete
+    unsigned int nsat_in = 0, nsat1 = 0, nsat2 = 0;
+
+    // ---- a tile's input patch: QITEMS x (3 x float4 | 12 bytes) per thread, all in flight together.  (Issuing the next
+    // tile's under C2 of the current one was measured slower in every form -- all of it, half of it, three or four
+    // workgroups per CU: profiles/r03_notes.md; the other workgroups of the CU cover the wait.)
+    float4 vf[U8 ? 1 : QITEMS][3];
+    uint3 vu[U8 ? QITEMS : 1];
+    auto load_input = [&](int t) {
+        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+#pragma unroll
+        for (int k = 0; k < QITEMS; ++k) {
+            const int r = qr0 + 16 * k;
+            const int gy = min(max(y0p + r, 0), H - 1);       // rows / groups past the patch or the image re-read valid data
+            const int gx = min(max(x0p + 4 * qj, 0), W - 4);
+            const size_t o = (size_t)gy * W + gx;
+            if constexpr (U8) {
+                vu[k] = *(const uint3 *)(p.x_u8 + ((size_t)b * plane + o) * 3);
+            } else {
+                const float *xb = p.x + (size_t)b * 3 * plane + o;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vf[k][c] = *(const float4 *)(xb + c * plane);
+            }
+        }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using KN = std::integral_constant<int, QITEMS>;
+
+    for (;; tile += G_) {
+        // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
+        // out of the tile loop as a loop invariant and held in registers
+        int li_ = li, g_ = g, lane_ = lane, tid_ = tid;
+        asm volatile("" : "+v"(qr0), "+v"(li_), "+v"(g_), "+v"(lane_), "+v"(tid_));
+        int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+        const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
+        stamp();
+
+        load_input(tile);
+        v4i w1g[U8 ? 4 : 1], b1g;
+        if constexpr (U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1g[v] = *(const v4i *)(p.wf + v * 1024 + lane_ * 16);
+            b1g = *(const v4i *)(p.bias1 + 4 * g_);
+        }
+#if FRONT_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();
+#endif
+
+        // ---- Q: quantise into the LDS patch of 4-byte pixels (r, g, b, 0): q = clamp(rne(x * 2^sa0))  (slim_yolo_v2.py:33-35).
+        // Patch column L holds global column x0p + 1 + L: the 4x4 neighbourhood of every conv1 window then starts on an
+        // 8-byte boundary (one pixel to the left of the aligned 4-pixel groups the loads use: the fourth word of an
+        // LDS group comes from the next lane).
+        auto quantise = [&](auto clampc, auto k0c, auto k1c) {
+            constexpr bool CLAMP = decltype(clampc)::value;      // cold: clamp (and count the tile's own clamped values)
+            float am = 0.f;
+            unsigned int sato = 0;
+#pragma unroll
+            for (int k = decltype(k0c)::value; k < decltype(k1c)::value; ++k) {
+                const int r = qr0 + 16 * k;
+                unsigned int w[4];
+                if constexpr (U8) {
+                    const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        // pixel px = bytes 3 px .. 3 px + 2 (B, G, R); RGB channel c = BGR byte 2 - c
+                        unsigned int e = 0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int bi = 3 * px + (2 - c);
+                            const unsigned int u = (d[bi >> 2] >> (8 * (bi & 3))) & 0xffu;
+                            e |= lut[c * 256 + u];
+                        }
+                        sato |= e;
+                        w[px] = e & 0x00ffffffu;
+                    }
+                } else {
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        const float xr = px == 0 ? vf[k][0].x : px == 1 ? vf[k][0].y : px == 2 ? vf[k][0].z : vf[k][0].w;
+                        const float xg = px == 0 ? vf[k][1].x : px == 1 ? vf[k][1].y : px == 2 ? vf[k][1].z : vf[k][1].w;
+                        const float xb = px == 0 ? vf[k][2].x : px == 1 ? vf[k][2].y : px == 2 ? vf[k][2].z : vf[k][2].w;
+                        float yr = fmaf(xr, sc, MAGIC), yg = fmaf(xg, sc, MAGIC), yb = fmaf(xb, sc, MAGIC);
+                        if constexpr (CLAMP) {
+                            yr = __builtin_amdgcn_fmed3f(yr, QLO, QHI);
+                            yg = __builtin_amdgcn_fmed3f(yg, QLO, QHI);
+                            yb = __builtin_amdgcn_fmed3f(yb, QLO, QHI);
+                        } else {
+                            am = vmax3abs(am, xr, xg);
+                            am = vmaxabs(am, xb);
+                        }
+                        w[px] = pack3(yr, yg, yb);
+                    }
+                }
+                const int gy = y0p + r, gx = x0p + 4 * qj;
+                const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const bool zero = border && !inside;              // pixels outside the image are conv1's zero padding
+#pragma unroll
+                for (int px = 0; px < 4; ++px) w[px] = zero ? 0u : w[px];
+                v4i wv;
+                wv[0] = (int)w[1];
+                wv[1] = (int)w[2];
+                wv[2] = (int)w[3];
+                wv[3] = (int)row_next(w[0]);
+                if (r < PH0 && qj < 15) *(v4i *)(patch + r * P0 + 4 * qj) = wv;
+                if constexpr (CLAMP) {
+                    // exact count over the pixels this tile OWNS (rows [3, 3 + 4 TOY), load groups [1, TOX] of the
+                    // patch: the tiles' exclusive input areas partition the image)
+                    const bool own = inside && r >= 3 && r < 3 + 4 * TOY && qj >= 1 && qj <= TOX;
+                    if constexpr (U8) {
+                        const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
+#pragma unroll
+                        for (int bi = 0; bi < 12; ++bi) {
+                            const unsigned int u = (d[bi >> 2] >> (8 * (bi & 3))) & 0xffu;
+                            nsat_in += (own && (lut[(2 - bi % 3) * 256 + u] >> 24)) ? 1u : 0u;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float xs[4] = {vf[k][c].x, vf[k][c].y, vf[k][c].z, vf[k][c].w};
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) nsat_in += (own && !(fabsf(xs[px]) < in_thr)) ? 1u : 0u;
+                        }
+                    }
+                }
+            }
+            return U8 ? (sato >> 24) != 0u : !(am < in_thr);          // also true for NaN / Inf inputs
+        };
+        if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{}, K0{}, KN{})) != 0ull) {
+            load_input(tile);                                 // cold: the input registers were given up after the hot pass
+            (void)quantise(std::true_type{}, K0{}, KN{});
+        }
+        // conv1: weight variant (dy, dx) = v >> 1, v & 1 and the biases as the MFMAs' C operand (accumulator register r of lane
+        // (li, g) = channel 4 g + r).  fp32 input: from the copy in LDS (the input registers leave no room to hold them
+        // through Q at 128 registers per lane); uint8 input: from global memory, in flight behind the frame bytes
+        v4i w1[4], b1v;
+        if constexpr (U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1[v] = w1g[v];
+            b1v = b1g;
+        }
+        stamp();
+        front_lds_barrier();                              // B1: patch complete
+        stamp();
+        if constexpr (!U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1[v] = *(const v4i *)(wl + v * 1024 + lane_ * 16);
+            b1v = *(const v4i *)(wl + 4096 + 16 * g_);
+        }
+        v4i cin1;
+        float bf1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cin1[r] = FOLD ? b1v[r] + 0x4B400000 : 0;
+            bf1[r] = (float)b1v[r];
+        }
+
+        // conv2 fragments [filter row][dx] of n-tile 0 (in flight during C1; n-tile 1's are loaded under the first C2 pass)
+        v4i w2a[3][2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) w2a[ky][dx] = *(const v4i *)(p.wf + 4096 + (ky * 2 + dx) * 1024 + lane_ * 16);
+        const v4i b2v[2] = {*(const v4i *)(p.bias2 + 8 * g_), *(const v4i *)(p.bias2 + 8 * g_ + 4)};   // channel 8 g + 4 n + r
+        // ---- C1: conv1 + pool1 -> p1.  Group = 16 consecutive windows of the 28 x 28 window grid (row-major);
+        // wave w owns groups w, w + 4, ...  Lane (li, g): window li of the group, neighbourhood row g.
+        const int gyp0 = 2 * TOY * ty - 1, gxp0 = 2 * TOX * tx - 1;     // pooled coordinates of window (0, 0)
+        // Passes (COLD = false / true).  FRONT_HOTCOLD: hot = round, pack and write UNCLAMPED, tracking the running max / min of
+        // the rounded values (two ops per four outputs); when they leave [-127, 127] (rare) the cold pass rewrites this
+        // wave's groups clamped and counts the tile's own clamped outputs.  Otherwise: hot = clamp + one detect op per
+        // output, cold = count only.
+        auto c1 = [&](auto coldc, auto borderc) {
+            constexpr bool COLD = decltype(coldc)::value, BORDER = decltype(borderc)::value;
+            constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
+            unsigned int satx = 0;
+            float ymx = MAGIC, ymn = MAGIC;
+            auto body = [&](int grp) {
+                const int w = grp * 16 + li_;
+                const int py = (w * 2341) >> 16;                  // w / 28 for w < 784
+                const int px = w - py * P1W;
+                const unsigned int *src = patch + (2 * py + g_) * P0 + 2 * px;
+                const uint2 lo = *(const uint2 *)src, hi = *(const uint2 *)(src + 2);
+                const v4i bq = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+                v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[0], bq, cin1, 0, 0, 0);
+                v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[1], bq, cin1, 0, 0, 0);
+                v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[2], bq, cin1, 0, 0, 0);
+                v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[3], bq, cin1, 0, 0, 0);
+                float y[4], yc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = max(max(a0[r], a1[r]), max(a2[r], a3[r]));
+                    y[r] = rq_round<FOLD>(m, bf1[r], f1);
+                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
+                }
+                const bool inimg = !(BORDER || COLD) || ((unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp);
+                if constexpr (!COLD) {
+                    if constexpr (FRONT_HOTCOLD) {
+                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
+                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
+                    }
+                } else {
+                    const bool own = inimg && py >= 1 && py < P1H - 1 && px >= 1 && px < P1W - 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                }
+                if constexpr (WRITE) {
+                    unsigned int word = pack4(yc[0], yc[1], yc[2], yc[3]);
+                    if constexpr (BORDER || COLD) word = inimg ? word : 0u;   // windows outside the image: conv2's zero padding
+                    *(unsigned int *)(p1 + (py * P1P + px) * 16 + 4 * g_) = word;
+                }
+            };
+            // wave w owns groups w, w + 4, ..., two per trip so that one group's epilogue runs under the other's MFMAs
+#pragma unroll 1
+            for (int i = 0; i < NG1 / 8; ++i) {
+                body(wave + 8 * i);
+                body(wave + 8 * i + 4);
+            }
+            if (wave < NG1 % 8) body(wave + 8 * (NG1 / 8));
+            static_assert(NG1 % 8 <= 4, "tail groups: at most one per wave");
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
+            return satx;
+        };
+        unsigned int s1 = border ? c1(std::false_type{}, std::true_type{}) : c1(std::false_type{}, std::false_type{});
+        if (__builtin_amdgcn_ballot_w64(s1 != 0) != 0ull) nsat1 += c1(std::true_type{}, std::true_type{});
+        stamp();
+        front_lds_barrier();                              // B2: p1 complete
+        stamp();
+
+        // ---- C2: conv2 + pool2 -> staged int8 tile, one pass per n-tile (16 output channels: channel 8 g + 4 n + r in
+        // register r of lane group g).  Group = 16 consecutive windows of the 13 x 13 grid (the last group's padding slots
+        // repeat window 168); k-step t = neighbourhood row t, lane group g = neighbourhood column.
+        v4i w2b[3][2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) w2b[ky][dx] = *(const v4i *)(p.wf + 4096 + ((3 + ky) * 2 + dx) * 1024 + lane_ * 16);
+        auto c2 = [&](auto coldc, auto nc, const v4i (&w2)[3][2]) {
+            constexpr bool COLD = decltype(coldc)::value;
+            constexpr int n = decltype(nc)::value;
+            constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
+            unsigned int satx = 0;
+            float ymx = MAGIC, ymn = MAGIC;
+            v4i cin2;
+            float bf2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cin2[r] = FOLD ? b2v[n][r] + 0x4B400000 : 0;
+                bf2[r] = (float)b2v[n][r];
+            }
+#pragma unroll 1
+            for (int grp = wave; grp < NG2; grp += 4) {
+                const int wraw = grp * 16 + li_;
+                const int w = min(wraw, NW2 - 1);
+                const int wy = (w * 5042) >> 16;                  // w / 13 for w < 169
+                const int wx = w - wy * TOX;
+                const char *src = p1 + ((2 * wy) * P1P + 2 * wx + g_) * 16;
+                v4i acc[2][2];                                    // [dy][dx]
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = cin2;
+                v4i bq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bq[t] = *(const v4i *)(src + t * P1P * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int ky = t - dy;
+                        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+                            acc[dy][dx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2[ky][dx], bq[t], acc[dy][dx], 0, 0, 0);
+                    }
+                float y[4], yc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = max(max(acc[0][0][r], acc[0][1][r]), max(acc[1][0][r], acc[1][1][r]));
+                    y[r] = rq_round<FOLD>(m, bf2[r], f2);
+                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
+                }
+                if constexpr (!COLD) {
+                    if constexpr (FRONT_HOTCOLD) {
+                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
+                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
+                    }
+                } else {
+                    const bool own = wraw < NW2 && TOY * ty + wy < Ho && TOX * tx + wx < Wo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                }
+                if constexpr (WRITE) *(unsigned int *)(stg + wraw * 32 + 8 * g_ + 4 * n) = pack4(yc[0], yc[1], yc[2], yc[3]);
+            }
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
+            return satx;
+        };
+        using N0 = std::integral_constant<int, 0>;
+        using N1 = std::integral_constant<int, 1>;
+        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}, N0{}, w2a) != 0) != 0ull) nsat2 += c2(std::true_type{}, N0{}, w2a);
+        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}, N1{}, w2b) != 0) != 0ull) nsat2 += c2(std::true_type{}, N1{}, w2b);
+        stamp();
+        front_lds_barrier();                              // B3: staged tile complete
+        stamp();
+
+        // ---- OUT: NHWC32 with halo, 16 bytes per thread and item (item = 2 * window + half)
+        {
+            int8_t *outb = p.out + (((size_t)b * (Ho + 2) + TOY * ty + 1) * (Wo + 2) + TOX * tx + 1) * 32;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int item = tid_ + 256 * k;
+                const int wdw = item >> 1;
+                const int row = (wdw * 5042) >> 16, col = wdw - row * TOX;        // wdw / 13 for wdw < 256
+                if (item < NW2 * 2 && TOY * ty + row < Ho && TOX * tx + col < Wo)
+                    *(v4i *)(outb + (row * (Wo + 2) + col) * 32 + (item & 1) * 16) = *(const v4i *)(stg + item * 16);
+            }
+        }
+        if (tile + G_ >= total_tiles) break;
+        // the next tile's Q phase writes `patch` (last read before B2) and its C1 writes `p1` (last read before B3):
+        // both are behind a barrier every wave has passed; `stg` is rewritten only after B2 of the next tile
+    }
+    if (nsat_in) atomicAdd(&p.ctr[0].in_sat, (unsigned long long)nsat_in);
+    if (nsat1) atomicAdd(&p.ctr[0].sat, (unsigned long long)nsat1);
+    if (nsat2) atomicAdd(&p.ctr[1].sat, (unsigned long long)nsat2);
+}
+
+// ---- round 4: the same arithmetic on 512-thread workgroups (fp32 input, FOLD epilogue).  A tile's phases are split over eight
+// waves, conv2's fragments live in LDS (every wave reads the six of its channel half per tile) and the staged output tile is
+// aliased onto the input patch: 44.5 KB of LDS and FRONT8_OCC x 8 waves per CU.
+#ifndef FRONT8_OCC
+#define FRONT8_OCC 3
+#endif
+template <bool U8, bool FOLD>
+__global__ __launch_bounds__(512, 2 * FRONT8_OCC) void front8_kernel(const FrontParams p, const int total_tiles) {
+    static_assert(!U8 && FOLD, "front8_kernel: fp32 input, folded epilogue");
+    // separate LDS objects: the compiler then knows that the writes of one phase do not alias the reads of the same phase
+    __shared__ __attribute__((aligned(16))) unsigned int patch[PH0 * P0];
+    __shared__ __attribute__((aligned(16))) char p1[P1ROWS * P1P * 16];
+    __shared__ __attribute__((aligned(16))) unsigned int lut[4];
+    __shared__ __attribute__((aligned(16))) char wl[16384 + 64];                 // all fragments (conv1: 4 KiB, conv2: 12 KiB) and conv1's biases
+    char *stg = (char *)patch;                                                   // dead between B2 and the next tile's Q
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int H = p.H, W = p.W;
+    const int Hp = H >> 1, Wp = W >> 1, Ho = H >> 2, Wo = W >> 2;
+    const size_t plane = (size_t)H * W;
+    const float sc = p.in_scale;
+    const float in_thr = 127.5f / sc;                  // |x| >= thr  <=>  rne(|x| * 2^sa0) > 127 (sc is a power of two)
+
+    // ---- nothing but a few constants stays in registers across phases: the weight fragments and biases (16 KiB + 192 B,
+    // L2-resident) are re-read per tile just ahead of the phase that uses them (128 registers per lane at four workgroups per CU)
+    const Requant rq1 = p.rq1, rq2 = p.rq2;
+    const RqF f1 = make_rqf<FOLD>(rq1), f2 = make_rqf<FOLD>(rq2);
+    if constexpr (U8) {
+        // normalise + quantise is a function of the byte: per channel a 256-entry table built with the reference's
+        // fp32 operations in the reference's order ((u/255 - mean)/std, data/__init__.py:43-45; round(x * 2^sa),
+        // slim_yolo_v2.py:35); entry = the int8 value already in the pixel word's byte c, bit 24 = "was clamped"
+        // (byte 3 of a pixel multiplies zero weights)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = (float)tid;
+            t /= 255.0f;
+            t -= p.nmean[c];
+            t /= p.nstd[c];
+            const float r = rintf(t * sc);
+            const float rc = fminf(fmaxf(r, -127.f), 127.f);
+            lut[c * 256 + tid] = (((unsigned int)(int)rc & 0xffu) << (8 * c)) | (rc != r ? (1u << 24) : 0u);
+        }
+    }
+
+    // ---- tile-independent per-thread geometry
+    // Q: wave-item q = wave + 4 k covers patch rows 4 q .. 4 q + 3; lane = 16 * (row in the item) + 4-pixel group j
+    // (j = 15 is an idle slot: 15 groups = 60 pixels per row are loaded)
+    int qr0 = 4 * wave + g;                            // row of item k: qr0 + 32 k
+    const int qj = li;
+    const int G_ = gridDim.x;
+    int tile = y355_xcd_remap(blockIdx.x, G_);
+    if (tile >= total_tiles) return;
+    int nstamp = 0;
+    auto stamp = [&]() {
+#if FRONT_DIAG
+        if (p.stamps && tid == 0 && nstamp < 32) p.stamps[(size_t)blockIdx.x * 32 + nstamp++] = __builtin_amdgcn_s_memtime();
+#endif
+    };
+    (void)nstamp;
+    *(v4i *)(wl + tid * 16) = *(const v4i *)(p.wf + tid * 16);
+    *(v4i *)(wl + 8192 + tid * 16) = *(const v4i *)(p.wf + 8192 + tid * 16);
+    if (tid < 4) *(v4i *)(wl + 16384 + 16 * tid) = *(const v4i *)(p.bias1 + 4 * tid);
+    front_lds_barrier();                                // the table / the fragments are complete
+    unsigned int nsat_in = 0, nsat1 = 0, nsat2 = 0;
+
+    // ---- a tile's input patch: QITEMS x (3 x float4 | 12 bytes) per thread, all in flight together.  (Issuing the next
+    // tile's under C2 of the current one was measured slower in every form -- all of it, half of it, three or four
+    // workgroups per CU: profiles/r03_notes.md; the other workgroups of the CU cover the wait.)
+    constexpr int QI8 = 2;                             // input items (row, 4-pixel group) per thread: 8 waves x 2 x 4 rows
+    float4 vf[QI8][3];
+    uint3 vu[1];
+    auto load_input = [&](int t) {
+        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+#pragma unroll
+        for (int k = 0; k < QI8; ++k) {
+            const int r = qr0 + 32 * k;
+            const int gy = min(max(y0p + r, 0), H - 1);       // rows / groups past the patch or the image re-read valid data
+            const int gx = min(max(x0p + 4 * qj, 0), W - 4);
+            const size_t o = (size_t)gy * W + gx;
+            if constexpr (U8) {
+                vu[k] = *(const uint3 *)(p.x_u8 + ((size_t)b * plane + o) * 3);
+            } else {
+                const float *xb = p.x + (size_t)b * 3 * plane + o;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vf[k][c] = *(const float4 *)(xb + c * plane);
+            }
+        }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using KN = std::integral_constant<int, QI8>;
+
+    for (;; tile += G_) {
+        // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
+        // out of the tile loop as a loop invariant and held in registers
+        int li_ = li, g_ = g, lane_ = lane, tid_ = tid;
+        asm volatile("" : "+v"(qr0), "+v"(li_), "+v"(g_), "+v"(lane_), "+v"(tid_));
+        int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+        const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
+        stamp();
+
+        load_input(tile);
+        v4i w1g[U8 ? 4 : 1], b1g;
+        if constexpr (U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1g[v] = *(const v4i *)(p.wf + v * 1024 + lane_ * 16);
+            b1g = *(const v4i *)(p.bias1 + 4 * g_);
+        }
+#if FRONT_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();
+#endif
+
+        // ---- Q: quantise into the LDS patch of 4-byte pixels (r, g, b, 0): q = clamp(rne(x * 2^sa0))  (slim_yolo_v2.py:33-35).
+        // Patch column L holds global column x0p + 1 + L: the 4x4 neighbourhood of every conv1 window then starts on an
+        // 8-byte boundary (one pixel to the left of the aligned 4-pixel groups the loads use: the fourth word of an
+        // LDS group comes from the next lane).
+        auto quantise = [&](auto clampc, auto k0c, auto k1c) {
+            constexpr bool CLAMP = decltype(clampc)::value;      // cold: clamp (and count the tile's own clamped values)
+            float am = 0.f;
+            unsigned int sato = 0;
+#pragma unroll
+            for (int k = decltype(k0c)::value; k < decltype(k1c)::value; ++k) {
+                const int r = qr0 + 32 * k;
+                unsigned int w[4];
+                if constexpr (U8) {
+                    const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        // pixel px = bytes 3 px .. 3 px + 2 (B, G, R); RGB channel c = BGR byte 2 - c
+                        unsigned int e = 0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int bi = 3 * px + (2 - c);
+                            const unsigned int u = (d[bi >> 2] >> (8 * (bi & 3))) & 0xffu;
+                            e |= lut[c * 256 + u];
+                        }
+                        sato |= e;
+                        w[px] = e & 0x00ffffffu;
+                    }
+                } else {
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        const float xr = px == 0 ? vf[k][0].x : px == 1 ? vf[k][0].y : px == 2 ? vf[k][0].z : vf[k][0].w;
+                        const float xg = px == 0 ? vf[k][1].x : px == 1 ? vf[k][1].y : px == 2 ? vf[k][1].z : vf[k][1].w;
+                        const float xb = px == 0 ? vf[k][2].x : px == 1 ? vf[k][2].y : px == 2 ? vf[k][2].z : vf[k][2].w;
+                        float yr = fmaf(xr, sc, MAGIC), yg = fmaf(xg, sc, MAGIC), yb = fmaf(xb, sc, MAGIC);
+                        if constexpr (CLAMP) {
+                            yr = __builtin_amdgcn_fmed3f(yr, QLO, QHI);
+                            yg = __builtin_amdgcn_fmed3f(yg, QLO, QHI);
+                            yb = __builtin_amdgcn_fmed3f(yb, QLO, QHI);
+                        } else {
+                            am = vmax3abs(am, xr, xg);
+                            am = vmaxabs(am, xb);
+                        }
+                        w[px] = pack3(yr, yg, yb);
+                    }
+                }
+                const int gy = y0p + r, gx = x0p + 4 * qj;
+                const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const bool zero = border && !inside;              // pixels outside the image are conv1's zero padding
+#pragma unroll
+                for (int px = 0; px < 4; ++px) w[px] = zero ? 0u : w[px];
+                v4i wv;
+                wv[0] = (int)w[1];
+                wv[1] = (int)w[2];
+                wv[2] = (int)w[3];
+                wv[3] = (int)row_next(w[0]);
+                if (r < PH0 && qj < 15) *(v4i *)(patch + r * P0 + 4 * qj) = wv;
+                if constexpr (CLAMP) {
+                    // exact count over the pixels this tile OWNS (rows [3, 3 + 4 TOY), load groups [1, TOX] of the
+                    // patch: the tiles' exclusive input areas partition the image)
+                    const bool own = inside && r >= 3 && r < 3 + 4 * TOY && qj >= 1 && qj <= TOX;
+                    if constexpr (U8) {
+                        const unsigned int d[3] = {vu[k].x, vu[k].y, vu[k].z};
+#pragma unroll
+                        for (int bi = 0; bi < 12; ++bi) {
+                            const unsigned int u = (d[bi >> 2] >> (8 * (bi & 3))) & 0xffu;
+                            nsat_in += (own && (lut[(2 - bi % 3) * 256 + u] >> 24)) ? 1u : 0u;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float xs[4] = {vf[k][c].x, vf[k][c].y, vf[k][c].z, vf[k][c].w};
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) nsat_in += (own && !(fabsf(xs[px]) < in_thr)) ? 1u : 0u;
+                        }
+                    }
+                }
+            }
+            return U8 ? (sato >> 24) != 0u : !(am < in_thr);          // also true for NaN / Inf inputs
+        };
+        if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{}, K0{}, KN{})) != 0ull) {
+            load_input(tile);                                 // cold: the input registers were given up after the hot pass
+            (void)quantise(std::true_type{}, K0{}, KN{});
+        }
+        // conv1: weight variant (dy, dx) = v >> 1, v & 1 and the biases as the MFMAs' C operand (accumulator register r of lane
+        // (li, g) = channel 4 g + r).  fp32 input: from the copy in LDS (the input registers leave no room to hold them
+        // through Q at 128 registers per lane); uint8 input: from global memory, in flight behind the frame bytes
+        v4i w1[4], b1v;
+        if constexpr (U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1[v] = w1g[v];
+            b1v = b1g;
+        }
+        stamp();
+        front_lds_barrier();                              // B1: patch complete
+        stamp();
+        if constexpr (!U8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w1[v] = *(const v4i *)(wl + v * 1024 + lane_ * 16);
+            b1v = *(const v4i *)(wl + 16384 + 16 * g_);
+        }
+        v4i cin1;
+        float bf1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cin1[r] = FOLD ? b1v[r] + 0x4B400000 : 0;
+            bf1[r] = (float)b1v[r];
+        }
+
+        // conv2 fragments [filter row][dx] of n-tile 0 (in flight during C1; n-tile 1's are loaded under the first C2 pass)
+        const int npass = wave >> 2;                       // this wave's half of conv2's output channels: 8 g + 4 npass + r
+        const v4i b2w = *(const v4i *)(p.bias2 + 8 * g_ + 4 * npass);
+        // ---- C1: conv1 + pool1 -> p1.  Group = 16 consecutive windows of the 28 x 28 window grid (row-major);
+        // wave w owns groups w, w + 4, ...  Lane (li, g): window li of the group, neighbourhood row g.
+        const int gyp0 = 2 * TOY * ty - 1, gxp0 = 2 * TOX * tx - 1;     // pooled coordinates of window (0, 0)
+        // Passes (COLD = false / true).  FRONT_HOTCOLD: hot = round, pack and write UNCLAMPED, tracking the running max / min of
+        // the rounded values (two ops per four outputs); when they leave [-127, 127] (rare) the cold pass rewrites this
+        // wave's groups clamped and counts the tile's own clamped outputs.  Otherwise: hot = clamp + one detect op per
+        // output, cold = count only.
+        auto c1 = [&](auto coldc, auto borderc) {
+            constexpr bool COLD = decltype(coldc)::value, BORDER = decltype(borderc)::value;
+            constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
+            unsigned int satx = 0;
+            float ymx = MAGIC, ymn = MAGIC;
+            auto body = [&](int grp) {
+                const int w = grp * 16 + li_;
+                const int py = (w * 2341) >> 16;                  // w / 28 for w < 784
+                const int px = w - py * P1W;
+                const unsigned int *src = patch + (2 * py + g_) * P0 + 2 * px;
+                const uint2 lo = *(const uint2 *)src, hi = *(const uint2 *)(src + 2);
+                const v4i bq = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+                v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[0], bq, cin1, 0, 0, 0);
+                v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[1], bq, cin1, 0, 0, 0);
+                v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[2], bq, cin1, 0, 0, 0);
+                v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[3], bq, cin1, 0, 0, 0);
+                float y[4], yc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = max(max(a0[r], a1[r]), max(a2[r], a3[r]));
+                    y[r] = rq_round<FOLD>(m, bf1[r], f1);
+                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
+                }
+                const bool inimg = !(BORDER || COLD) || ((unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp);
+                if constexpr (!COLD) {
+                    if constexpr (FRONT_HOTCOLD) {
+                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
+                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
+                    }
+                } else {
+                    const bool own = inimg && py >= 1 && py < P1H - 1 && px >= 1 && px < P1W - 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                }
+                if constexpr (WRITE) {
+                    unsigned int word = pack4(yc[0], yc[1], yc[2], yc[3]);
+                    if constexpr (BORDER || COLD) word = inimg ? word : 0u;   // windows outside the image: conv2's zero padding
+                    *(unsigned int *)(p1 + (py * P1P + px) * 16 + 4 * g_) = word;
+                }
+            };
+            // wave w owns groups w, w + 4, ..., two per trip so that one group's epilogue runs under the other's MFMAs
+#pragma unroll 1
+            for (int i = 0; i < NG1 / 16; ++i) {
+                body(wave + 16 * i);
+                body(wave + 16 * i + 8);
+            }
+            if (wave < NG1 % 16) body(wave + 16 * (NG1 / 16));
+            static_assert(NG1 % 16 <= 8, "tail groups: at most one per wave");
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
+            return satx;
+        };
+        unsigned int s1 = border ? c1(std::false_type{}, std::true_type{}) : c1(std::false_type{}, std::false_type{});
+        if (__builtin_amdgcn_ballot_w64(s1 != 0) != 0ull) nsat1 += c1(std::true_type{}, std::true_type{});
+        stamp();
+        front_lds_barrier();                              // B2: p1 complete
+        stamp();
+
+        // ---- C2: conv2 + pool2 -> staged int8 tile, one pass per n-tile (16 output channels: channel 8 g + 4 n + r in
+        // register r of lane group g).  Group = 16 consecutive windows of the 13 x 13 grid (the last group's padding slots
+        // repeat window 168); k-step t = neighbourhood row t, lane group g = neighbourhood column.
+        v4i w2r[3][2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) w2r[ky][dx] = *(const v4i *)(wl + 4096 + ((npass * 3 + ky) * 2 + dx) * 1024 + lane_ * 16);
+        auto c2 = [&](auto coldc, const v4i (&w2)[3][2]) {
+            constexpr bool COLD = decltype(coldc)::value;
+            const int n = npass;
+            constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
+            unsigned int satx = 0;
+            float ymx = MAGIC, ymn = MAGIC;
+            v4i cin2;
+            float bf2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cin2[r] = FOLD ? b2w[r] + 0x4B400000 : 0;
+                bf2[r] = (float)b2w[r];
+            }
+#pragma unroll 1
+            for (int grp = wave & 3; grp < NG2; grp += 4) {
+                const int wraw = grp * 16 + li_;
+                const int w = min(wraw, NW2 - 1);
+                const int wy = (w * 5042) >> 16;                  // w / 13 for w < 169
+                const int wx = w - wy * TOX;
+                const char *src = p1 + ((2 * wy) * P1P + 2 * wx + g_) * 16;
+                v4i acc[2][2];                                    // [dy][dx]
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = cin2;
+                v4i bq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bq[t] = *(const v4i *)(src + t * P1P * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int ky = t - dy;
+                        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+                            acc[dy][dx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2[ky][dx], bq[t], acc[dy][dx], 0, 0, 0);
+                    }
+                float y[4], yc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = max(max(acc[0][0][r], acc[0][1][r]), max(acc[1][0][r], acc[1][1][r]));
+                    y[r] = rq_round<FOLD>(m, bf2[r], f2);
+                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
+                }
+                if constexpr (!COLD) {
+                    if constexpr (FRONT_HOTCOLD) {
+                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
+                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
+                    }
+                } else {
+                    const bool own = wraw < NW2 && TOY * ty + wy < Ho && TOX * tx + wx < Wo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                }
+                if constexpr (WRITE) *(unsigned int *)(stg + wraw * 32 + 8 * g_ + 4 * n) = pack4(yc[0], yc[1], yc[2], yc[3]);
+            }
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
+            return satx;
+        };
+        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}, w2r) != 0) != 0ull) nsat2 += c2(std::true_type{}, w2r);
+        stamp();
+        front_lds_barrier();                              // B3: staged tile complete
+        stamp();
+
+        // ---- OUT: NHWC32 with halo, 16 bytes per thread and item (item = 2 * window + half)
+        {
+            int8_t *outb = p.out + (((size_t)b * (Ho + 2) + TOY * ty + 1) * (Wo + 2) + TOX * tx + 1) * 32;
+#pragma unroll
+            for (int k = 0; k < 1; ++k) {
+                const int item = tid_ + 512 * k;
+                const int wdw = item >> 1;
+                const int row = (wdw * 5042) >> 16, col = wdw - row * TOX;        // wdw / 13 for wdw < 256
+                if (item < NW2 * 2 && TOY * ty + row < Ho && TOX * tx + col < Wo)
+                    *(v4i *)(outb + (row * (Wo + 2) + col) * 32 + (item & 1) * 16) = *(const v4i *)(stg + item * 16);
+            }
+        }
+        if (tile + G_ >= total_tiles) break;
+        front_lds_barrier();                              // B4: the staged tile (= the patch) has been read out
+    }
+    if (nsat_in) atomicAdd(&p.ctr[0].in_sat, (unsigned long long)nsat_in);
+    if (nsat1) atomicAdd(&p.ctr[0].sat, (unsigned long long)nsat1);
+    if (nsat2) atomicAdd(&p.ctr[1].sat, (unsigned long long)nsat2);
+}
+
+void y355_front_tiles(int H, int W, int *tx, int *ty) {
+    *tx = (W / 4 + TOX - 1) / TOX;
+    *ty = (H / 4 + TOY - 1) / TOY;
+}
+
+// Weight fragments of the fused front end (16 KiB): MFMA A operands, lane (i = l & 15: accumulator row, g = l >> 4), 16 bytes.
+//   conv1, variant v = 2 dy + dx (offset of the conv output inside the pooling window), at v * 1024:
+//     row i = output channel i; g = neighbourhood row; byte 4 nc + c = w[i][c][g - dy][nc - dx] (zero outside the 3x3 filter)
+//   conv2, fragment ((n * 3 + ky) * 2 + dx) at 4096 + ... * 1024:
+//     row i = output channel 8 (i >> 2) + 4 n + (i & 3); g = neighbourhood column; byte ci = w[ch][ci][ky][g - dx]
+void y355_pack_front(const int8_t *q_w1 /*[16][3][3][3]*/, const int8_t *q_w2 /*[32][16][3][3]*/, int8_t *dst /*16384*/) {
+    memset(dst, 0, 16384);
+    if (q_w1) {
+        for (int v = 0; v < 4; ++v)
+            for (int l = 0; l < 64; ++l) {
+                const int i = l & 15, g = l >> 4, ky = g - (v >> 1);
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int kx = (kk >> 2) - (v & 1), c = kk & 3;
+                    if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3 && c < 3)
+                        dst[v * 1024 + l * 16 + kk] = q_w1[((i * 3 + c) * 3 + ky) * 3 + kx];
+                }
+            }
+    }
+    if (q_w2) {
+        for (int n = 0; n < 2; ++n)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int dx = 0; dx < 2; ++dx)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = l & 15, g = l >> 4, kx = g - dx;
+                        const int ch = 8 * (i >> 2) + 4 * n + (i & 3);
+                        if (kx < 0 || kx > 2) continue;
+                        for (int ci = 0; ci < 16; ++ci)
+                            dst[4096 + ((n * 3 + ky) * 2 + dx) * 1024 + l * 16 + ci] = q_w2[((ch * 16 + ci) * 3 + ky) * 3 + kx];
+                    }
+    }
+}
+
+// true when the fused launch covers these two layers: 32-bit epilogues whose t stays below 2^24 (exact in fp32)
+bool y355_front_eligible(const Requant &rq1, const Requant &rq2) {
+    return !rq1.wide && !rq2.wide && rq1.tmax_log2 <= 24 && rq2.tmax_log2 <= 24;
+}
+
+void y355_launch_front(const FrontParams &p, hipStream_t s) {
+    const int total = p.tiles_x * p.tiles_y * p.B;
+    int grid = 256 * FRONT_OCC;
+    if (grid > total) grid = total;
+    auto foldable = [](const Requant &rq) { return rq.shl == 0 && rq.tmax_log2 <= 22 && rq.sh <= 22 && rq.sh - rq.lk >= -8; };
+    const bool fold = foldable(p.rq1) && foldable(p.rq2);
+    FrontParams q = p;
+    q.ev_start = q.ev_stop = nullptr;
+    if (p.x) {
+#if FRONT8
+        if (fold) {
+            int g8 = 256 * FRONT8_OCC;
+            if (g8 > total) g8 = total;
+            Y355_LAUNCH((front8_kernel<false, true>), dim3(g8), dim3(512), 0, s, p.ev_start, p.ev_stop, q, total);
+        }
+#else
+        if (fold) Y355_LAUNCH((front_kernel<false, true>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+#endif
+        else Y355_LAUNCH((front_kernel<false, false>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+    } else {
+        if (fold) Y355_LAUNCH((front_kernel<true, true>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+        else Y355_LAUNCH((front_kernel<true, false>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+    }
+}
