@@ -53,7 +53,7 @@ def signatures(build):
                     out[name]["vmcnt"][m.group(1)] = out[name]["vmcnt"].get(m.group(1), 0) + 1
     return out
 
-GUARDED = ("conv3x3_i8_ring_kernel", "conv3x3_i8_v2_kernel", "conv1_fast_kernel", "front_kernel", "convpx_kernel", "convr_kernel")
+GUARDED = ("conv3x3_i8_ring_kernel", "conv1_fast_kernel", "front_kernel", "convpx_kernel", "convr_kernel")
 
 
 def main(build):

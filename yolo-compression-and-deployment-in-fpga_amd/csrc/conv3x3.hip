@@ -302,7 +302,7 @@ struct ConvInst {
     }
 };
 
-// conv3_1's tile (shared with conv3x3_v2.hip through y355_common.h: the weight packing depends on WN)
+// conv3_1's tile (y355_common.h: the weight packing depends on WN)
 static const ConvKernelInfo g_kernels[Y355_K_COUNT] = {
     //        CIN  BN  TH  TW  POOL  WM WN      tuned for 416x416
     ConvInst<16, 32, 16, 52, true, 4, 1>::info(),     // conv2    208x208
@@ -310,7 +310,7 @@ static const ConvKernelInfo g_kernels[Y355_K_COUNT] = {
     ConvInst<64, 64, 26, 26, true, 4, 1>::info(),     // conv3_2  104x104
     ConvInst<64, 128, 13, 26, false, 2, 2>::info(),   // conv4_1  52x52
     ConvInst<128, 64, 26, 26, true, 4, 1>::info(),    // conv4_2  52x52
-    ConvInst<128, 128, 13, 26, false, 2, 2>::info(),  // conv5    26x26  (13x26 strip x 128 channels: see conv3x3_v2.hip)
+    ConvInst<128, 128, 13, 26, false, 2, 2>::info(),  // conv5    26x26  (13x26 strip x 128 channels)
     ConvInst<256, 128, 13, 26, false, 2, 2>::info(),  // conv6/7  26x26
     ConvInst<256, 64, 13, 13, false, 4, 1>::info(),   // pred     26x26
     // generic small-tile variants (operator-level API, any shape)

@@ -1,7 +1,7 @@
 // yolo355 -- fused int8 3x3 convolution, production kernel for layers with >= 64 input channels
 // (conv3_2 .. conv7, pred): persistent workgroups, LDS-DMA rings with a DEEP weight prefetch.
 //
-// Measured on conv3x3_v2.hip (s_memtime stamps, profiles/README.md): a k-step's MFMAs take ~700-900
+// Measured on the round-1 two-slot ring kernel (s_memtime stamps, profiles/README.md): a k-step's MFMAs take ~700-900
 // cycles, but every step also waited 300-2700 cycles for its LDS-DMA data -- an LDS-DMA issued behind
 // other traffic lands 1-1.5 us later, and the v2 ring kept only two k-steps in flight.  This kernel
 // keeps PF (5) k-steps of weights in flight:
@@ -14,7 +14,7 @@
 //     vmcnt stream;
 //   * the LDS that buys this comes from the epilogue: the int8 output tile is staged in the slab
 //     slot that just died (in two passes where it is larger than a slot), not in its own buffer.
-// Same math, tile geometry, weight packing and epilogue arithmetic as conv3x3_v2.hip / conv3x3.hip.
+// Same math, tile geometry, weight packing and epilogue arithmetic as conv3x3.hip.
 #include "y355_common.h"
 #include <hip/hip_ext.h>
 #include <cstdlib>

@@ -25,7 +25,7 @@
 //     0x4B400000 rides in as the MFMAs' C operand and the accumulator IS the float 1.5 * 2^23 + t; FOLD 1 (shift 0, |t| < 2^24):
 //     the bias rides in, one v_cvt; FOLD 0: v_cvt + fma; the hot pass stores unclamped and tracks max / min, a cold pass re-does a wave's groups clamped and
 //     counts when a value left [-127, 127].
-// Integer semantics: DESIGN.md section 2, bit for bit those of conv3x3_ring.hip / conv3x3_v2.hip / conv3x3.hip.
+// Integer semantics: DESIGN.md section 2, bit for bit those of conv3x3_ring.hip / conv3x3.hip.
 #include "y355_common.h"
 #include <cstring>
 #include <type_traits>

@@ -73,8 +73,6 @@ int y355_prepare_kernels() {
     }
     if (int e = y355_prepare_head())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(head): ") + hipGetErrorString((hipError_t)e));
-    if (int e = y355_prepare_conv_v2())
-        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(v2): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_ring())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(ring): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_px())
@@ -507,21 +505,16 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.rq = L.rq;
         p.mode = mode;
         p.guard = guard;
-        // kernel-selection switches of the experiment builds (make EXTRA=-DY355_EXPERIMENTS); the default library has one
-        // fixed kernel per layer and reads no environment variable
+        // one production kernel per layer, then ONE fallback family (conv3x3.hip: statistics mode, head-room guard, 64-bit
+        // epilogue, any shape).  conv3_1 .. conv4_2: weights in registers, pixels as the B operand (convpx.hip); conv3_2 .. pred:
+        // LDS-DMA rings (conv3x3_ring.hip); conv2 (only when the fused front end is off) and whatever those two refuse: conv3x3.hip.
+        // (Round 4: the resident-weight family conv3x3_v2.hip is gone -- it only ever ran where the fused front end or convpx refused.)
 #ifdef Y355_EXPERIMENTS
-        static const bool no_v2 = getenv("Y355_NO_V2") != nullptr;
-        static const int v2dbg = getenv("Y355_V2_DBG") ? atoi(getenv("Y355_V2_DBG")) : 0;
-        if (mode == 0) p.mode |= v2dbg << 8;
-        static const int fine = getenv("Y355_STAMP_FINE") ? 1 : 0;
-        if (mode == 0 && fine) p.mode |= 1 << 16;
-        static const int no_v2_mask = getenv("Y355_NO_V2_MASK") ? atoi(getenv("Y355_NO_V2_MASK")) : 0;
         static const int no_ring_mask = getenv("Y355_NO_RING_MASK") ? atoi(getenv("Y355_NO_RING_MASK")) : 0;
 #else
-        constexpr bool no_v2 = false;
-        constexpr int no_v2_mask = 0, no_ring_mask = 0;
+        constexpr int no_ring_mask = 0;
 #endif
-        if (!no_v2 && L.wpx_dev) {                            // conv3_1 .. conv4_2: weights in registers, pixels as the B operand (convpx.hip)
+        if (L.wpx_dev) {
             ConvParams q = p;
             q.w = L.wpx_dev;
             if (y355_launch_conv_px(L.kid, q, h->stream)) {
@@ -530,19 +523,12 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
                 return 0;
             }
         }
-        // layers whose whole weight tensor stays resident in LDS run conv3x3_v2.hip (no per-k-step barrier); the others the ring
-        if (!no_v2 && y355_conv_v2_preferred(L.kid) && y355_launch_conv_v2(L.kid, p, h->stream)) {
+        if (!((no_ring_mask >> k) & 1) && y355_launch_conv_ring(L.kid, p, h->stream)) {
             HIPCHK(hipGetLastError());
             h->kev_set[k] = p.ev_start != nullptr;
             return 0;
         }
-        if (!no_v2 && !((no_ring_mask >> k) & 1) && y355_launch_conv_ring(L.kid, p, h->stream)) {
-            HIPCHK(hipGetLastError());
-            h->kev_set[k] = p.ev_start != nullptr;
-            return 0;
-        }
-        if (no_v2 || ((no_v2_mask >> k) & 1) || !y355_launch_conv_v2(L.kid, p, h->stream))
-            ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
+        ki.launch(p, p.tiles_x * p.tiles_y * p.nblk * B, h->stream);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -22,7 +22,7 @@
 //     product once, to the integer grid of [2^23, 2^24), ties to even; five VALU operations instead of eight;
 //   * the input quantisation uses the same fma: q = low byte of fma(x, 2^sa0, M); three values are packed with two
 //     v_perm_b32; clamped inputs are detected from max |x| and handled (and counted exactly) in a cold pass.
-// Integer semantics are those of conv1.hip / conv3x3_v2.hip, bit for bit; saturation is detected with one op per output
+// Integer semantics are those of conv1.hip / conv3x3.hip, bit for bit; saturation is detected with one op per output
 // and counted exactly (own pixels only) in a cold second pass.
 #include "y355_common.h"
 #include <type_traits>

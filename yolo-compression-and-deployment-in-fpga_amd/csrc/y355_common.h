@@ -211,7 +211,7 @@ __device__ __forceinline__ unsigned long long y355_wave_max_u64(unsigned long lo
 }
 
 // conv3_1 (32 -> 64 channels at a quarter of the input resolution) tile geometry, shared by the generic kernel
-// (conv3x3.hip, always 4 waves: GWM x WN) and the production kernel (conv3x3_v2.hip, WM x WN waves)
+// (conv3x3.hip, always 4 waves: GWM x WN); the weight packing depends on WN
 #ifndef Y355_C31_TH
 #define Y355_C31_TH 13
 #define Y355_C31_TW 52
@@ -242,10 +242,6 @@ enum {
     Y355_K_COUNT
 };
 
-// production conv kernels (conv3x3_v2.hip): false = not available for this launch, use ki.launch
-bool y355_launch_conv_v2(int kid, const ConvParams &p, hipStream_t s);
-int y355_prepare_conv_v2(void);
-bool y355_conv_v2_preferred(int kid);     // true: this layer's production kernel is the resident-weight one of conv3x3_v2.hip
 // conv3_1 .. conv4_2 with the weights in registers and the pixels as the MFMA's B operand (convpx.hip); p.w = y355_pack_px layout
 bool y355_launch_conv_px(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_px(void);
