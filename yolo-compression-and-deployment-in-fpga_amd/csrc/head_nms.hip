@@ -594,7 +594,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         // out evaluates to ovr <= thr in the formula below as well (that is what the bounds prove) -- in branch-free code the
         // extra test was 25 instructions that saved none.  The partner's area comes from LDS (computed once per candidate).
         const float aj = __int_as_float(ctj.y);
-        const bool cand = ok && (q > i) && ((ctj.x & 0xffff) == ci);
+        const bool cand = ok & (q > i) & ((ctj.x & 0xffff) == ci);      // (&, not &&: no branch, no bool -> int -> bool round trip)
         // v_max / v_min issued as they are: hipcc quiets BOTH operands of every fmaxf / fminf first (8 extra v_max per test);
         // on numbers -- the coordinates are clamped to [0, 1] by the decode -- the bare instructions give the same result
         const float xx1 = raw_max(bi.x, bj.x), yy1 = raw_max(bi.y, bj.y);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
         const float iw = raw_max(1e-28f, xx2 - xx1), ih = raw_max(1e-28f, yy2 - yy1);
         const float inter = iw * ih, den = ai + aj - inter;
         const float qv = inter * __builtin_amdgcn_rcpf(den);
-        const bool sure = fast & (den > 1e-30f) & (den < 1e30f) & ((qv > q_hi) | (qv < q_lo));
+        const bool sure = fast & (den > 1e-30f) & ((qv > q_hi) | (qv < q_lo));     // (den <= 2: the decode clamps every box to [0, 1]; a NaN fails every comparison and takes the exact path)
         bool hit = cand & sure & (qv > q_hi);
         if (__any(cand & !sure)) {                         // rare: the correctly rounded quotient decides
             if (cand & !sure) hit = !(inter / den <= thr);
