@@ -298,7 +298,7 @@ def test_tiny_dropin_quantized():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [FP32_CASES[0], TINY[0]], ids=["slim", "tiny"])
+@pytest.mark.parametrize("case", FP32_CASES, ids=IDS)
 def test_bf16_fused_front_matches_layer_launches(case):
     """round 4: a forward without the tap runs conv(3->16)+pool and conv(16->32)+pool of the bf16 nets in ONE launch
     (csrc/frontb.hip); the tap forward runs them as two.  Same operands, same rounding points, only the order of the fp32
@@ -310,6 +310,7 @@ def test_bf16_fused_front_matches_layer_launches(case):
     fused = fnet.forward(x)
     nt = fnet.num_tensors
     npred = 2 if case[1] == "tiny_yolo_v3" else 1
+    assert not np.any(fnet.get_tensor(0, B)), "the fused launch does not write conv1's own map (the net is fresh: still zero)"
     t1_f = fnet.get_tensor(1, B).astype(np.float64)
     pred_f = [fnet.get_tensor(nt - npred + k, B).astype(np.float64) for k in range(npred)]
     tap = fnet.forward(x, tap=True)
