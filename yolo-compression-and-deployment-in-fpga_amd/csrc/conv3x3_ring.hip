@@ -253,10 +253,12 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         }
 
         v4i acc[MT][NT];
+        if constexpr (!FPE) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){0, 0, 0, 0};
+                for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){0, 0, 0, 0};
+        }
 
         // ---- pre-phase: publish W(0) (and slab 0) and read W(0)'s B fragments.
         // vmcnt is in issue order: "at most N younger operations may still fly".  Younger than W(0):
@@ -267,6 +269,15 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         else rwait_vmcnt<PF * WPW + ring_sp(-PF, -1, PPW, true) + NIT>();
         __builtin_amdgcn_s_barrier();
         pstamp(first ? 2 : 6);
+        if constexpr (FPE) {
+            // the accumulators start at the bias (t = acc + bias is what the epilogue wants: one v_add per output less there);
+            // the LDS copy of the biases is the prologue's oldest DMA: landed and published by the barrier above
+            const v4i bv = *(const v4i *)(smem + OFF_BIAS + (nb * BN + wn * (NT * 16) + li * NT) * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){bv[t], bv[t], bv[t], bv[t]};
+        }
         {
             const char *wb0 = smem + OFF_W + wq * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
@@ -409,9 +420,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
             const float s_pos = __int_as_float((127 + rq.lk - rq.sh_r) << 23), s_neg = __int_as_float((127 - rq.sh_r) << 23);
             int biasf[NT];
             if constexpr (FPE) {
-                const v4i bv = *(const v4i *)(smem + OFF_BIAS + (nb * BN + ncol) * 4);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) biasf[t] = bv[t];
+                for (int t = 0; t < NT; ++t) biasf[t] = 0;           // already in the accumulators (their initial value)
             }
             auto requantf = [&](int v, int t) {
                 const float tf = (float)(v + biasf[t]);
