@@ -1,4 +1,15 @@
 #include <hip/hip_runtime.h>
+// v_max_f32 with an SDWA byte destination: does byte k of d receive bits [7:0] of the fp32 result, the rest preserved?
+__global__ void kmax(const float *x, unsigned int *out) {
+    float a = x[threadIdx.x], b = x[threadIdx.x + 64], c = x[threadIdx.x + 128];
+    const float M = 12582912.0f;
+    float ya = a + M, yb = b + M, yc = c + M;          // bit patterns 0x4B400000 + value
+    unsigned int w = 0xdeadbeefu;
+    asm volatile("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(ya), "v"(yb));
+    asm volatile("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(yb), "v"(yc));
+    asm volatile("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(ya), "v"(yc));
+    out[threadIdx.x] = w;
+}
 __global__ void k(const float *x, unsigned int *out) {
     float a = x[threadIdx.x], b = x[threadIdx.x + 64], c = x[threadIdx.x + 128];
     unsigned int w = 0;
@@ -19,5 +30,14 @@ int main() {
         bad += want != r[i];
     }
     printf("sdwa cvt pack: %d mismatches, sample %08x\n", bad, r[5]);
-    return bad != 0;
+    kmax<<<1, 64>>>(x, o);
+    hipMemcpy(r, o, 256, hipMemcpyDeviceToHost);
+    int bad2 = 0;
+    for (int i = 0; i < 64; ++i) {
+        auto mx = [](float p, float q) { return (unsigned)(int)(p > q ? p : q) & 0xffu; };
+        unsigned int want = mx(h[i], h[i + 64]) | (mx(h[i + 64], h[i + 128]) << 8) | (mx(h[i], h[i + 128]) << 16) | 0xde000000u;
+        bad2 += want != r[i];
+    }
+    printf("sdwa v_max_f32 byte pack: %d mismatches, sample %08x\n", bad2, r[5]);
+    return (bad | bad2) != 0;
 }
