@@ -31,8 +31,8 @@
 #define FRONT_OCC 4
 #endif
 #ifndef FRONT_P0
-#define FRONT_P0 64              // patch pitch in pixels (dwords): 32 mod 64 keeps the two filter rows of a half-wave's
-#endif                           // ds_read_b64 on disjoint banks
+#define FRONT_P0 72              // patch pitch in pixels (dwords): 8 mod 64 puts the eight neighbourhood rows a half-wave's
+#endif                           // ds_read_b64 touches (4 window rows x 2 lane groups, 8 dwords each) on disjoint banks
 #ifndef FRONT_HOTCOLD
 #define FRONT_HOTCOLD 1          // 1: the hot pass does not clamp (running max / min of the rounded values detect a clamp; a cold pass
 #endif                           //    then rewrites the wave's outputs clamped and counts); 0: clamp + detect per output in the hot pass
@@ -47,14 +47,14 @@ constexpr int PH0 = 2 * P1H + 2;                     // input patch rows (= colu
 constexpr int P0 = FRONT_P0;
 constexpr int P1P = P1W;                             // p1 pitch in 16-byte pixels (28: rows two apart differ by 8 mod 16 slots)
 constexpr int P1ROWS = P1H + 2;                      // slack rows: the clamped padding windows of C2 stay inside
-constexpr int NW1 = P1H * P1W;                       // 784 conv1 windows = 49 groups of 16
-constexpr int NG1 = NW1 / 16;
+// 784 conv1 windows = 49 groups of 16: 7 x 7 blocks of 4 x 4 windows
+constexpr int BW1 = P1W / 4, BH1 = P1H / 4;          // blocks per row / rows of blocks of the window grid
 constexpr int NW2 = TOY * TOX;                       // 169 conv2 windows = 11 groups of 16 (7 padding slots)
 constexpr int NG2 = (NW2 + 15) / 16;
 constexpr int QITEMS = 4;                            // input items (row, 4-pixel group) per thread: 16 wave-items of 4 rows
 constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23
 constexpr float QLO = 12582785.0f, QHI = 12583039.0f;   // MAGIC -+ 127
-static_assert(NW1 % 16 == 0 && PH0 <= 4 * 4 * QITEMS && P0 % 4 == 0 && P0 >= PH0 + 2, "front geometry");
+static_assert(P1H % 4 == 0 && P1W % 4 == 0 && PH0 <= 4 * 4 * QITEMS && P0 % 4 == 0 && P0 >= PH0 + 2, "front geometry");
 
 __device__ __forceinline__ void front_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -109,25 +109,78 @@ __device__ __forceinline__ unsigned int pack3(float r, float g, float b) {
 // (M * (1 - s) is representable for 2^-22 <= s <= 2^8).
 struct RqF {
     float s_pos, s_neg;      // 2^(lk - sh), neg_mul * 2^-sh
-    float c_pos, c_neg;      // FOLD: M * (1 - s); else M
     float scl;               // !FOLD: 2^shl
 };
 template <bool FOLD>
 __device__ __forceinline__ RqF make_rqf(const Requant &rq) {
     RqF r;
-    // wave-uniform: the two scales live in SGPRs (one constant-bus operand per fma), the addends in VGPRs
+    // wave-uniform: the two scales wait in SGPRs between the phases that use them
     r.s_pos = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, rq.lk - rq.sh))));
     r.s_neg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)rq.neg_mul * ldexpf(1.0f, -rq.sh))));
-    r.c_pos = FOLD ? MAGIC - MAGIC * r.s_pos : MAGIC;
-    r.c_neg = FOLD ? MAGIC - MAGIC * r.s_neg : MAGIC;
     r.scl = ldexpf(1.0f, rq.shl);
     return r;
 }
-// pooled accumulator -> M + rne(t' * 2^-sh), unclamped
+// pooled accumulator -> the two branches of the LeakyReLU, each M + rne(t * scale), unclamped.  y = max(pos, neg) (RNE is
+// monotone: round(max) = max(round)); with 0 <= s_neg <= s_pos (y355_front_eligible): t >= 0 -> pos >= neg >= M, t < 0 ->
+// pos <= neg <= M, so  y > M + 127 <=> pos > M + 127  and  y < M - 127 <=> neg < M - 127.
+// The scales and addends are VGPR operands on purpose: an SGPR source takes a vector instruction off the fast issue path
+// (scratch/ubench/valu_rates.hip: v_fma_f32 3.0 cycles per SIMD with VGPR sources, 4.6 with one SGPR source).
+struct RqV {
+    float sp, sn, cp, cn;    // the scales; the addends: FOLD M * (1 - s), else M
+};
 template <bool FOLD>
-__device__ __forceinline__ float rq_round(int m, float biasf, const RqF &r) {
+__device__ __forceinline__ RqV make_rqv(const RqF &r) {
+    RqV v = {r.s_pos, r.s_neg, FOLD ? MAGIC - MAGIC * r.s_pos : MAGIC, FOLD ? MAGIC - MAGIC * r.s_neg : MAGIC};
+    asm volatile("" : "+v"(v.sp), "+v"(v.sn), "+v"(v.cp), "+v"(v.cn));
+    return v;
+}
+template <bool FOLD>
+__device__ __forceinline__ void rq_pair(int m, float biasf, const RqF &r, const RqV &v, float &pos, float &neg) {
     const float tf = FOLD ? __int_as_float(m) : fmaf((float)m, r.scl, biasf);   // (float)m exact: |t| < 2^24
-    return vmax(fmaf(tf, r.s_pos, r.c_pos), fmaf(tf, r.s_neg, r.c_neg));         // RNE is monotone: round(max) = max(round)
+    pos = fmaf(tf, v.sp, v.cp);
+    neg = fmaf(tf, v.sn, v.cn);
+}
+// byte B of w = bits [7:0] of max(a, b), the other bytes kept (B = 0: zeroed): the LeakyReLU's max and the int8 pack in one
+// SDWA instruction per output (the same issue cost as the plain v_max_f32)
+template <int B>
+__device__ __forceinline__ void max_to_byte(unsigned int &w, float a, float b) {
+    if constexpr (B == 0)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 1)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 2)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+}
+// The epilogue of four pooled accumulators of one lane -> packed int8 word.
+//   hot (CLAMP = false): unclamped low bytes; ymx / ymn track the branches that can leave [-127, 127] (two ops per four outputs each)
+//   CLAMP: clamped bytes; nbad = outputs that were clamped
+template <bool FOLD, bool CLAMP>
+__device__ __forceinline__ unsigned int rq_word(const int (&m)[4], const float (&biasf)[4], const RqF &r, const RqV &v, float &ymx,
+                                                float &ymn, unsigned int &nbad) {
+    float pos[4], neg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rq_pair<FOLD>(m[q], biasf[q], r, v, pos[q], neg[q]);
+    unsigned int w;
+    if constexpr (!CLAMP) {
+        ymx = vmax3(vmax3(ymx, pos[0], pos[1]), pos[2], pos[3]);
+        ymn = vmin3(vmin3(ymn, neg[0], neg[1]), neg[2], neg[3]);
+        max_to_byte<0>(w, pos[0], neg[0]);
+        max_to_byte<1>(w, pos[1], neg[1]);
+        max_to_byte<2>(w, pos[2], neg[2]);
+        max_to_byte<3>(w, pos[3], neg[3]);
+    } else {
+        float yc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float y = vmax(pos[q], neg[q]);
+            yc[q] = __builtin_amdgcn_fmed3f(y, QLO, QHI);
+            nbad += y != yc[q] ? 1u : 0u;
+        }
+        w = pack4(yc[0], yc[1], yc[2], yc[3]);
+    }
+    return w;
 }
 }  // namespace
 
@@ -175,7 +228,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     // Q: wave-item q = wave + 4 k covers patch rows 4 q .. 4 q + 3; lane = 16 * (row in the item) + 4-pixel group j
     // (j = 15 is an idle slot: 15 groups = 60 pixels per row are loaded)
     int qr0 = 4 * wave + g;                            // row of item k: qr0 + 16 k
-    const int qj = li;
+    int qj = li;
     const int G_ = gridDim.x;
     int tile = y355_xcd_remap(blockIdx.x, G_);
     if (tile >= total_tiles) return;
@@ -198,45 +251,50 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     // workgroups per CU: profiles/r03_notes.md; the other workgroups of the CU cover the wait.)
     float4 vf[U8 ? 1 : QITEMS][3];
     uint3 vu[U8 ? QITEMS : 1];
-    auto load_input = [&](int t) {
+    // SAFE: every row / 4-pixel group the loads touch lies inside the image (interior tiles): no clamps, no zero padding
+    auto load_input = [&](int t, auto safec) {
+        constexpr bool SAFE = decltype(safec)::value;
         const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
         const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
+        // wave-uniform bases (SGPR pairs) + 32-bit lane offsets: the loads take the saddr form, no 64-bit vector arithmetic
+        const char *bu8 = (const char *)p.x_u8 + (size_t)b * plane * 3;
+        const char *bf[3] = {(const char *)(p.x + ((size_t)b * 3 + 0) * plane), (const char *)(p.x + ((size_t)b * 3 + 1) * plane),
+                             (const char *)(p.x + ((size_t)b * 3 + 2) * plane)};
 #pragma unroll
         for (int k = 0; k < QITEMS; ++k) {
             const int r = qr0 + 16 * k;
-            const int gy = min(max(y0p + r, 0), H - 1);       // rows / groups past the patch or the image re-read valid data
-            const int gx = min(max(x0p + 4 * qj, 0), W - 4);
-            const size_t o = (size_t)gy * W + gx;
+            int gy = y0p + r, gx = x0p + 4 * qj;
+            if constexpr (!SAFE) {
+                gy = min(max(gy, 0), H - 1);                  // rows / groups past the patch or the image re-read valid data
+                gx = min(max(gx, 0), W - 4);
+            }
+            const unsigned int o = (unsigned int)(gy * W + gx);
             if constexpr (U8) {
-                vu[k] = *(const uint3 *)(p.x_u8 + ((size_t)b * plane + o) * 3);
+                vu[k] = *(const uint3 *)(bu8 + o * 3u);
             } else {
-                const float *xb = p.x + (size_t)b * 3 * plane + o;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) vf[k][c] = *(const float4 *)(xb + c * plane);
+                for (int c = 0; c < 3; ++c) vf[k][c] = *(const float4 *)(bf[c] + o * 4u);
             }
         }
     };
-    using K0 = std::integral_constant<int, 0>;
-    using KN = std::integral_constant<int, QITEMS>;
+    using TT = std::true_type;
+    using FF = std::false_type;
 
-    for (;; tile += G_) {
+    for (int trip = 0;; tile += G_, ++trip) {
         // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
         // out of the tile loop as a loop invariant and held in registers
         int li_ = li, g_ = g, lane_ = lane, tid_ = tid;
-        asm volatile("" : "+v"(qr0), "+v"(li_), "+v"(g_), "+v"(lane_), "+v"(tid_));
+        asm volatile("" : "+v"(qr0), "+v"(qj), "+v"(li_), "+v"(g_), "+v"(lane_), "+v"(tid_));
         int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
         const int b = tile / (p.tiles_x * p.tiles_y);
         const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
         const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
+        // the loads of all QITEMS items (rows y0p .. y0p + 63, columns x0p .. x0p + 63) stay inside the image
+        const bool qsafe = y0p >= 0 && x0p >= 0 && y0p + 16 * QITEMS <= H && x0p + 64 <= W;
         stamp();
 
-        load_input(tile);
-        v4i w1g[U8 ? 4 : 1], b1g;
-        if constexpr (U8) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) w1g[v] = *(const v4i *)(p.wf + v * 1024 + lane_ * 16);
-            b1g = *(const v4i *)(p.bias1 + 4 * g_);
-        }
+        if (qsafe) load_input(tile, TT{});
+        else load_input(tile, FF{});
 #if FRONT_DIAG
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp();
@@ -246,12 +304,15 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
         // Patch column L holds global column x0p + 1 + L: the 4x4 neighbourhood of every conv1 window then starts on an
         // 8-byte boundary (one pixel to the left of the aligned 4-pixel groups the loads use: the fourth word of an
         // LDS group comes from the next lane).
-        auto quantise = [&](auto clampc, auto k0c, auto k1c) {
+        auto quantise = [&](auto clampc, auto safec) {
             constexpr bool CLAMP = decltype(clampc)::value;      // cold: clamp (and count the tile's own clamped values)
+            constexpr bool SAFE = decltype(safec)::value;
             float am = 0.f;
             unsigned int sato = 0;
+            float scv = sc, mg = MAGIC;                          // VGPR operands: the fast issue path of v_fma_f32
+            asm volatile("" : "+v"(scv), "+v"(mg));
 #pragma unroll
-            for (int k = decltype(k0c)::value; k < decltype(k1c)::value; ++k) {
+            for (int k = 0; k < QITEMS; ++k) {
                 const int r = qr0 + 16 * k;
                 unsigned int w[4];
                 if constexpr (U8) {
@@ -275,7 +336,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                         const float xr = px == 0 ? vf[k][0].x : px == 1 ? vf[k][0].y : px == 2 ? vf[k][0].z : vf[k][0].w;
                         const float xg = px == 0 ? vf[k][1].x : px == 1 ? vf[k][1].y : px == 2 ? vf[k][1].z : vf[k][1].w;
                         const float xb = px == 0 ? vf[k][2].x : px == 1 ? vf[k][2].y : px == 2 ? vf[k][2].z : vf[k][2].w;
-                        float yr = fmaf(xr, sc, MAGIC), yg = fmaf(xg, sc, MAGIC), yb = fmaf(xb, sc, MAGIC);
+                        float yr = fmaf(xr, scv, mg), yg = fmaf(xg, scv, mg), yb = fmaf(xb, scv, mg);
                         if constexpr (CLAMP) {
                             yr = __builtin_amdgcn_fmed3f(yr, QLO, QHI);
                             yg = __builtin_amdgcn_fmed3f(yg, QLO, QHI);
@@ -288,10 +349,12 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                     }
                 }
                 const int gy = y0p + r, gx = x0p + 4 * qj;
-                const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                const bool zero = border && !inside;              // pixels outside the image are conv1's zero padding
+                const bool inside = SAFE || ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W);
+                if constexpr (!SAFE) {
+                    const bool zero = border && !inside;          // pixels outside the image are conv1's zero padding
 #pragma unroll
-                for (int px = 0; px < 4; ++px) w[px] = zero ? 0u : w[px];
+                    for (int px = 0; px < 4; ++px) w[px] = zero ? 0u : w[px];
+                }
                 v4i wv;
                 wv[0] = (int)w[1];
                 wv[1] = (int)w[2];
@@ -321,18 +384,20 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
             }
             return U8 ? (sato >> 24) != 0u : !(am < in_thr);          // also true for NaN / Inf inputs
         };
-        if (__builtin_amdgcn_ballot_w64(quantise(std::false_type{}, K0{}, KN{})) != 0ull) {
-            load_input(tile);                                 // cold: the input registers were given up after the hot pass
-            (void)quantise(std::true_type{}, K0{}, KN{});
+        const bool qsat = qsafe ? quantise(FF{}, TT{}) : quantise(FF{}, FF{});
+        if (__builtin_amdgcn_ballot_w64(qsat) != 0ull) {
+            load_input(tile, FF{});                           // cold: the input registers were given up after the hot pass
+            (void)quantise(TT{}, FF{});
         }
         // conv1: weight variant (dy, dx) = v >> 1, v & 1 and the biases as the MFMAs' C operand (accumulator register r of lane
         // (li, g) = channel 4 g + r).  fp32 input: from the copy in LDS (the input registers leave no room to hold them
-        // through Q at 128 registers per lane); uint8 input: from global memory, in flight behind the frame bytes
+        // through Q at 128 registers per lane); uint8 input (the table takes the LDS): from global memory, in flight across
+        // the barrier
         v4i w1[4], b1v;
         if constexpr (U8) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) w1[v] = w1g[v];
-            b1v = b1g;
+            for (int v = 0; v < 4; ++v) w1[v] = *(const v4i *)(p.wf + v * 1024 + lane_ * 16);
+            b1v = *(const v4i *)(p.bias1 + 4 * g_);
         }
         stamp();
         front_lds_barrier();                              // B1: patch complete
@@ -350,101 +415,126 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
             bf1[r] = (float)b1v[r];
         }
 
-        // conv2 fragments [filter row][dx] of n-tile 0 (in flight during C1; n-tile 1's are loaded under the first C2 pass)
-        v4i w2a[3][2];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) w2a[ky][dx] = *(const v4i *)(p.wf + 4096 + (ky * 2 + dx) * 1024 + lane_ * 16);
-        const v4i b2v[2] = {*(const v4i *)(p.bias2 + 8 * g_), *(const v4i *)(p.bias2 + 8 * g_ + 4)};   // channel 8 g + 4 n + r
-        // ---- C1: conv1 + pool1 -> p1.  Group = 16 consecutive windows of the 28 x 28 window grid (row-major);
-        // wave w owns groups w, w + 4, ...  Lane (li, g): window li of the group, neighbourhood row g.
+        // conv2 fragments [n-tile][filter row][dx]: issued behind C1, they land under the barrier (held through C1 they would
+        // take the registers that let two blocks of C1 be in flight)
+        v4i w2[2][3][2];
+        // ---- C1: conv1 + pool1 -> p1.  Group = one 4 x 4 block of the 28 x 28 window grid (7 x 7 blocks).  A wave owns the block
+        // rows wrot and wrot + 4 (wrot = 3: one row only) and walks them left to right: with the row folded into the lane's base
+        // addresses, every block's LDS addresses are base + compile-time immediate -- no address arithmetic per block, vector
+        // or scalar (scalar instructions take issue slots too: scratch/ubench/valu_issue.hip).  wrot rotates with the
+        // workgroup's tile count, so over four tiles every wave (= every SIMD of the CU) computes 49 blocks.
+        // Lane (li, g): window (li >> 2, li & 3) of the block, neighbourhood row g.
         const int gyp0 = 2 * TOY * ty - 1, gxp0 = 2 * TOX * tx - 1;     // pooled coordinates of window (0, 0)
+        const int wrot = (wave + trip) & 3;
+        const int wyl = li_ >> 2, wxl = li_ & 3;
+        const int lsrc = (2 * wyl + g_) * P0 + 2 * wxl + 8 * P0 * wrot;              // dwords into `patch`
+        const int ldst = ((wyl + 4 * wrot) * P1P + wxl) * 16 + 4 * g_;               // bytes into `p1`
         // Passes (COLD = false / true).  FRONT_HOTCOLD: hot = round, pack and write UNCLAMPED, tracking the running max / min of
         // the rounded values (two ops per four outputs); when they leave [-127, 127] (rare) the cold pass rewrites this
-        // wave's groups clamped and counts the tile's own clamped outputs.  Otherwise: hot = clamp + one detect op per
-        // output, cold = count only.
-        auto c1 = [&](auto coldc, auto borderc) {
-            constexpr bool COLD = decltype(coldc)::value, BORDER = decltype(borderc)::value;
+        // wave's blocks clamped and counts the tile's own clamped outputs.  Otherwise: hot = clamp + detect per output,
+        // cold = count only.  Windows outside the image (conv2's zero padding; tiles on the image's edge only) are zeroed by
+        // the wave that wrote them, behind its hot pass.
+        auto c1 = [&](auto coldc) {
+            constexpr bool COLD = decltype(coldc)::value;
             constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
             unsigned int satx = 0;
             float ymx = MAGIC, ymn = MAGIC;
-            auto body = [&](int grp) {
-                const int w = grp * 16 + li_;
-                const int py = (w * 2341) >> 16;                  // w / 28 for w < 784
-                const int px = w - py * P1W;
-                const unsigned int *src = patch + (2 * py + g_) * P0 + 2 * px;
+            const RqV v1 = make_rqv<FOLD>(f1);
+            auto body = [&](int r2, int bx) {                      // hot: compile-time (unrolled); cold: scalars
+                const unsigned int *src = patch + lsrc + (32 * P0 * r2 + 8 * bx);
                 const uint2 lo = *(const uint2 *)src, hi = *(const uint2 *)(src + 2);
                 const v4i bq = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
                 v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[0], bq, cin1, 0, 0, 0);
                 v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[1], bq, cin1, 0, 0, 0);
                 v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[2], bq, cin1, 0, 0, 0);
                 v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[3], bq, cin1, 0, 0, 0);
-                float y[4], yc[4];
+                int m[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = max(max(a0[r], a1[r]), max(a2[r], a3[r]));
-                    y[r] = rq_round<FOLD>(m, bf1[r], f1);
-                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
-                }
-                const bool inimg = !(BORDER || COLD) || ((unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp);
+                for (int r = 0; r < 4; ++r) m[r] = max(max(a0[r], a1[r]), max(a2[r], a3[r]));
+                unsigned int nbad = 0;
+                unsigned int word = rq_word<FOLD, CLAMP>(m, bf1, f1, v1, ymx, ymn, nbad);
                 if constexpr (!COLD) {
-                    if constexpr (FRONT_HOTCOLD) {
-                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
-                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
-                    }
+                    if constexpr (!FRONT_HOTCOLD) satx += nbad;
                 } else {
+                    const int py = 4 * (wrot + 4 * r2) + wyl, px = 4 * bx + wxl;
+                    const bool inimg = (unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp;
                     const bool own = inimg && py >= 1 && py < P1H - 1 && px >= 1 && px < P1W - 1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                    satx += own ? nbad : 0u;
                 }
-                if constexpr (WRITE) {
-                    unsigned int word = pack4(yc[0], yc[1], yc[2], yc[3]);
-                    if constexpr (BORDER || COLD) word = inimg ? word : 0u;   // windows outside the image: conv2's zero padding
-                    *(unsigned int *)(p1 + (py * P1P + px) * 16 + 4 * g_) = word;
-                }
+                if constexpr (WRITE) *(unsigned int *)(p1 + ldst + (16 * P1P * r2 + 4 * bx) * 16) = word;
             };
-            // wave w owns groups w, w + 4, ..., two per trip so that one group's epilogue runs under the other's MFMAs
+            if constexpr (!COLD) {
+                // two blocks between scheduling fences: one block's epilogue runs under the other's MFMAs, and the live ranges
+                // of the straight-line code stay inside the register budget
+#pragma unroll
+                for (int bx = 0; bx < BW1; ++bx) {
+                    body(0, bx);
+                    if (bx & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (wrot + 4 < BH1) {
+#pragma unroll
+                    for (int bx = 0; bx < BW1; ++bx) {
+                        body(1, bx);
+                        if (bx & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
 #pragma unroll 1
-            for (int i = 0; i < NG1 / 8; ++i) {
-                body(wave + 8 * i);
-                body(wave + 8 * i + 4);
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    if (wrot + 4 * r2 >= BH1) break;
+#pragma unroll 1
+                    for (int bx = 0; bx < BW1; ++bx) body(r2, bx);
+                }
             }
-            if (wave < NG1 % 8) body(wave + 8 * (NG1 / 8));
-            static_assert(NG1 % 8 <= 4, "tail groups: at most one per wave");
             if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
             return satx;
         };
-        unsigned int s1 = border ? c1(std::false_type{}, std::true_type{}) : c1(std::false_type{}, std::false_type{});
-        if (__builtin_amdgcn_ballot_w64(s1 != 0) != 0ull) nsat1 += c1(std::true_type{}, std::true_type{});
+        if (__builtin_amdgcn_ballot_w64(c1(FF{}) != 0) != 0ull) nsat1 += c1(TT{});
+        if (border) {
+            // the wave's own windows (block rows wrot, wrot + 4: 8 x 28) that lie outside the image -> zero (same wave, same LDS
+            // queue: ordered behind the writes above)
+            v4i zero4 = {0, 0, 0, 0};
+            asm volatile("" : "+v"(zero4));                        // materialised here, not held across the tile loop
+#pragma unroll 1
+            for (int idx = lane_; idx < 8 * P1W; idx += 64) {
+                const int rl = (idx * 2341) >> 16;                    // idx / 28 for idx < 784
+                const int px = idx - rl * P1W;
+                const int py = 4 * wrot + (rl & 3) + 16 * (rl >> 2);
+                const bool inimg = (unsigned)(gyp0 + py) < (unsigned)Hp && (unsigned)(gxp0 + px) < (unsigned)Wp;
+                if (py < P1H && !inimg) *(v4i *)(p1 + (py * P1P + px) * 16) = zero4;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    w2[n][ky][dx] = *(const v4i *)(p.wf + 4096 + ((3 * n + ky) * 2 + dx) * 1024 + lane_ * 16);
+        const v4i b2v[2] = {*(const v4i *)(p.bias2 + 8 * g_), *(const v4i *)(p.bias2 + 8 * g_ + 4)};   // channel 8 g + 4 n + r
         stamp();
         front_lds_barrier();                              // B2: p1 complete
         stamp();
 
-        // ---- C2: conv2 + pool2 -> staged int8 tile, one pass per n-tile (16 output channels: channel 8 g + 4 n + r in
-        // register r of lane group g).  Group = 16 consecutive windows of the 13 x 13 grid (the last group's padding slots
-        // repeat window 168); k-step t = neighbourhood row t, lane group g = neighbourhood column.
-        v4i w2b[3][2];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) w2b[ky][dx] = *(const v4i *)(p.wf + 4096 + ((3 + ky) * 2 + dx) * 1024 + lane_ * 16);
-        auto c2 = [&](auto coldc, auto nc, const v4i (&w2)[3][2]) {
+        // ---- C2: conv2 + pool2 -> staged int8 tile.  Group = 16 consecutive windows of the 13 x 13 grid (the last group's
+        // padding slots repeat window 168); k-step t = neighbourhood row t, lane group g = neighbourhood column.  One set of LDS
+        // reads feeds both n-tiles (16 output channels each: channel 8 g + 4 n + r in register r of lane group g), whose
+        // eight int8 results leave as one ds_write_b64.
+        auto c2 = [&](auto coldc) {
             constexpr bool COLD = decltype(coldc)::value;
-            constexpr int n = decltype(nc)::value;
             constexpr bool CLAMP = COLD || !FRONT_HOTCOLD, WRITE = !COLD || FRONT_HOTCOLD;
             unsigned int satx = 0;
             float ymx = MAGIC, ymn = MAGIC;
-            v4i cin2;
-            float bf2[4];
+            const RqV v2 = make_rqv<FOLD>(f2);
+            v4i cin2[2];
+            float bf2[2][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                cin2[r] = FOLD ? b2v[n][r] + 0x4B400000 : 0;
-                bf2[r] = (float)b2v[n][r];
-            }
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cin2[n][r] = FOLD ? b2v[n][r] + 0x4B400000 : 0;
+                    bf2[n][r] = (float)b2v[n][r];
+                }
 #pragma unroll 1
             for (int grp = wave; grp < NG2; grp += 4) {
                 const int wraw = grp * 16 + li_;
@@ -452,53 +542,45 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                 const int wy = (w * 5042) >> 16;                  // w / 13 for w < 169
                 const int wx = w - wy * TOX;
                 const char *src = p1 + ((2 * wy) * P1P + 2 * wx + g_) * 16;
-                v4i acc[2][2];                                    // [dy][dx]
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = cin2;
                 v4i bq[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) bq[t] = *(const v4i *)(src + t * P1P * 16);
+                unsigned int word[2];
+                unsigned int nbad = 0;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int n = 0; n < 2; ++n) {
+                    v4i acc[2][2];                                // [dy][dx]
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy) {
-                        const int ky = t - dy;
-                        if (ky < 0 || ky > 2) continue;
+                    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
-                            acc[dy][dx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2[ky][dx], bq[t], acc[dy][dx], 0, 0, 0);
-                    }
-                float y[4], yc[4];
+                        for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = cin2[n];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = max(max(acc[0][0][r], acc[0][1][r]), max(acc[1][0][r], acc[1][1][r]));
-                    y[r] = rq_round<FOLD>(m, bf2[r], f2);
-                    yc[r] = CLAMP ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy) {
+                            const int ky = t - dy;
+                            if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx)
+                                acc[dy][dx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2[n][ky][dx], bq[t], acc[dy][dx], 0, 0, 0);
+                        }
+                    int m[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = max(max(acc[0][0][r], acc[0][1][r]), max(acc[1][0][r], acc[1][1][r]));
+                    word[n] = rq_word<FOLD, CLAMP>(m, bf2[n], f2, v2, ymx, ymn, nbad);
                 }
                 if constexpr (!COLD) {
-                    if constexpr (FRONT_HOTCOLD) {
-                        ymx = vmax3(vmax3(ymx, y[0], y[1]), y[2], y[3]);
-                        ymn = vmin3(vmin3(ymn, y[0], y[1]), y[2], y[3]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) satx += __float_as_uint(y[r]) ^ __float_as_uint(yc[r]);
-                    }
+                    if constexpr (!FRONT_HOTCOLD) satx += nbad;
                 } else {
                     const bool own = wraw < NW2 && TOY * ty + wy < Ho && TOX * tx + wx < Wo;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) satx += (own && y[r] != yc[r]) ? 1u : 0u;
+                    satx += own ? nbad : 0u;
                 }
-                if constexpr (WRITE) *(unsigned int *)(stg + wraw * 32 + 8 * g_ + 4 * n) = pack4(yc[0], yc[1], yc[2], yc[3]);
+                if constexpr (WRITE) *(uint2 *)(stg + wraw * 32 + 8 * g_) = make_uint2(word[0], word[1]);
             }
             if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
             return satx;
         };
-        using N0 = std::integral_constant<int, 0>;
-        using N1 = std::integral_constant<int, 1>;
-        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}, N0{}, w2a) != 0) != 0ull) nsat2 += c2(std::true_type{}, N0{}, w2a);
-        if (__builtin_amdgcn_ballot_w64(c2(std::false_type{}, N1{}, w2b) != 0) != 0ull) nsat2 += c2(std::true_type{}, N1{}, w2b);
+        if (__builtin_amdgcn_ballot_w64(c2(FF{}) != 0) != 0ull) nsat2 += c2(TT{});
         stamp();
         front_lds_barrier();                              // B3: staged tile complete
         stamp();
@@ -562,8 +644,10 @@ void y355_pack_front(const int8_t *q_w1 /*[16][3][3][3]*/, const int8_t *q_w2 /*
 }
 
 // true when the fused launch covers these two layers: 32-bit epilogues whose t stays below 2^24 (exact in fp32)
+// and a LeakyReLU slope in [0, 1] (the epilogue takes max(t * s_pos, t * s_neg) and reads a clamp off the branch that can reach it)
 bool y355_front_eligible(const Requant &rq1, const Requant &rq2) {
-    return !rq1.wide && !rq2.wide && rq1.tmax_log2 <= 24 && rq2.tmax_log2 <= 24;
+    auto slope_ok = [](const Requant &rq) { return rq.neg_mul >= 0 && rq.neg_mul <= (1 << rq.lk); };
+    return !rq1.wide && !rq2.wide && rq1.tmax_log2 <= 24 && rq2.tmax_log2 <= 24 && slope_ok(rq1) && slope_ok(rq2);
 }
 
 void y355_launch_front(const FrontParams &p, hipStream_t s) {
