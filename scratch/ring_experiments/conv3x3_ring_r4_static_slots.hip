@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT (round 4, not in the build): compile-time ring / slab slots (STATIC) when the ring length divides the
+// k-steps of a tile (build with -DY355_RING_PF=4 or 7): 16 fewer scalar / vector instructions per wave and k-step, bit-exact,
+// conv6 31.6 -> 31.5 / 31.3 us: the compiler reschedules the fragment reads right in front of their MFMAs and the gain is gone.
 // yolo355 -- fused int8 3x3 convolution, production kernel for layers with >= 64 input channels
 // (conv3_2 .. conv7, pred): persistent workgroups, LDS-DMA rings with a DEEP weight prefetch.
 //
@@ -135,6 +138,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     static_assert(!(FPE && (DIRECT_REQ || ROLL)), "the fp32 epilogue is written for the staged path and the unrolled chunk loop");
     static_assert(DIRECT || (RP * SSTR <= SLABB && MT % NPASS == 0), "staging fits the dead slot");
     constexpr int UNRC = ROLL ? 1 : NCH;
+    // STATIC: the weight ring and the two slab slots are back at slot 0 when a tile ends (the ring's length divides the tile's
+    // k-steps, the chunk count is even), so in the unrolled loop every LDS slot is a compile-time constant: the scalar
+    // bookkeeping of the ring (compare / select / add per step and wave: ~12 scalar instructions that take issue slots beside
+    // the MFMAs, scratch/ubench/valu_issue.hip) and the vector address of the B fragments disappear.
+    constexpr bool STATIC = !ROLL && KS % WSLOTS == 0 && NCH % 2 == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
 #pragma unroll
         for (int j = 0; j < WPW; ++j) {
             const int f = wave + NW * j;
-            const bool ok = f < NFR;
+            const bool ok = NFR % NW == 0 || f < NFR;             // whole rounds of pieces: no dummy destination, no select
             const int8_t *src = p.w + ((size_t)(nb * KS + ks) * NFR + (ok ? f : 0)) * 1024 + lane * 16;
             char *dst = ok ? smem + OFF_W + slot * WB + f * 1024 : smem + OFF_DUMMY;
             rglds16(src, dst);
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){bv[t], bv[t], bv[t], bv[t]};
         }
         {
-            const char *wb0 = smem + OFF_W + wq * WB + (wn * NT) * 1024 + lane * 16;
+            const char *wb0 = smem + OFF_W + (STATIC ? 0 : wq) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) bfb[0][tt] = *(const v4i *)(wb0 + tt * 1024);
         }
@@ -298,7 +306,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         // (the tile's first chunk, which also sees the previous tile's stores, and the others).
 #pragma unroll UNRC
         for (int c = 0; c < NCH; ++c) {
-            const int soff = sl * SLABB;                        // wave-uniform: one v_add per A read
+            const int slc = STATIC ? (c & 1) : sl;              // slab slot of this chunk
+            const int soff = slc * SLABB;                       // wave-uniform: one v_add per A read (STATIC: an immediate)
             const bool lastc = (c + 1 == NCH);
 #pragma unroll
             for (int t = 0; t < SPC; ++t) {
@@ -348,10 +357,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 if (Y355_DIAG12 && first && c == (NCH > 1 ? 1 : 0)) stamp();
                 // ---- refill: one slab piece (t = 1..PPW) into the slot that died two barriers ago,
                 // W(s+1+PF) into the ring slot read in step s-2
-                const int wqs = wq;
+                const int wqs = STATIC ? s_idx % WSLOTS : wq;
                 {
                     if (t >= 1 && t <= PPW) {
-                        issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
+                        issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, slc ^ 1, t - 1);
                     }
                     const int ksn = s_idx + 1 + PF;
                     const bool nxt = ksn >= KS;
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 const int ko = (t / 3) * PWL * 64;
                 const int acol = t % 3;
                 const int cur = ROLL ? (t & 1) : (s_idx & 1);     // rolled: every chunk starts with its B fragments in bfb[0]
-                wq = wrap(wq + 1);
+                if constexpr (!STATIC) wq = wrap(wq + 1);
                 v4i af[MT];
                 {
                     if (t == 0) {
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) bfb[0][tt] = bfb[1][tt];
             }
-            sl ^= 1;
+            if constexpr (!STATIC) sl ^= 1;
         }
 
         if (Y355_DIAG12 && first) { nstamp = 24; stamp(); }
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
             float ymx = RMAGIC, ymn = RMAGIC;
             unsigned int satx = 0;                              // sum of (clamped ^ unclamped): non-zero iff something saturated
             if (Y355_DIAG12 && first) stamp();
-            char *stg = smem + (sl ^ 1) * SLABB;
+            char *stg = smem + (STATIC ? 1 : (sl ^ 1)) * SLABB;
             const int halo = p.out_halo;
             constexpr int OTW = POOL ? TW / 2 : TW;
             const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;

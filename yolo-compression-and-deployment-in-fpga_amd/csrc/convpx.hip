@@ -60,6 +60,19 @@ __device__ __forceinline__ float pvmin3(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// byte B of w = bits [7:0] of max(a, b), the other bytes kept (B = 0: zeroed): the LeakyReLU's max and the int8 pack in one
+// SDWA instruction per output (front.hip)
+template <int B>
+__device__ __forceinline__ void pmax_to_byte(unsigned int &w, float a, float b) {
+    if constexpr (B == 0)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 1)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 2)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ unsigned int ppack4(float a, float b, float c, float d) {
     const unsigned int ab = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x0c0c0400u);
     const unsigned int cd = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x04000c0cu);
@@ -145,6 +158,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx_kernel(const Con
     const float s_pos = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, rq.lk - rq.sh))));
     const float s_neg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)rq.neg_mul * ldexpf(1.0f, -rq.sh))));
     const float c_pos = FOLD == 2 ? MAGIC - MAGIC * s_pos : MAGIC, c_neg = FOLD == 2 ? MAGIC - MAGIC * s_neg : MAGIC;
+    // VGPR operands for the epilogue's fma: an SGPR source takes a vector instruction off the fast issue path
+    // (scratch/ubench/valu_rates.hip: 3.0 cycles per SIMD against 4.6)
+    float spv = s_pos, snv = s_neg, cpv = c_pos, cnv = c_neg;
+    asm volatile("" : "+v"(spv), "+v"(snv), "+v"(cpv), "+v"(cnv));
     const float scl = ldexpf(1.0f, rq.shl);
     const float invWo = 1.0f / (float)Wo;
 
@@ -331,21 +348,35 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx_kernel(const Con
             unsigned int word[NTN];
 #pragma unroll
             for (int n = 0; n < NTN; ++n) {
-                float y[4], yc[4];
+                // the two branches of the LeakyReLU, each M + rne(t * scale); y = max(pos, neg).  0 <= s_neg <= s_pos (launcher), so
+                // y > M + 127 <=> pos > M + 127 and y < M - 127 <=> neg < M - 127: the hot pass tracks the branches and packs the
+                // unclamped low bytes with one SDWA max per output
+                float pos[4], neg[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int m = acc[0][n][r];
                     if constexpr (POOL) m = max(max(m, acc[1][n][r]), max(acc[2][n][r], acc[3][n][r]));
                     const float tf = FOLD == 2 ? __int_as_float(m) : FOLD == 1 ? (float)m : fmaf((float)m, scl, bf[n][r]);
-                    y[r] = pvmax(fmaf(tf, s_pos, c_pos), fmaf(tf, s_neg, c_neg));
-                    yc[r] = COLD ? __builtin_amdgcn_fmed3f(y[r], QLO, QHI) : y[r];
-                    if constexpr (COLD) nsat += (grp * 16 + li < npw && y[r] != yc[r]) ? 1u : 0u;
+                    pos[r] = fmaf(tf, spv, cpv);
+                    neg[r] = fmaf(tf, snv, cnv);
                 }
                 if constexpr (!COLD) {
-                    ymx = pvmax3(pvmax3(ymx, y[0], y[1]), y[2], y[3]);
-                    ymn = pvmin3(pvmin3(ymn, y[0], y[1]), y[2], y[3]);
+                    ymx = pvmax3(pvmax3(ymx, pos[0], pos[1]), pos[2], pos[3]);
+                    ymn = pvmin3(pvmin3(ymn, neg[0], neg[1]), neg[2], neg[3]);
+                    pmax_to_byte<0>(word[n], pos[0], neg[0]);
+                    pmax_to_byte<1>(word[n], pos[1], neg[1]);
+                    pmax_to_byte<2>(word[n], pos[2], neg[2]);
+                    pmax_to_byte<3>(word[n], pos[3], neg[3]);
+                } else {
+                    float yc[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float y = pvmax(pos[r], neg[r]);
+                        yc[r] = __builtin_amdgcn_fmed3f(y, QLO, QHI);
+                        nsat += (grp * 16 + li < npw && y != yc[r]) ? 1u : 0u;
+                    }
+                    word[n] = ppack4(yc[0], yc[1], yc[2], yc[3]);
                 }
-                word[n] = ppack4(yc[0], yc[1], yc[2], yc[3]);
             }
             // unconditional: the padding lanes rewrite the image's last pixel with the same bytes, and the number of stores a
             // wave has in flight stays a function of its group count (the counted wait above)
@@ -501,6 +532,7 @@ bool y355_pack_px(int kid, const int8_t *q_w, int cout, int cin, int8_t *dst) {
 // map too wide for two slabs in LDS): the caller falls back to the ring / v2 / generic kernels.  `p.w` = y355_pack_px layout.
 bool y355_launch_conv_px(int kid, const ConvParams &p, hipStream_t s) {
     if ((p.mode & 0xff) != 0 || p.rq.wide || p.guard || p.rq.tmax_log2 > 24) return false;
+    if (p.rq.neg_mul < 0 || p.rq.neg_mul > (1 << p.rq.lk)) return false;      // the epilogue assumes a LeakyReLU slope in [0, 1]
     switch (kid) {
     case Y355_K_CONV3_1: return PX_C3_1::launch(p, PX_R31, s);
     case Y355_K_CONV3_2: return PX_C3_2::launch(p, 2, s);
