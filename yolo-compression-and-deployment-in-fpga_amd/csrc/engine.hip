@@ -658,10 +658,20 @@ static int launch_front(y355_engine *h, int B, const float *x_dev) {
     return 0;
 }
 
+// The per-forward reset of the saturation counters as an ordinary kernel launch: hipMemsetAsync's fill goes down the runtime's
+// blit path, and with three handles sharing the GPU every queue sat idle in front of it (profiles/r04_notes.md section 10:
+// the launch-to-launch gap in front of __amd_rocclr_fillBufferAligned was the only gap of the step).
+__global__ void y355_zero_u64_kernel(unsigned long long *p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0ull;
+}
+void y355_zero_counters(Counters *c, int n, hipStream_t s) {
+    hipLaunchKernelGGL(y355_zero_u64_kernel, dim3(1), dim3(64), 0, s, (unsigned long long *)c, n * (int)(sizeof(Counters) / 8));
+}
+
 // enqueue one forward on `s` (refresh_layer must have run)
 static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
                            int32_t *cls_dev, int32_t *count_dev, bool prof) {
-    HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * 10, h->stream));
+    y355_zero_counters(h->ctr_dev, 10, h->stream);
     const int guard = (flags & Y355_F_GUARD) ? 1 : 0;
     // the fused front end covers the 32-bit epilogue without the head-room guard; conv2's packed weights must be the
     // resident-weight layout (one n-block of 32 channels), which they are for this network

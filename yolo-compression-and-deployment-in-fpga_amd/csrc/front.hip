@@ -441,9 +441,12 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
             float ymx = MAGIC, ymn = MAGIC;
             const RqV v1 = make_rqv<FOLD>(f1);
             auto body = [&](int r2, int bx) {                      // hot: compile-time (unrolled); cold: scalars
+                // two ds_read_b64 (2 LDS cycles each, 64 banks, 32-lane groups: conflict-free with P0 = 8 mod 64), not the
+                // ds_read2_b64 the compiler merges plain loads into (8 cycles, 32 banks, 16-lane groups: 2-way conflicts on top)
                 const unsigned int *src = patch + lsrc + (32 * P0 * r2 + 8 * bx);
-                const uint2 lo = *(const uint2 *)src, hi = *(const uint2 *)(src + 2);
-                const v4i bq = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+                typedef const volatile unsigned long long __attribute__((address_space(3))) lds_cv64;
+                const unsigned long long lo = *(lds_cv64 *)src, hi = *(lds_cv64 *)(src + 2);
+                const v4i bq = {(int)(unsigned int)lo, (int)(unsigned int)(lo >> 32), (int)(unsigned int)hi, (int)(unsigned int)(hi >> 32)};
                 v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[0], bq, cin1, 0, 0, 0);
                 v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[1], bq, cin1, 0, 0, 0);
                 v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[2], bq, cin1, 0, 0, 0);

@@ -1191,7 +1191,7 @@ extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int 
     const int nops = h->arch->nops;
     if (!h->bf) {
         if (int rc = refresh_i8(h)) return rc;
-        HIPCHK(hipMemsetAsync(h->ctr_dev, 0, sizeof(Counters) * (nops + 1), h->stream));
+        y355_zero_counters(h->ctr_dev, nops + 1, h->stream);
     }
     // tap forwards (parity tests read every tensor) run the first two layers one by one: the fused launch does not write conv1's map
     const bool fuse_front = h->front_graph && (h->bf || h->front_ok) && !(flags & Y355_F_TAP);

@@ -84,6 +84,8 @@ struct Counters {
     unsigned long long guard; // head-room violations
 };
 
+void y355_zero_counters(Counters *c, int n, hipStream_t s);   // engine.hip: a kernel launch, not hipMemsetAsync
+
 struct ConvParams {
     const int8_t *in;     // int8 NHWC with halo  [B][H+2][W+2][CIN]
     int8_t *out;          // int8 NHWC [B][Ho+2h][Wo+2h][cstride]
