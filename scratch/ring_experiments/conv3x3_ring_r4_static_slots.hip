@@ -283,6 +283,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         // W(1..PF), the slab pieces issued with them, and the previous tile's NIT output stores.
         v4i bfb[2][NT];
         v4i afp[2];
+#ifdef Y355_RING_SGB
+        v4i afq[MT];                                           // the next step's A fragments 2 .. MT-1 (0, 1: afp)
+#endif
         if (first) rwait_vmcnt<PF * WPW>();
         else rwait_vmcnt<PF * WPW + ring_sp(-PF, -1, PPW, true) + NIT>();
         __builtin_amdgcn_s_barrier();
@@ -379,6 +382,49 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                         af[0] = afp[0];
                         if constexpr (MT > 1) af[1] = afp[1];
                     }
+#ifdef Y355_RING_SGB
+                    // pinned order: every operand of this step is in registers when its MFMAs start (the whole next step's A
+                    // and B fragments are read under this step's MFMAs, two reads per m-tile); only a chunk's first step reads
+                    // its A fragments in front of the MFMAs (the slab is published by that step's barrier)
+                    if (t == 0) {
+#pragma unroll
+                        for (int m = 2; m < MT; ++m) af[m] = *(const v4i *)(smem + abase[m][acol] + soff + ko);
+                    } else {
+#pragma unroll
+                        for (int m = 2; m < MT; ++m) af[m] = afq[m];
+                    }
+                    auto mf = [&](int m) {
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                    };
+                    constexpr int RDPM = (NT + MT + MT - 1) / MT;      // reads per m-tile
+                    const int ko2 = ((t + 1) / 3) * PWL * 64;
+                    const int acol2 = (t + 1) % 3;
+                    const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        mf(m);
+                        // this m-tile's share of the next step's list of reads: B0 .. B3, A0 .. A(MT-1)
+#pragma unroll
+                        for (int k = RDPM * m; k < RDPM * m + RDPM; ++k) {
+                            if (k < NT) {
+                                if (s_idx + 1 < KS) bfb[cur ^ 1][k] = *(const v4i *)(wbn + k * 1024);
+                            } else if (k - NT < MT && t + 1 < SPC) {
+                                const int ma = k - NT;
+                                const v4i v = *(const v4i *)(smem + abase[ma][acol2] + soff + ko2);
+                                if (ma < 2) afp[ma] = v;
+                                else afq[ma] = v;
+                            }
+                        }
+                    }
+                    if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, RDPM, 0);
+                    }
+#else
                     if (s_idx + 1 < KS) {                            // B fragments of step s+1, under this step's MFMAs
                         const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
@@ -397,6 +443,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                         for (int tt = 0; tt < NT; ++tt)
                             acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
                     }
+#endif
                 }
             }
             // 9 steps: the last one (cur = 0) read the next chunk's first fragments into bfb[1]

@@ -25,7 +25,7 @@
 #define Y355_DIAG12 (Y355_DIAG == 1 || Y355_DIAG == 2)
 #endif
 #ifndef Y355_RING_PF
-#define Y355_RING_PF 5              // k-steps of weights in flight (ring of PF + 2 slots); 4..7 measured equal (profiles/r02_notes.md)
+#define Y355_RING_PF 4              // k-steps of weights in flight (ring of PF + 2 = 6 slots: divides the 18 / 36 k-steps of the deep layers' tiles, which makes every slot a compile-time constant -- STATIC below); 4..7 measured equal before that (profiles/r02_notes.md)
 #endif
 // The timing ablations, the hand-placed (volatile asm) k-step, the row-dependent chunk swizzle, the refill-position and
 // half-tile variants of round 2 live in scratch/ring_experiments/conv3x3_ring_r2_experiments.hip; none of them paid
@@ -135,6 +135,13 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     static_assert(!(FPE && (DIRECT_REQ || ROLL)), "the fp32 epilogue is written for the staged path and the unrolled chunk loop");
     static_assert(DIRECT || (RP * SSTR <= SLABB && MT % NPASS == 0), "staging fits the dead slot");
     constexpr int UNRC = ROLL ? 1 : NCH;
+    // STATIC: the weight ring and the two slab slots are back at slot 0 when a tile ends (the ring's length divides the tile's
+    // k-steps, the chunk count is even), so in the unrolled loop every LDS slot is a compile-time constant: the scalar
+    // bookkeeping of the ring (compare / select / add: ~12 scalar instructions per step and wave, which take issue slots beside
+    // the MFMAs: scratch/ubench/valu_issue.hip) and the vector address of the B fragments disappear -- 46 instead of 62
+    // instructions per wave and k-step.  The order of what is left is pinned (sched_group_barrier below): left to itself the
+    // scheduler moves each fragment read in front of the MFMAs that use it and the gain is gone (profiles/r04_notes.md 11).
+    constexpr bool STATIC = !ROLL && KS % WSLOTS == 0 && NCH % 2 == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
 #pragma unroll
         for (int j = 0; j < WPW; ++j) {
             const int f = wave + NW * j;
-            const bool ok = f < NFR;
+            const bool ok = NFR % NW == 0 || f < NFR;             // whole rounds of pieces: no dummy destination, no select
             const int8_t *src = p.w + ((size_t)(nb * KS + ks) * NFR + (ok ? f : 0)) * 1024 + lane * 16;
             char *dst = ok ? smem + OFF_W + slot * WB + f * 1024 : smem + OFF_DUMMY;
             rglds16(src, dst);
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 for (int t = 0; t < NT; ++t) acc[m][t] = (v4i){bv[t], bv[t], bv[t], bv[t]};
         }
         {
-            const char *wb0 = smem + OFF_W + wq * WB + (wn * NT) * 1024 + lane * 16;
+            const char *wb0 = smem + OFF_W + (STATIC ? 0 : wq) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) bfb[0][tt] = *(const v4i *)(wb0 + tt * 1024);
         }
@@ -298,7 +305,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
         // (the tile's first chunk, which also sees the previous tile's stores, and the others).
 #pragma unroll UNRC
         for (int c = 0; c < NCH; ++c) {
-            const int soff = sl * SLABB;                        // wave-uniform: one v_add per A read
+            const int slc = STATIC ? (c & 1) : sl;              // slab slot of this chunk
+            const int soff = slc * SLABB;                       // wave-uniform: one v_add per A read (STATIC: an immediate)
             const bool lastc = (c + 1 == NCH);
 #pragma unroll
             for (int t = 0; t < SPC; ++t) {
@@ -348,10 +356,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 if (Y355_DIAG12 && first && c == (NCH > 1 ? 1 : 0)) stamp();
                 // ---- refill: one slab piece (t = 1..PPW) into the slot that died two barriers ago,
                 // W(s+1+PF) into the ring slot read in step s-2
-                const int wqs = wq;
+                const int wqs = STATIC ? s_idx % WSLOTS : wq;
                 {
                     if (t >= 1 && t <= PPW) {
-                        issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
+                        issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, slc ^ 1, t - 1);
                     }
                     const int ksn = s_idx + 1 + PF;
                     const bool nxt = ksn >= KS;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 const int ko = (t / 3) * PWL * 64;
                 const int acol = t % 3;
                 const int cur = ROLL ? (t & 1) : (s_idx & 1);     // rolled: every chunk starts with its B fragments in bfb[0]
-                wq = wrap(wq + 1);
+                if constexpr (!STATIC) wq = wrap(wq + 1);
                 v4i af[MT];
                 {
                     if (t == 0) {
@@ -370,6 +378,40 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                         af[0] = afp[0];
                         if constexpr (MT > 1) af[1] = afp[1];
                     }
+                    if constexpr (STATIC) {
+                        // pinned order: this step's remaining A fragments, the MFMAs of the two m-tiles whose fragments are
+                        // already here, then the next step's B fragments and first A fragments two reads per m-tile
+#pragma unroll
+                        for (int m = 2; m < MT; ++m) af[m] = *(const v4i *)(smem + abase[m][acol] + soff + ko);
+                        auto mf = [&](int m) {
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt)
+                                acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
+                        };
+                        mf(0);
+                        if constexpr (MT > 1) mf(1);
+                        if (s_idx + 1 < KS) {
+                            const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
+                        }
+                        if (t + 1 < SPC) {
+                            const int ko2 = ((t + 1) / 3) * PWL * 64;
+                            const int acol2 = (t + 1) % 3;
+                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                        }
+#pragma unroll
+                        for (int m = 2; m < MT; ++m) mf(m);
+                        if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, MT - 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+#pragma unroll
+                        for (int m = 2; m < MT; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                        }
+                    } else {
                     if (s_idx + 1 < KS) {                            // B fragments of step s+1, under this step's MFMAs
                         const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
@@ -388,6 +430,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                         for (int tt = 0; tt < NT; ++tt)
                             acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
                     }
+                    }
                 }
             }
             // 9 steps: the last one (cur = 0) read the next chunk's first fragments into bfb[1]
@@ -395,7 +438,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) bfb[0][tt] = bfb[1][tt];
             }
-            sl ^= 1;
+            if constexpr (!STATIC) sl ^= 1;
         }
 
         if (Y355_DIAG12 && first) { nstamp = 24; stamp(); }
@@ -448,7 +491,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
             float ymx = RMAGIC, ymn = RMAGIC;
             unsigned int satx = 0;                              // sum of (clamped ^ unclamped): non-zero iff something saturated
             if (Y355_DIAG12 && first) stamp();
-            char *stg = smem + (sl ^ 1) * SLABB;
+            char *stg = smem + (STATIC ? 1 : (sl ^ 1)) * SLABB;
             const int halo = p.out_halo;
             constexpr int OTW = POOL ? TW / 2 : TW;
             const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
