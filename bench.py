@@ -38,7 +38,7 @@ PEAK_I8_DENSE = 5.0e15                          # MI355X dense int8 MFMA (2x bf1
 LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7", "pred"]
 
 
-DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 5, false, false"   # prefix: the last template argument selects the epilogue (true = fp32)
+DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 4, false, false"   # prefix: the last template argument selects the epilogue (true = fp32)
 
 
 TRAFFIC_FILES = ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first

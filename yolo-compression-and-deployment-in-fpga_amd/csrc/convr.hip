@@ -51,7 +51,7 @@ constexpr int fring_sp(int lo, int hi, int ppw, bool prev) {
     }
     return n;
 }
-constexpr int PF = 5;
+constexpr int PF = 4;        // ring of PF + 2 = 6 weight slots: divides the k-steps of every multi-chunk layer here (STATIC below)
 }  // namespace
 
 // CINB = bytes per input pixel (a multiple of 64), BN output channels per workgroup
@@ -78,6 +78,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
     constexpr int OFF_DUMMY = OFF_W + WSLOTS * WB;
     constexpr int NIT = POOL ? MT : MT * 4;                        // output stores per thread per tile (static)
     static_assert(CINB % 64 == 0 && NT == 4 && NW == 8, "64-byte chunks, four n-tiles per wave, eight waves");
+    // STATIC (conv3x3_ring.hip): ring and slab slots are compile-time constants of the unrolled loop when the ring's length divides
+    // the tile's k-steps and the chunk count is even; the k-step's read / MFMA order is pinned below
+    constexpr bool STATIC = KS % WSLOTS == 0 && NCH % 2 == 0;
     static_assert(PPW <= 8, "slab pieces go out at t = 1..PPW");
     static_assert((NW * 16) % PWL == 0 && NPIX % 16 == 0, "slab pieces step by whole patch rows");
     static_assert(!POOL || (TH % 2 == 0 && TW % 2 == 0), "pooled tiles are even");
@@ -189,13 +192,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
         else fwait_vmcnt_dyn(PF * WPW + fring_sp(-PF, -1, PPW, true) + NIT);
         __builtin_amdgcn_s_barrier();
         {
-            const char *wb0 = smem + OFF_W + wq * WB + (wn * NT) * 1024 + lane * 16;
+            const char *wb0 = smem + OFF_W + (STATIC ? 0 : wq) * WB + (wn * NT) * 1024 + lane * 16;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) bfb[0][tt] = *(const v4i *)(wb0 + tt * 1024);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int soff = sl * SLABB;
+            const int slc = STATIC ? (c & 1) : sl;
+            const int soff = slc * SLABB;
             const bool lastc = (c + 1 == NCH);
 #pragma unroll
             for (int t = 0; t < SPC; ++t) {
@@ -218,10 +222,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
                 __builtin_amdgcn_s_barrier();
                 // refill: one slab piece (t = 1..PPW) into the slot that died two barriers ago, W(s+1+PF) into the ring slot
                 // read in step s-2
-                const int wqs = wq;
+                const int wqs = STATIC ? s_idx % WSLOTS : wq;
                 {
                     if (t >= 1 && t <= PPW)
-                        issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, sl ^ 1, t - 1);
+                        issue_slab_piece(lastc ? b2 : b, lastc ? y2 : y0, lastc ? x2 : x0, lastc ? 0 : c + 1, slc ^ 1, t - 1);
                     const int ksn = s_idx + 1 + PF;
                     const bool nxt = ksn >= KS;
                     issue_w(nxt ? nb2 : nb, nxt ? ksn - KS : ksn, wrap(wqs + PF + 1));
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
                 const int ko = (t / 3) * PWL * 64;
                 const int acol = t % 3;
                 const int cur = s_idx & 1;
-                wq = wrap(wq + 1);
+                if constexpr (!STATIC) wq = wrap(wq + 1);
                 v4i af[MT];
                 if (t == 0) {
                     af[0] = *(const v4i *)(smem + abase[0][acol] + soff + ko);
@@ -238,20 +242,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
                     af[0] = afp[0];
                     if constexpr (MT > 1) af[1] = afp[1];
                 }
-                if (s_idx + 1 < KS) {                            // B fragments of step s+1, under this step's MFMAs
-                    const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
-                    if (m == MT - 1 && t + 1 < SPC) {            // next step's first A fragments (same slab)
-                        const int ko2 = ((t + 1) / 3) * PWL * 64;
-                        const int acol2 = (t + 1) % 3;
-                        afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
-                        if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
-                    }
+                auto mf = [&](int m) {
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) {
                         if constexpr (BF)
@@ -260,9 +251,66 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
                         else
                             acc[m][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[m], bfb[cur][tt], acc[m][tt], 0, 0, 0);
                     }
+                };
+                if constexpr (STATIC) {
+                    // pinned order (conv3x3_ring.hip): this step's remaining A fragments, the MFMAs of the two m-tiles whose
+                    // fragments are already here, then the next step's B fragments and first A fragments two reads per m-tile.
+                    // Plain scheduling fences between the groups: the sched_group_barrier pipelines of conv3x3_ring.hip take the
+                    // compiler tens of minutes on this file's 72- and 144-step loops.
+#pragma unroll
+                    for (int m = 2; m < MT; ++m) af[m] = *(const v4i *)(smem + abase[m][acol] + soff + ko);
+                    mf(0);
+                    if constexpr (MT > 1) mf(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
+                    const int ko2 = ((t + 1) / 3) * PWL * 64;
+                    const int acol2 = (t + 1) % 3;
+                    constexpr int RDPM = MT > 2 ? (NT + 2 + MT - 3) / (MT - 2) : 0;   // reads per m-tile behind the first two
+#pragma unroll
+                    for (int m = 2; m < MT; ++m) {
+                        // this m-tile's share of the next step's list of reads: B0 .. B3, A0, A1
+#pragma unroll
+                        for (int k = RDPM * (m - 2); k < RDPM * (m - 2) + RDPM; ++k) {
+                            if (k < NT) {
+                                if (s_idx + 1 < KS) bfb[cur ^ 1][k] = *(const v4i *)(wbn + k * 1024);
+                            } else if (k - NT < 2 && k - NT < MT && t + 1 < SPC) {
+                                afp[k - NT] = *(const v4i *)(smem + abase[k - NT][acol2] + soff + ko2);
+                            }
+                        }
+                        mf(m);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+
+                    if constexpr (MT <= 2) {                          // no m-tile behind the first two: the reads go out here
+                        if (s_idx + 1 < KS) {
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
+                        }
+                        if (t + 1 < SPC) {
+                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                        }
+                    }
+                } else {
+                    if (s_idx + 1 < KS) {                        // B fragments of step s+1, under this step's MFMAs
+                        const char *wbn = smem + OFF_W + wrap(wqs + 1) * WB + (wn * NT) * 1024 + lane * 16;
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) bfb[cur ^ 1][tt] = *(const v4i *)(wbn + tt * 1024);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        if (m + 2 < MT) af[m + 2] = *(const v4i *)(smem + abase[m + 2][acol] + soff + ko);
+                        if (m == MT - 1 && t + 1 < SPC) {        // next step's first A fragments (same slab)
+                            const int ko2 = ((t + 1) / 3) * PWL * 64;
+                            const int acol2 = (t + 1) % 3;
+                            afp[0] = *(const v4i *)(smem + abase[0][acol2] + soff + ko2);
+                            if constexpr (MT > 1) afp[1] = *(const v4i *)(smem + abase[1][acol2] + soff + ko2);
+                        }
+                        mf(m);
+                    }
                 }
             }
-            sl ^= 1;
+            if constexpr (!STATIC) sl ^= 1;
         }
 
         // ---- epilogue straight from the registers (convg.hip's arithmetic, expression for expression)
