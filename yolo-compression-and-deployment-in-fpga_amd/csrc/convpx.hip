@@ -186,26 +186,45 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx_kernel(const Con
     constexpr int CPX = PXB / 16;                        // 16-byte chunks per pixel
     const int dpx = lane / CPX, dch = lane % CPX;
     const int ppr = PWL / PPP;                           // pieces per row
-    // pieces [q, q + NW, ...) < npiece of rows r0 ..: at most `count` of them; (rr, pc) = (q / ppr, q % ppr) travel with the cursor
-    struct Cursor { int q, rr, pc; };
-    auto cursor_at = [&](int q) { Cursor c; c.q = q; c.rr = q / ppr; c.pc = q - c.rr * ppr; return c; };
-    auto issue_pieces = [&](int r0, int npiece, Cursor &c, int count) {
+    // Who sends which piece: a wave owns ONE piece column pc0 (its lanes' pixel, swizzled chunk and byte offset inside a row are
+    // launch constants) and every RS-th row of it -- ppr <= NW: NW / ppr rows per round of the waves (the waves beyond RS * ppr
+    // send nothing); wider rows: every row, the columns pc0, pc0 + NW, ...  A piece then costs one scalar multiply-add for the
+    // row's offsets and the DMA (before: a (row, column) cursor with a wrap loop, ~17 scalar and 6 vector instructions per
+    // piece, 900 - 1 600 scalar instructions per wave and launch: profiles/r04_notes.md 13).
+    const int RS = ppr < NW ? NW / ppr : 1;
+    const int CPW = ppr < NW ? 1 : (ppr + NW - 1) / NW;
+    const int pc0 = ppr < NW ? wave % ppr : wave;
+    const int rr0 = ppr < NW ? (wave / ppr < RS ? wave / ppr : (1 << 28)) : 0;
+    auto lane_off = [&](int pc) {                        // byte offset of this lane's 16 bytes inside a padded input row
+        const int col = pc * PPP + dpx;
+        int sch = dch;
+        if constexpr (CPX == 4) sch ^= ((col >> 2) & 1) << 1;
+        if constexpr (CPX == 8) sch ^= ((col >> 1) & 3) << 1;
+        return min(col, PW - 1) * PXB + 16 * sch;
+    };
+    const int goff0 = lane_off(pc0);
+    // rows r0 + rr, rr = cursor, cursor + RS, ... < nrows: at most about `count` pieces; the cursor travels with the caller
+    auto issue_pieces = [&](int r0, int nrows, int &rr, int count) {
         int done = 0;
-        for (; c.q < npiece && done < count; ++done) {
-            const int row = r0 + c.rr, col = c.pc * PPP + dpx;
-            int sch = dch;
-            if constexpr (CPX == 4) sch ^= ((col >> 2) & 1) << 1;
-            if constexpr (CPX == 8) sch ^= ((col >> 1) & 3) << 1;
-            pglds16(p.in + ((row * PW + min(col, PW - 1)) * PXB + 16 * sch), smem + (row & RM) * rowb + c.pc * 1024);
-            c.q += NW;
-            c.pc += NW;
-            while (c.pc >= ppr) { c.pc -= ppr; ++c.rr; }
+        for (; rr < nrows && done < count; rr += RS) {
+            const int row = r0 + rr;
+            const int8_t *src = p.in + (size_t)row * (size_t)(PW * PXB);
+            char *dst = smem + (row & RM) * rowb;
+            pglds16(src + goff0, dst + pc0 * 1024);
+            ++done;
+            for (int j = 1; j < CPW; ++j) {              // rows wider than NW pieces (not the shapes of this network)
+                const int pc = pc0 + j * NW;
+                if (pc < ppr) {
+                    pglds16(src + lane_off(pc), dst + pc * 1024);
+                    ++done;
+                }
+            }
         }
         return done;
     };
     auto issue_rows = [&](int r0, int r1) {
-        Cursor c = cursor_at(wave);
-        issue_pieces(r0, (r1 - r0) * ppr, c, 1 << 30);
+        int rr = rr0;
+        issue_pieces(r0, r1 - r0, rr, 1 << 30);
     };
 
     int nstamp = 0;
@@ -247,18 +266,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx_kernel(const Con
         // the next chunk's new rows, as far as they fit beside the rows this chunk still reads, go out a few pieces at a time
         // behind each group's MFMAs (the SIMD's other wave computes while this one issues); the chunk boundary may leave in
         // flight only the stores issued after the LAST piece
-        int pf_r0 = 0, pf_np = 0;
+        int pf_r0 = 0, pf_nr = 0;
         if (more) {
             const int top = min(nx.hi, ch.lo + R);
             pf_r0 = max(loaded, nx.lo);
             if (top > pf_r0) {
-                pf_np = (top - pf_r0) * ppr;
+                pf_nr = top - pf_r0;
                 loaded = top;
             }
         }
-        Cursor pfc = cursor_at(wave);
+        int pfc = rr0;
         auto prefetch = [&](int count) {
-            if (issue_pieces(pf_r0, pf_np, pfc, count) > 0) nstores = 0;
+            if (issue_pieces(pf_r0, pf_nr, pfc, count) > 0) nstores = 0;
         };
         stamp();
         int8_t *outb = p.out + (((size_t)ch.b * (Ho + 2) + 1) * (Wo + 2) + 1) * COUT + cb * CPB;    // wave-uniform
@@ -458,7 +477,8 @@ struct PxInst {
         while ((1 << a.logr) < need) ++a.logr;
         // a chunk adds about MUL * 16 cg / Wo rows = that many * pwl / PPP pieces, dealt over NW waves and `rounds` groups each
         const int newrows = (POOL ? 2 : 1) * ((16 * a.cg + Wo - 1) / Wo + 1);
-        const int per_wave = (newrows * (a.pwl / G::PPP) + NW - 1) / NW;
+        const int ppr = a.pwl / G::PPP, rs = ppr < NW ? NW / ppr : 1, cpw = ppr < NW ? 1 : (ppr + NW - 1) / NW;
+        const int per_wave = (newrows + rs - 1) / rs * cpw;         // a wave sends one piece column of every rs-th row
         a.ppg = (per_wave + rounds - 1) / rounds;
         return a;
     }
