@@ -1,6 +1,7 @@
-// ARCHIVED EXPERIMENT (round 4, not in the build): compile-time ring / slab slots (STATIC) when the ring length divides the
-// k-steps of a tile (build with -DY355_RING_PF=4 or 7): 16 fewer scalar / vector instructions per wave and k-step, bit-exact,
-// conv6 31.6 -> 31.5 / 31.3 us: the compiler reschedules the fragment reads right in front of their MFMAs and the gain is gone.
+// ARCHIVED EXPERIMENT (round 4, not in the build): the exploration behind the production kernel's compile-time ring / slab slots.
+//   -DY355_RING_PF=4 (or 7): STATIC alone -- 16 fewer scalar / vector instructions per wave and k-step, conv6 31.6 -> 31.5 / 31.3 us: the compiler
+//   moves every fragment read right in front of its MFMAs.  -DY355_RING_SGB on top: the WHOLE next step's A and B fragments are read under the current
+//   step's MFMAs (244 VGPRs): 29.7 us, no better than the pinned order that went into production (this step's A fragments, eight MFMAs, two reads per m-tile: 29.4).
 // yolo355 -- fused int8 3x3 convolution, production kernel for layers with >= 64 input channels
 // (conv3_2 .. conv7, pred): persistent workgroups, LDS-DMA rings with a DEEP weight prefetch.
 //
