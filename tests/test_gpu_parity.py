@@ -317,7 +317,7 @@ def test_forward_frames_equals_normalised_tensor():
 
 
 @pytest.mark.parametrize("H,W,B,gain", [(416, 416, 3, 1.0), (96, 96, 2, 1.0), (320, 416, 2, 1.0), (240, 320, 2, 1.6),
-                                         (112, 64, 1, 2.5)])
+                                         (112, 64, 1, 2.5), (320, 608, 1, 1.0)])   # W = 608: input rows wider than 8 DMA pieces (convpx)
 def test_fused_front_end_equals_layer_launches(H, W, B, gain):
     """conv1 + pool1 + conv2 + pool2 as ONE launch (csrc/front.hip, the default) against the oracle's conv2 map and against
     the one-launch-per-layer route: identical int8 maps, detections and saturation counters; fp32 tensors and uint8 frames;
