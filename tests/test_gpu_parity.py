@@ -316,8 +316,40 @@ def test_forward_frames_equals_normalised_tensor():
     eng.close()
 
 
+def test_deep_layers_clamp_on_the_ring_kernels():
+    """The deep layers' fp32 epilogue (csrc/conv3x3_ring.hip) stages unclamped bytes in its hot pass and re-stages a tile
+    clamped when a value left [-127, 127]: with the output exponents of conv5 .. pred raised by two (every activation four
+    times larger) the maps, the prediction and the per-layer saturation counts must still equal the oracle's."""
+    H = W = 416
+    B = 2
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2, pred_gain=400.0, obj_bias=-4.0))
+    eng = Engine([H, W], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+    eng.load_quantized(ql)
+    frames = synth.make_frames_u8(11, B, H, W, "blocks")
+    xc = synth.normalize_frames(frames)[:1]
+    eng.calibrate(xc, [RangeTracker() for _ in range(11)])
+    otr = [O.RangeTracker() for _ in range(11)]
+    O.detect(xc, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2)
+    sa = list(eng.get_act_exponents())
+    for k in (7, 8, 9, 10):                      # trackers behind conv5, conv6, conv7, pred
+        sa[k] += 2
+        otr[k].scale = otr[k].scale * 4
+    eng.set_act_exponents(sa)
+    x = synth.normalize_frames(frames)
+    r = O.detect(x, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2, saturate=True, keep=True)
+    assert list(r["sa"]) == sa
+    eng.forward(x)
+    sat = [eng.layer_stats(k)["saturated"] for k in range(10)]
+    assert sat == list(r["sat_out"]), (sat, r["sat_out"])
+    assert min(sat[6:10]) > 0, "the fixture must clamp in every ring-kernel layer"
+    for k in (6, 7, 8):
+        assert np.array_equal(eng.get_feature(k, B), r["maps"][k].astype(np.int8)), "layer %d" % k
+    assert np.array_equal(eng.get_feature(9, B), r["pred_q"].astype(np.int8))
+    eng.close()
+
+
 @pytest.mark.parametrize("H,W,B,gain", [(416, 416, 3, 1.0), (96, 96, 2, 1.0), (320, 416, 2, 1.0), (240, 320, 2, 1.6),
-                                         (112, 64, 1, 2.5), (320, 608, 1, 1.0)])   # W = 608: input rows wider than 8 DMA pieces (convpx)
+                                         (112, 64, 1, 2.5), (320, 608, 1, 1.0), (416, 416, 2, 3.0)])   # W = 608: input rows wider than 8 DMA pieces (convpx)
 def test_fused_front_end_equals_layer_launches(H, W, B, gain):
     """conv1 + pool1 + conv2 + pool2 as ONE launch (csrc/front.hip, the default) against the oracle's conv2 map and against
     the one-launch-per-layer route: identical int8 maps, detections and saturation counters; fp32 tensors and uint8 frames;

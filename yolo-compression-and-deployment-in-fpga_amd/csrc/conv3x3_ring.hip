@@ -16,6 +16,7 @@
 //     slot that just died (in two passes where it is larger than a slot), not in its own buffer.
 // Same math, tile geometry, weight packing and epilogue arithmetic as conv3x3.hip.
 #include "y355_common.h"
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #ifndef Y355_DIAG
@@ -57,6 +58,18 @@ __device__ __forceinline__ float rvmin3(float a, float b, float c) {
     float d;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
+}
+// byte B of w = bits [7:0] of max(a, b), the other bytes kept (B = 0: zeroed) -- front.hip
+template <int B>
+__device__ __forceinline__ void rmax_to_byte(unsigned int &w, float a, float b) {
+    if constexpr (B == 0)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 1)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 2)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ unsigned int rpack4(float a, float b, float c, float d) {   // low bytes of four floats M + q
     const unsigned int ab = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x0c0c0400u);
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 const float tf = (float)(v + biasf[t]);
                 pos = fmaf(tf, spv, mgv);
                 neg = fmaf(tf, snv, mgv);
-                return rvmax(pos, neg);
+                return 0.f;
             };
             float ymx = RMAGIC, ymn = RMAGIC;
             unsigned int satx = 0;                              // sum of (clamped ^ unclamped): non-zero iff something saturated
@@ -537,44 +550,62 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                 // both passes); local row = (wm*MH + m - ps*MH) * RPMT + (row inside the m-tile)
                 constexpr int MH = MT / NPASS;
                 constexpr int RPMT = POOL ? 4 : 16;                 // staged rows per m-tile
+                // FPE: the hot pass stages UNCLAMPED low bytes (the LeakyReLU's max writes its byte straight into the packed word:
+                // SDWA, no med3 / pack) and tracks the two branches; when one left [-127, 127] (rare) this wave stages the pass
+                // again, clamped, before the barrier -- same rows, no store: the counted waits see the same operations
+                auto stage = [&](auto clampc) {
+                    constexpr bool CL = decltype(clampc)::value;
 #pragma unroll
-                for (int mm = 0; mm < MH; ++mm) {
-                    const int m = ps * MH + mm;
+                    for (int mm = 0; mm < MH; ++mm) {
+                        const int m = ps * MH + mm;
 #pragma unroll
-                    for (int r = 0; r < RPM; ++r) {
-                        const int lrow = POOL ? (wm * MH + mm) * 4 + g : (wm * MH + mm) * 16 + 4 * g + r;
-                        unsigned int w = 0;
-                        float yq[NT], ypos[NT], yneg[NT];
+                        for (int r = 0; r < RPM; ++r) {
+                            const int lrow = POOL ? (wm * MH + mm) * 4 + g : (wm * MH + mm) * 16 + 4 * g + r;
+                            unsigned int w = 0;
+                            float yq[NT], ypos[NT], yneg[NT];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            int v;
-                            if constexpr (POOL) {
-                                const v4i a = acc[m][t];
-                                v = max(max(a[0], a[1]), max(a[2], a[3]));
-                            } else {
-                                v = acc[m][t][r];
+                            for (int t = 0; t < NT; ++t) {
+                                int v;
+                                if constexpr (POOL) {
+                                    const v4i a = acc[m][t];
+                                    v = max(max(a[0], a[1]), max(a[2], a[3]));
+                                } else {
+                                    v = acc[m][t][r];
+                                }
+                                if constexpr (FPE) {
+                                    if constexpr (CL) asm volatile("" : "+v"(v));      // recomputed here: nothing of the hot pass stays live
+                                    yq[t] = requantf(v, t, ypos[t], yneg[t]);
+                                } else {
+                                    const int qq = requant(v, t);
+                                    const int q = y355_clamp8<int>(qq);
+                                    satx += (unsigned int)(q ^ qq);     // v_xad_u32; the exact count is taken below, rarely
+                                    w |= (unsigned int)(q & 0xff) << (8 * t);
+                                }
                             }
                             if constexpr (FPE) {
-                                yq[t] = requantf(v, t, ypos[t], yneg[t]);
-                            } else {
-                                const int qq = requant(v, t);
-                                const int q = y355_clamp8<int>(qq);
-                                satx += (unsigned int)(q ^ qq);     // v_xad_u32; the exact count is taken below, rarely
-                                w |= (unsigned int)(q & 0xff) << (8 * t);
-                            }
-                        }
-                        if constexpr (FPE) {
-                            static_assert(!FPE || NT == 4, "the fp32 epilogue packs four channels per lane and row");
-                            float yc[NT];
+                                static_assert(!FPE || NT == 4, "the fp32 epilogue packs four channels per lane and row");
+                                if constexpr (CL) {
+                                    float yc[NT];
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) yc[t] = __builtin_amdgcn_fmed3f(yq[t], RQLO, RQHI);
-                            ymx = rvmax3(rvmax3(ymx, ypos[0], ypos[1]), ypos[2], ypos[3]);
-                            ymn = rvmin3(rvmin3(ymn, yneg[0], yneg[1]), yneg[2], yneg[3]);
-                            w = rpack4(yc[0], yc[1], yc[2], yc[3]);
+                                    for (int t = 0; t < NT; ++t) yc[t] = __builtin_amdgcn_fmed3f(rvmax(ypos[t], yneg[t]), RQLO, RQHI);
+                                    w = rpack4(yc[0], yc[1], yc[2], yc[3]);
+                                } else {
+                                    ymx = rvmax3(rvmax3(ymx, ypos[0], ypos[1]), ypos[2], ypos[3]);
+                                    ymn = rvmin3(rvmin3(ymn, yneg[0], yneg[1]), yneg[2], yneg[3]);
+                                    rmax_to_byte<0>(w, ypos[0], yneg[0]);
+                                    rmax_to_byte<1>(w, ypos[1], yneg[1]);
+                                    rmax_to_byte<2>(w, ypos[2], yneg[2]);
+                                    rmax_to_byte<3>(w, ypos[3], yneg[3]);
+                                }
+                            }
+                            *(unsigned int *)(stg + lrow * SSTR + ncol) = w;
+                            if constexpr (FPE) __builtin_amdgcn_sched_barrier(0);   // one row at a time: short live ranges (no spill)
                         }
-                        *(unsigned int *)(stg + lrow * SSTR + ncol) = w;
-                        if constexpr (FPE) __builtin_amdgcn_sched_barrier(0);   // one row at a time: short live ranges (no spill)
                     }
+                };
+                stage(std::false_type{});
+                if constexpr (FPE) {
+                    if (__builtin_amdgcn_ballot_w64(ymx > RQHI || ymn < RQLO) != 0ull) stage(std::true_type{});
                 }
                 if (Y355_DIAG12 && first) stamp();                   // requantised and staged (this wave)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -611,7 +642,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
                             if constexpr (FPE) {
                                 asm volatile("" : "+v"(v));        // recompute here: do not keep the hot pass's 96 values alive for this branch
                                 float ypc, ync;
-                                const float y = requantf(v, t, ypc, ync);
+                                (void)requantf(v, t, ypc, ync);
+                                const float y = rvmax(ypc, ync);
                                 nsat += (srow < OROWS && (y > RQHI || y < RQLO)) ? 1u : 0u;
                             } else {
                                 const int qq = requant(v, t);
