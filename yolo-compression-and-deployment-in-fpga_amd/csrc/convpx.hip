@@ -330,15 +330,21 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx_kernel(const Con
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int n = 0; n < NTN; ++n) acc[0][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[ks][n], bq[ks], acc[0][n], 0, 0, 0);
+                // pinned: every read of the group, then its MFMAs (one exposed LDS wait per group instead of three)
+                __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, KS * NTN, 0);
             } else {
-                // neighbourhood row r feeds conv output (dy, dx) with filter tap (r - dy, c - dx)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v4i bq[4][KPP];
+                // neighbourhood row r feeds conv output (dy, dx) with filter tap (r - dy, c - dx).  The order is pinned
+                // (sched_group_barrier): rows 0 and 1 are read, then row r's MFMAs run over the reads of row r + 2 -- left to
+                // itself the scheduler puts every read right in front of the MFMAs that use it, nine exposed LDS waits per group
+                v4i bq[4][4][KPP];
+                auto rd = [&](int r) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int h = 0; h < KPP; ++h) bq[c][h] = *(const v4i *)(smem + roff[r] + (xoff[c] ^ (h << 6)));
+                        for (int h = 0; h < KPP; ++h) bq[r][c][h] = *(const v4i *)(smem + roff[r] + (xoff[c] ^ (h << 6)));
+                };
+                auto mm = [&](int r) {
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy) {
                         const int ty = r - dy;
@@ -353,9 +359,32 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void convpx_kernel(const Con
                                 for (int h = 0; h < KPP; ++h)
 #pragma unroll
                                     for (int n = 0; n < NTN; ++n)
-                                        acc[2 * dy + dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[(ty * 3 + tx) * KPP + h][n], bq[c][h],
+                                        acc[2 * dy + dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[(ty * 3 + tx) * KPP + h][n], bq[r][c][h],
                                                                                                    acc[2 * dy + dx][n], 0, 0, 0);
                             }
+                    }
+                };
+                if constexpr (KPP == 1) {
+                    rd(0);
+                    rd(1);
+                    mm(0);
+                    rd(2);
+                    mm(1);
+                    rd(3);
+                    mm(2);
+                    mm(3);
+                    constexpr int RDS = 4 * KPP, M03 = 6 * KPP * NTN, M12 = 12 * KPP * NTN;     // reads per row; MFMAs of rows 0 / 3 and 1 / 2
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * RDS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, M03, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RDS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, M12, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RDS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, M12 + M03, 0);
+                } else {                                           // two k-steps per tap: the weights leave no room for two rows in flight
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        rd(r);
+                        mm(r);                                     // (a row's reads pinned in front of its MFMAs: measured, no change)
                     }
                 }
             }
