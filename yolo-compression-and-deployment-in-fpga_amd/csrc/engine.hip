@@ -511,10 +511,11 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         // (Round 4: the resident-weight family conv3x3_v2.hip is gone -- it only ever ran where the fused front end or convpx refused.)
 #ifdef Y355_EXPERIMENTS
         static const int no_ring_mask = getenv("Y355_NO_RING_MASK") ? atoi(getenv("Y355_NO_RING_MASK")) : 0;
+        static const int no_px_mask = getenv("Y355_NO_PX_MASK") ? atoi(getenv("Y355_NO_PX_MASK")) : 0;
 #else
-        constexpr int no_ring_mask = 0;
+        constexpr int no_ring_mask = 0, no_px_mask = 0;
 #endif
-        if (L.wpx_dev) {
+        if (L.wpx_dev && !((no_px_mask >> k) & 1)) {
             ConvParams q = p;
             q.w = L.wpx_dev;
             if (y355_launch_conv_px(L.kid, q, h->stream)) {
