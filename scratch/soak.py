@@ -1,4 +1,4 @@
-"""soak: three handles in throughput mode (192 workgroups per launch), N rounds of 6 interleaved steps, every output compared with the
+"""soak: three handles in throughput mode (SOAK_WGS workgroups per launch, default 128 as bench.py), N rounds of 6 interleaved steps, every output compared with the
 stand-alone result; also the u8 route and a second input.  usage: soak.py [rounds]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,7 +30,7 @@ for x in xs:
     refs.append([t.clone() for t in scratch])
 bufs = [tuple(torch.zeros_like(t) for t in engs[0]._buffers(B)) for _ in range(6)]
 for e in engs:
-    e.set_option(_ffi.OPT_RING_WORKGROUPS, 192)
+    e.set_option(_ffi.OPT_RING_WORKGROUPS, int(os.environ.get("SOAK_WGS", "128")))
 bad = 0
 t0 = time.time()
 for it in range(rounds):
