@@ -659,9 +659,9 @@ static int launch_front(y355_engine *h, int B, const float *x_dev) {
     return 0;
 }
 
-// The per-forward reset of the saturation counters as an ordinary kernel launch: hipMemsetAsync's fill goes down the runtime's
-// blit path, and with three handles sharing the GPU every queue sat idle in front of it (profiles/r04_notes.md section 10:
-// the launch-to-launch gap in front of __amd_rocclr_fillBufferAligned was the only gap of the step).
+// The per-forward reset of the saturation counters as an ordinary kernel launch instead of hipMemsetAsync (whose fill goes down
+// the runtime's blit path).  Measured equal to the memset in the three-handle regime (299.7 k against 300.0 k img/s); under
+// rocprofv3 the memset shows a 280 us gap in front of it, which is the profiler's own per-dispatch cost, not the runtime's.
 __global__ void y355_zero_u64_kernel(unsigned long long *p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0ull;
 }
