@@ -345,9 +345,13 @@ int y355_net_counters(y355_net *h, int64_t *saturated);
 int y355_net_forward(y355_net *h, const float *x_dev, int batch, int flags,
                      float *boxes_dev, float *scores_dev, int32_t *cls_dev, int32_t *count_dev);
 int y355_net_get_candidates(y355_net *h, int batch, float *boxes, float *scores, int32_t *cls);
-/* parity tap: activation tensor idx (graph order, see csrc/net.hip) as fp32 NCHW on the host */
+/* parity tap: activation tensor idx (graph order, see csrc/net.hip) as fp32 NCHW on the host.
+ * Tensor taps and calibration need a forward with Y355_F_TAP: on SlimYOLOv2 / YOLOv3tiny graphs a plain forward runs the first
+ * two layers in one launch and never writes the first layer's map -- reading that tensor (here or through
+ * y355_net_tensor_absmax) after such a forward returns Y355_ENOTREADY instead of stale data, as y355_get_feature(h, 0, ...)
+ * does on the q_bf engine. */
 int y355_net_get_tensor(y355_net *h, int idx, int batch, float *dst_host);
-/* max |value| of an activation tensor of the last forward (calibration of the int8 recipe) */
+/* max |value| of an activation tensor of the last forward (calibration of the int8 recipe); see the note above */
 int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *out_max);
 int y355_net_max_det(y355_net *h);
 int y355_net_num_anchors_total(y355_net *h);

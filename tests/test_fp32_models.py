@@ -264,11 +264,25 @@ def test_int8_tiny_bit_exact(case, gold):
     # (conv_1's own map is not written by that launch: it still holds the tap forward's)
     tap_t = [net.get_tensor(t, B) for t in range(net.num_tensors)]
     out2 = net.forward(x)
+    from yolo355 import _ffi
+    with pytest.raises(_ffi.Y355Error) as ei:              # conv_1's map was not written by this forward
+        net.get_tensor(0, B)
+    assert ei.value.code == _ffi.ENOTREADY
     for t in range(1, net.num_tensors):
         assert np.array_equal(net.get_tensor(t, B), tap_t[t]), "tensor %d differs between the fused and the layer-by-layer front end" % t
     assert net.counters() == ref["sat"]
     for bi in range(B):
         assert all(np.array_equal(a, b) for a, b in zip(out[bi], out2[bi]))
+    # Y355_NET_OPT_WORKGROUPS: fewer persistent workgroups per convr launch + one pair-walk workgroup per image
+    # change the schedule only -- every tensor, the counters and the detection lists are the same
+    for n in (7, 128, 0):
+        net.set_option(_ffi.NET_OPT_WORKGROUPS, n)
+        out3 = net.forward(x)
+        for t in range(1, net.num_tensors):
+            assert np.array_equal(net.get_tensor(t, B), tap_t[t]), "workgroups %d: tensor %d differs" % (n, t)
+        assert net.counters() == ref["sat"]
+        for bi in range(B):
+            assert all(np.array_equal(a, b) for a, b in zip(out[bi], out3[bi])), "workgroups %d: image %d" % (n, bi)
     net.close()
 
 
@@ -310,7 +324,12 @@ def test_bf16_fused_front_matches_layer_launches(case):
     fused = fnet.forward(x)
     nt = fnet.num_tensors
     npred = 2 if case[1] == "tiny_yolo_v3" else 1
-    assert not np.any(fnet.get_tensor(0, B)), "the fused launch does not write conv1's own map (the net is fresh: still zero)"
+    # the fused launch does not write conv1's own map: reading it (or its maximum) is an error, not stale data
+    from yolo355 import _ffi
+    for read in (lambda: fnet.get_tensor(0, B), lambda: fnet.tensor_absmax(0, B)):
+        with pytest.raises(_ffi.Y355Error) as ei:
+            read()
+        assert ei.value.code == _ffi.ENOTREADY
     t1_f = fnet.get_tensor(1, B).astype(np.float64)
     pred_f = [fnet.get_tensor(nt - npred + k, B).astype(np.float64) for k in range(npred)]
     tap = fnet.forward(x, tap=True)

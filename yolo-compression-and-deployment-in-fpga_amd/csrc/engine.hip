@@ -665,14 +665,15 @@ static int launch_front(y355_engine *h, int B, const float *x_dev) {
 __global__ void y355_zero_u64_kernel(unsigned long long *p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0ull;
 }
-void y355_zero_counters(Counters *c, int n, hipStream_t s) {
+int y355_zero_counters(Counters *c, int n, hipStream_t s) {
     hipLaunchKernelGGL(y355_zero_u64_kernel, dim3(1), dim3(64), 0, s, (unsigned long long *)c, n * (int)(sizeof(Counters) / 8));
+    return (int)hipGetLastError();                   // a failed launch must not leave the previous forward's counts in place
 }
 
 // enqueue one forward on `s` (refresh_layer must have run)
 static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
                            int32_t *cls_dev, int32_t *count_dev, bool prof) {
-    y355_zero_counters(h->ctr_dev, 10, h->stream);
+    HIPCHK((hipError_t)y355_zero_counters(h->ctr_dev, 10, h->stream));
     const int guard = (flags & Y355_F_GUARD) ? 1 : 0;
     // the fused front end covers the 32-bit epilogue without the head-room guard; conv2's packed weights must be the
     // resident-weight layout (one n-block of 32 channels), which they are for this network

@@ -441,6 +441,7 @@ struct y355_net {
     // models/slim_yolo_v2.py:549-575, backbone/darknet.py:216-220): both layers in ONE launch of the q_bf engine's fused front
     // end (front.hip) when their epilogues are exact in fp32 (y355_front_eligible); tap forwards run the layers one by one
     bool front_graph = false, front_ok = false, front_dirty = true;
+    bool t0_skipped = false;                            // the last forward ran the fused front end: tensor 0 (conv1's map) was not written
     int8_t *wf_dev = nullptr;         // 16 KiB of front-end weight fragments (y355_pack_front)
     int *fb1_dev = nullptr, *fb2_dev = nullptr;   // pre-shifted int32 biases of the two layers
     Requant frq1{}, frq2{};
@@ -1191,10 +1192,11 @@ extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int 
     const int nops = h->arch->nops;
     if (!h->bf) {
         if (int rc = refresh_i8(h)) return rc;
-        y355_zero_counters(h->ctr_dev, nops + 1, h->stream);
+        HIPCHK((hipError_t)y355_zero_counters(h->ctr_dev, nops + 1, h->stream));
     }
     // tap forwards (parity tests read every tensor) run the first two layers one by one: the fused launch does not write conv1's map
     const bool fuse_front = h->front_graph && (h->bf || h->front_ok) && !(flags & Y355_F_TAP);
+    h->t0_skipped = fuse_front;
     for (int i = 0; i < nops; ++i) {
         if (prof) HIPCHK(hipEventRecord(h->ev[i], h->stream));
         if (fuse_front && i < 2) {
@@ -1265,6 +1267,9 @@ extern "C" int y355_net_get_candidates(y355_net *h, int batch, float *boxes, flo
 extern "C" int y355_net_get_tensor(y355_net *h, int idx, int batch, float *dst) {
     if (!h || !dst || idx < 0 || idx >= h->arch->ntensors) return y355_fail(Y355_EINVAL, "bad argument");
     if (batch < 1 || batch > h->cfg.max_batch) return y355_fail(Y355_EINVAL, "batch out of range");
+    if (idx == h->arch->ops[0].out && h->t0_skipped)
+        return y355_fail(Y355_ENOTREADY, "the first layer's map of the last forward was not written (fused front end): "
+                                         "run the forward with Y355_F_TAP to read it");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     const Tensor &t = h->T[idx];
     const int Hp = t.H + 2 * t.halo, Wp = t.W + 2 * t.halo;
@@ -1299,6 +1304,9 @@ extern "C" int y355_net_tensor_absmax(y355_net *h, int idx, int batch, float *ou
     const Tensor &t = h->T[idx];
     if (!h->bf) return y355_fail(Y355_EINVAL, "absmax taps exist on bf16 nets (the calibration run)");
     if (t.pred) return y355_fail(Y355_EINVAL, "prediction maps are fp32: read them with y355_net_get_tensor");
+    if (idx == h->arch->ops[0].out && h->t0_skipped)
+        return y355_fail(Y355_ENOTREADY, "the first layer's map of the last forward was not written (fused front end): "
+                                         "calibrate from a forward with Y355_F_TAP");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemsetAsync(h->absmax_dev, 0, 16, h->stream));
     const size_t n = (size_t)batch * (t.H + 2) * (t.W + 2) * t.Cpad;

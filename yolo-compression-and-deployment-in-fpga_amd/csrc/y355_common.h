@@ -84,7 +84,7 @@ struct Counters {
     unsigned long long guard; // head-room violations
 };
 
-void y355_zero_counters(Counters *c, int n, hipStream_t s);   // engine.hip: a kernel launch, not hipMemsetAsync
+int y355_zero_counters(Counters *c, int n, hipStream_t s);    // engine.hip: a kernel launch, not hipMemsetAsync; returns the launch status (hipError_t)
 
 struct ConvParams {
     const int8_t *in;     // int8 NHWC with halo  [B][H+2][W+2][CIN]
