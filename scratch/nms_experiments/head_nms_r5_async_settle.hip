@@ -715,35 +715,35 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
 #define PAIRS_LDS (NMS_CAP * 24 + (NMS_CAP + 8) * 4 + WG_EDGE_CAP * 4)
 
 // ---- resolve_emit_kernel: one workgroup per image.
-// Greedy NMS = for every candidate, "kept unless an EARLIER (score desc, anchor index asc) kept
-// candidate suppresses it".  With the suppressing pairs known, that is settled without sorting, by
-// rounds over the edge list held in LDS (each thread owns a strided set of slots and compacts it in
-// place):
-//   A  for every live edge (a earlier -> b): a kept -> b is dead, edge retires; a dead -> edge
-//      retires; a undecided -> b is blocked this round;
-//   B  every undecided candidate that is neither dead nor blocked is kept.
-// A candidate is decided one round after its last earlier neighbour, so the number of rounds is the
-// longest chain of alternating decisions (16-17 on the benchmark's images), each a few hundred
-// cycles.  Classes need no special handling: edges only join candidates of one class.
+// Greedy NMS = for every candidate, "kept unless an EARLIER (score desc, anchor index asc) kept candidate suppresses it".
+// With the suppressing pairs known that is a dataflow problem on a DAG: a candidate is KEPT once all its earlier neighbours
+// are dead and DEAD as soon as one of them is kept.  Round 5: settled NODE-CENTRIC and ASYNCHRONOUSLY, without block barriers:
+//   1  the edge list is oriented by the NMS order and turned into in-edge lists (CSR by the LATER endpoint: a count per
+//      candidate through LDS atomics, a block-wide exclusive scan, a scatter of the earlier endpoints into `adj`);
+//   2  every thread owns four candidates (tid + 1024 k: neighbours in the (group, bin) order -- which are each other's
+//      suppressors -- sit in adjacent lanes) and polls its undecided ones: four in-neighbours' states per trip; one kept
+//      neighbour kills, leading dead neighbours are skipped for good, a list walked to its end keeps.  States only ever go
+//      0 -> 1 or 0 -> 2 and only their owner writes them, so a stale read merely postpones a decision; the earliest undecided
+//      candidate of the image can always be decided by its owner, so the loop ends.  A decision travels to the next
+//      candidate of a suppression chain in one trip of the owning wave (~0.3-0.5 k cycles) instead of one round of the whole
+//      workgroup (rounds 1-4: two 16-wave barriers + every thread's seven edge slots per round, 2.6 k cycles, 20 rounds on the
+//      benchmark images -- profiles/r04_notes.md 12; the state gathers drop from ~135 k per image to ~12 k).
+// Classes need no special handling: edges only join candidates of one class.
 // Survivors are then written in anchor-index order into the padded outputs.
-// Fallback (an edge list overflowed, or more edges than the LDS list holds): the textbook walk over
-// the candidates sorted by score, with the reference's predicate evaluated on the fly.
-// Round 5: a node-centric ASYNCHRONOUS settle (in-edge lists per candidate, every thread polling its own candidates'
-// earlier neighbours, no block barriers) was built bit-exact and measured 53.7 us (all four candidates of a thread per trip) and
-// 112.8 us (one candidate per trip, neighbour indices in registers) against these rounds' 40.6: a decision still travels one
-// WAVE TRIP per link of a suppression chain, and a trip of sixteen polling waves costs what a round costs
-// (scratch/nms_experiments/head_nms_r5_async_settle.hip, profiles/r05_notes.md section 2).
-#define RE_REG 7                    // edge slots per thread held in registers (7168 edges)
-#define RE_NONE 0x00ffffffu          // a retired / absent edge: (4095, 4095), never a real pair (i < q)
+// Fallback (an edge list overflowed, or more edges than `adj` holds): the textbook walk over the candidates sorted by score,
+// with the reference's predicate evaluated on the fly.
+#define RE_REG 7                    // oriented edges per thread kept in registers between the count and the scatter pass (7168 edges)
 
 __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, const HeadWork wk, float thr) {
-    __shared__ __attribute__((aligned(16))) unsigned int sedge[LDS_EDGE_CAP - RE_REG * 1024];   // edges past the register slots; sort keys of the fallback walk
+    __shared__ __attribute__((aligned(16))) unsigned short adj[LDS_EDGE_CAP];    // in-edge lists: the earlier endpoints; sort keys of the fallback walk
     __shared__ __attribute__((aligned(16))) unsigned char state[NMS_CAP];        // 0 undecided, 1 kept, 2 dead
-    __shared__ __attribute__((aligned(16))) unsigned char blocked[NMS_CAP];
+    __shared__ __attribute__((aligned(16))) int cur[NMS_CAP];                    // in-degree -> list start -> list end of candidate pos
     __shared__ unsigned int skey[2 * NMS_CAP];        // NMS order key of a candidate: (score bits, ~anchor index); later the emit scratch
     __shared__ unsigned long long keepn[64];          // survivors by anchor index
-    __shared__ int pend[2];
+    __shared__ int wsum[16];
     __shared__ int wbase[64];
+    static_assert(NMS_CAP == 4096, "four candidates per thread of a 1024-thread workgroup");
+    static_assert(LDS_EDGE_CAP * 2 >= NMS_CAP * 8, "the fallback's sort keys alias adj");
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     NSTAMP(2, blockIdx.x, 0);
     const int M = wk.count[b];
@@ -754,110 +754,163 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     const int ne = wk.nedges[b * 2];
     const bool brute = wk.nedges[b * 2 + 1] != 0 || ne > LDS_EDGE_CAP;
     const unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
+    // the first RE_REG edges of this thread are in flight while the candidates' keys are staged
+    const int kmax = __builtin_amdgcn_readfirstlane((ne + 1023) >> 10);
+    unsigned int ed[RE_REG];
+#pragma unroll
+    for (int k = 0; k < RE_REG; ++k) {
+        const int e = tid + k * 1024;
+        ed[k] = (!brute && e < ne) ? ge[e] : 0u;          // 0 = (0, 0): not a pair (i < q), "no edge"
+    }
     for (int pos = tid; pos < NMS_CAP; pos += 1024) {
-        state[pos] = (pos < M && brute) ? 0 : 1;          // kept unless it is an endpoint of an edge (below)
-        blocked[pos] = 0;
+        state[pos] = pos < M ? 0 : 1;                     // undecided until its in-edges are settled (a candidate without any is kept)
+        cur[pos] = 0;
         // scores are non-negative floats: their bit patterns order like the values.  Staged once, coalesced: the
-        // orientation loop below used to gather cs / co from global memory per edge (15 k cycles of dependent loads)
+        // orientation below used to gather cs / co from global memory per edge (15 k cycles of dependent loads)
         skey[2 * pos] = pos < M ? __float_as_uint(cs[pos]) : 0u;
         skey[2 * pos + 1] = pos < M ? (unsigned int)co[pos] : 0u;
     }
     if (tid < 64) keepn[tid] = 0ull;
-    if (tid < 2) pend[tid] = 0;
     __syncthreads();
+    NSTAMP(2, blockIdx.x, 5);
     if (!brute) {
-        // The first RE_REG entries of a thread's edge slots (slot k of thread tid = list entry tid + 1024 k) live in registers,
-        // the rest (only images with more than 7168 suppressing pairs have any) in LDS; the candidate states in LDS.
-        // A round is two LDS round trips and two barriers:
-        //   A  all state reads of my live edges issued together, then the writes (dead / blocked marks);
-        //   B  every thread settles its own four candidates (one dword of `state`, one of `blocked`).
-        // (Measured before: edges compacted in LDS, three dependent LDS stages per trip of four edges: 4-6 k cycles per
-        // round, 16-17 rounds.)
-        const int kmax = __builtin_amdgcn_readfirstlane((ne + 1023) >> 10);
-        unsigned int ed[RE_REG];
+        // ---- 1a: orient every edge (earlier << 12 | later) and count the later endpoint's in-edges
         auto orient = [&](unsigned int pq) {
-            // orient the pair by the NMS order (score desc, anchor index asc); both endpoints become undecided
             const int i = (int)(pq >> 12), q = (int)(pq & 0xfffu);
             const uint2 ki = *(const uint2 *)&skey[2 * i], kq = *(const uint2 *)&skey[2 * q];
             const bool i_first = ki.x > kq.x || (ki.x == kq.x && ki.y < kq.y);
-            state[i] = 0;
-            state[q] = 0;
             return i_first ? pq : (((unsigned int)q << 12) | (unsigned int)i);
         };
 #pragma unroll
-        for (int k = 0; k < RE_REG; ++k) {
+        for (int k = 0; k < RE_REG; ++k)
+            if (ed[k] != 0u) {
+                ed[k] = orient(ed[k]);
+                atomicAdd(&cur[ed[k] & 0xfffu], 1);
+            }
+        for (int k = RE_REG; k < kmax; ++k) {                                   // rare: images with more than 7168 suppressing pairs
             const int e = tid + k * 1024;
-            ed[k] = e < ne ? ge[e] : RE_NONE;
+            if (e < ne) atomicAdd(&cur[orient(ge[e]) & 0xfffu], 1);
         }
+        __syncthreads();
+        NSTAMP(2, blockIdx.x, 3);
+        // ---- 1b: exclusive scan of the in-degrees (thread t: candidates 4 t .. 4 t + 3), in place: cur[pos] = start of pos's list
+        {
+            const int4 d = *(const int4 *)&cur[4 * tid];
+            const int tsum = d.x + d.y + d.z + d.w;
+            int incl = tsum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wsum[tid >> 6] = incl;
+            __syncthreads();
+            int base = incl - tsum;
+            for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];                 // wave-uniform trip count, 16 broadcast reads at most
+            *(int4 *)&cur[4 * tid] = make_int4(base, base + d.x, base + d.x + d.y, base + d.x + d.y + d.z);
+        }
+        __syncthreads();
+        NSTAMP(2, blockIdx.x, 4);
+        // ---- 1c: scatter the earlier endpoints; afterwards cur[pos] = END of pos's list (= start of pos + 1's)
 #pragma unroll
         for (int k = 0; k < RE_REG; ++k)
-            if (ed[k] != RE_NONE) ed[k] = orient(ed[k]);
+            if (ed[k] != 0u) adj[atomicAdd(&cur[ed[k] & 0xfffu], 1)] = (unsigned short)(ed[k] >> 12);
         for (int k = RE_REG; k < kmax; ++k) {
             const int e = tid + k * 1024;
-            sedge[e - RE_REG * 1024] = e < ne ? orient(ge[e]) : RE_NONE;
+            if (e < ne) {
+                const unsigned int o = orient(ge[e]);
+                adj[atomicAdd(&cur[o & 0xfffu], 1)] = (unsigned short)(o >> 12);
+            }
         }
         __syncthreads();
         NSTAMP(2, blockIdx.x, 1);
-        // one step of A for an edge whose endpoint states were read as (sa, sc): returns the edge, or RE_NONE once it retires
-        // (the later endpoint's state is not read: an edge whose later endpoint already died only marks it blocked a few more
-        // times, which nobody looks at -- half the LDS gathers of a round)
-        auto settle = [&](unsigned int e, int sa) {
-            if (e == RE_NONE || sa == 2) return RE_NONE;                           // the earlier endpoint died: the edge is void
-            const int c = (int)(e & 0xfffu);
-            if (sa == 1) { state[c] = 2; return RE_NONE; }                        // earlier endpoint kept: the later one dies
-            blocked[c] = 1;                                                        // earlier endpoint undecided
-            return e;
-        };
-        int nround = 0;
-        (void)nround;
-        for (;;) {
-            ++nround;
-            {
-                int sa[RE_REG];
+        // ---- 2: asynchronous settle.  `state` is read through a volatile pointer: other waves write it while this one polls.
+        // A lane works on ONE of its four candidates at a time, with the indices of that candidate's next four in-neighbours in
+        // registers: a trip of the wave is four state reads (first version: all four candidates' neighbours AND their indices
+        // re-read every trip = 32 LDS instructions per wave and trip, sixteen spinning waves saturating the LDS pipe: 53.7 us
+        // against the rounds' 40.6).  A candidate that made no progress hands over to the lane's next open one (no head-of-line
+        // blocking: somebody else's chain may be waiting for that one).
+        volatile unsigned char *vstate = state;
+        int lb[4], le[4];                                   // my candidates' remaining in-edge ranges; lb >= le: decided
 #pragma unroll
-                for (int k = 0; k < RE_REG; ++k) sa[k] = state[ed[k] >> 12];      // RE_NONE reads candidate 4095: harmless
-#pragma unroll
-                for (int k = 0; k < RE_REG; ++k) ed[k] = settle(ed[k], sa[k]);
+        for (int k = 0; k < 4; ++k) {
+            const int c = tid + k * 1024;
+            lb[k] = 0;
+            le[k] = 0;
+            if (c < M) {
+                lb[k] = c ? cur[c - 1] : 0;
+                le[k] = cur[c];
+                if (lb[k] == le[k]) vstate[c] = 1;          // nobody earlier overlaps it: kept
             }
-            for (int k = RE_REG; k < kmax; ++k) {                                   // rare: the LDS-resident tail
-                const unsigned int e = sedge[tid + (k - RE_REG) * 1024];
-                if (e != RE_NONE) sedge[tid + (k - RE_REG) * 1024] = settle(e, state[e >> 12]);
-            }
-            __syncthreads();
-#ifdef Y355_EXPERIMENTS
-            if (nround == 1) NSTAMP(2, blockIdx.x, 3);
-#endif
-            unsigned int st = *(const unsigned int *)&state[4 * tid], bl = *(const unsigned int *)&blocked[4 * tid];
-            int pending = 0;
-            if (((st - 0x01010101u) & ~st & 0x80808080u) != 0u) {                      // some byte of st is 0 (undecided)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (((st >> (8 * u)) & 0xffu) == 0u) {
-                        if (((bl >> (8 * u)) & 0xffu) == 0u) st |= 1u << (8 * u);
-                        else pending = 1;
-                    }
-                }
-                *(unsigned int *)&state[4 * tid] = st;
-            }
-            if (bl) *(unsigned int *)&blocked[4 * tid] = 0u;
-            // "anybody still undecided?" through one LDS word per round parity and ONE barrier (was __syncthreads_or)
-            if (pending) pend[nround & 1] = 1;
-            __syncthreads();
-            const int again = pend[nround & 1];
-            if (tid == 0) pend[(nround + 1) & 1] = 0;      // written again only after the next round's first barrier
-#ifdef Y355_EXPERIMENTS
-            if (nround == 1) NSTAMP(2, blockIdx.x, 4);
-            if (nround == 2) NSTAMP(2, blockIdx.x, 5);
-            if (!again && wk.stamps && tid == 0 && blockIdx.x < 256) wk.stamps[((2 * 256 + blockIdx.x) * 8) + 6] = wk.stamps[((2 * 256 + blockIdx.x) * 8) + 5] + nround;
-#endif
-#if defined(Y355_ABL_NMS) && (Y355_ABL_NMS & 1)
-            break;                                  // timing ablation (WRONG RESULTS): one round only
-#endif
-            if (!again) break;
         }
+        int kc = 0, clb = lb[0], cle = le[0];               // the candidate this lane works on
+        auto pick = [&](int from) {                         // first open candidate at or after slot `from`, cyclically; kc = 4: none
+            kc = 4;
+#pragma unroll
+            for (int d = 3; d >= 0; --d) {
+                const int k = (from + d) & 3;
+                const int l = k == 0 ? lb[0] : k == 1 ? lb[1] : k == 2 ? lb[2] : lb[3];
+                const int e = k == 0 ? le[0] : k == 1 ? le[1] : k == 2 ? le[2] : le[3];
+                if (l < e) { kc = k; clb = l; cle = e; }
+            }
+        };
+        auto put = [&](int k, int l, int e) {               // write the working range back
+            if (k == 0) { lb[0] = l; le[0] = e; } else if (k == 1) { lb[1] = l; le[1] = e; }
+            else if (k == 2) { lb[2] = l; le[2] = e; } else if (k == 3) { lb[3] = l; le[3] = e; }
+        };
+        pick(0);
+        bool fresh = true;                                  // the neighbour window has to be (re)loaded
+        int nb[4] = {-1, -1, -1, -1};
+        int ntrip = 0;
+        (void)ntrip;
+#if defined(Y355_ABL_NMS) && (Y355_ABL_NMS & 1)
+        if (false)                                  // timing ablation (WRONG RESULTS): no settle loop
+#endif
+        while (__any(kc < 4)) {
+#ifdef Y355_EXPERIMENTS
+            ++ntrip;
+#endif
+            const bool have = kc < 4;
+            if (__any(have && fresh)) {
+                if (have && fresh) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nb[j] = clb + j < cle ? (int)adj[clb + j] : -1;
+                }
+            }
+            fresh = false;
+            int sn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sn[j] = (have && nb[j] >= 0) ? (int)vstate[nb[j]] : 2;      // past the end: counts as dead
+            bool moved = false;
+            if (have) {
+                const bool kill = sn[0] == 1 || sn[1] == 1 || sn[2] == 1 || sn[3] == 1;
+                int lead = 0;                               // dead neighbours at the front of the list: never looked at again
+                if (sn[0] == 2) { lead = 1; if (sn[1] == 2) { lead = 2; if (sn[2] == 2) { lead = 3; if (sn[3] == 2) lead = 4; } } }
+                const int c = tid + kc * 1024;
+                const int nlb = min(clb + lead, cle);
+                if (kill || nlb == cle) {
+                    vstate[c] = kill ? 2 : 1;
+                    put(kc, 0, 0);
+                    pick(kc + 1);
+                    fresh = true;
+                    moved = true;
+                } else {
+                    moved = lead > 0;
+                    put(kc, nlb, cle);
+                    const int was = kc;
+                    pick(kc + 1);                           // somebody else's turn (the same one again if it is my only open one)
+                    fresh = kc != was || lead > 0;
+                }
+            }
+            if (!__any(moved)) __builtin_amdgcn_s_sleep(1);  // everything this wave waits for is another wave's to decide
+        }
+#ifdef Y355_EXPERIMENTS
+        if (wk.stamps && tid == 0 && blockIdx.x < 256) wk.stamps[((2 * 256 + blockIdx.x) * 8) + 6] = (unsigned long long)ntrip;
+#endif
+        __syncthreads();
     } else {
         // ---- fallback: sort all candidates by (score desc, anchor index asc), walk them one at a time
-        unsigned long long *keys = (unsigned long long *)sedge;       // [NMS_CAP]
+        unsigned long long *keys = (unsigned long long *)adj;         // [NMS_CAP]
         for (int i = tid; i < NMS_CAP; i += 1024)
             keys[i] = i < M ? (((unsigned long long)(~__float_as_uint(cs[i])) << 32) | ((unsigned long long)(unsigned int)co[i] << 12) |
                                (unsigned int)i)

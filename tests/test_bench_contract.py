@@ -82,3 +82,10 @@ def test_world2_bench_logic_on_one_gpu():
     assert d["mismatching_values_c_abi_route"] is None and d["y355_comm_world"] is None     # RCCL needs one GPU per rank
     assert d["truncated_images"] == 128 and d["gather_full_records"]["truncated_images"] == 0
     assert d["value"] > 0 and d["scaling"] == "weak"
+    # a first N-GPU run diagnoses itself -- every rank's own rate, the N = 1 sub-result of the same process,
+    # the transport's version
+    pr = d["per_rank"]
+    assert len(pr["value_per_rank"]) == 2 and 0 < pr["min"] <= pr["max"] and abs(pr["sum"] - sum(pr["value_per_rank"])) < 1.0
+    assert pr["min"] * 2 >= d["value"] * 0.5                # the aggregate cannot be far above twice the slowest rank's own rate
+    assert d["n1_same_process"]["value"] > 0 and d["n1_same_process"]["ms_per_step"] > 0
+    assert isinstance(d["rccl_version"], str) and d["rccl_version"]

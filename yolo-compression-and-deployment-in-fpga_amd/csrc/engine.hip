@@ -292,7 +292,7 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     if (!rc) rc = dmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
     if (!rc) rc = dmalloc(h, &h->ws.corig, sizeof(int) * cap * B, false);
     if (!rc) rc = dmalloc(h, &h->ws.count, sizeof(int) * B, true);
-    if (!rc) rc = dmalloc(h, &h->ws.edges, sizeof(unsigned int) * 64 * cap * B, false);      // EDGE_CAP pairs per image
+    if (!rc) rc = dmalloc(h, &h->ws.edges, sizeof(unsigned int) * (size_t)Y355_HEAD_EDGE_CAP * B, false);      // EDGE_CAP pairs per image
     if (!rc) rc = dmalloc(h, &h->ws.nedges, sizeof(int) * 2 * (size_t)B, true);
     if (!rc) rc = dmalloc(h, &h->ws.binstart, sizeof(int) * (cap + 8) * B, true);
     if (!rc) rc = dmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXG * B, true);

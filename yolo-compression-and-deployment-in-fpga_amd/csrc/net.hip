@@ -601,7 +601,7 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     if (!rc) rc = nmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
     if (!rc) rc = nmalloc(h, &h->ws.corig, sizeof(int) * cap * B, false);
     if (!rc) rc = nmalloc(h, &h->ws.count, sizeof(int) * B, true);
-    if (!rc) rc = nmalloc(h, &h->ws.edges, sizeof(unsigned int) * 64 * cap * B, false);      // EDGE_CAP pairs per image
+    if (!rc) rc = nmalloc(h, &h->ws.edges, sizeof(unsigned int) * (size_t)Y355_HEAD_EDGE_CAP * B, false);      // EDGE_CAP pairs per image
     if (!rc) rc = nmalloc(h, &h->ws.nedges, sizeof(int) * 2 * (size_t)B, true);
     if (!rc) rc = nmalloc(h, &h->ws.binstart, sizeof(int) * (cap + 8) * B, true);
     if (!rc) rc = nmalloc(h, &h->ws.astat, sizeof(float) * 4 * Y355_HEAD_MAXG * B, true);
@@ -1441,7 +1441,7 @@ extern "C" int y355_head_f32(int device_id, int nlev, const float *const *pred, 
     if (!rc) rc = alloc(&w.ccls, sizeof(int) * cap * B, false);
     if (!rc) rc = alloc(&w.corig, sizeof(int) * cap * B, false);
     if (!rc) rc = alloc(&w.count, sizeof(int) * B, true);
-    if (!rc) rc = alloc(&w.edges, sizeof(unsigned int) * 64 * cap * B, false);
+    if (!rc) rc = alloc(&w.edges, sizeof(unsigned int) * (size_t)Y355_HEAD_EDGE_CAP * B, false);
     if (!rc) rc = alloc(&w.nedges, sizeof(int) * 2 * (size_t)B, true);
     if (!rc) rc = alloc(&w.binstart, sizeof(int) * (cap + 8) * B, true);
     if (!rc) rc = alloc(&w.astat, sizeof(float) * 4 * Y355_HEAD_MAXG * B, true);

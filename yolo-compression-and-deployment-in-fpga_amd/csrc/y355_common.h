@@ -289,10 +289,11 @@ struct HeadParams {
     int *out_count;
 };
 #define Y355_NMS_CAP 4096   // anchors per image the NMS workspace is sized for
+#define Y355_HEAD_EDGE_CAP 28672   // suppressing pairs per image the NMS edge list holds (more: the sorted fallback walk)
 #define Y355_HEAD_MAXA 16
 #define Y355_HEAD_MAXG 32   // candidate groups of the NMS sort: anchor types, area octaves, or -- heads with 3 .. 32 classes -- the classes
 // head_nms.hip workspace, per image: cbox f32[CAP][4], cscore f32[CAP], ccls i32[CAP], corig i32[CAP],
-// count i32, edges u32[64*CAP] (suppressing pairs), nedges i32[2] (count, overflow flag),
+// count i32, edges u32[Y355_HEAD_EDGE_CAP] (suppressing pairs), nedges i32[2] (count, overflow flag),
 // binstart i32[CAP+8], astat f32[Y355_HEAD_MAXG][4], tiny i32[CAP], ntiny i32, ctype i32[CAP] (candidate group),
 // dbox f32[CAP][4] / dscore f32[CAP] / dcls i32[CAP] (decode of every anchor).
 // Heads with more than Y355_NMS_CAP anchors per image also need rbox f32[rstride][4], rscore f32[rstride], rcls i32[rstride]
