@@ -904,8 +904,21 @@ def main():
         dom_ms = float(kernel_ms[7] + kernel_ms[8]) / 2 if have_k else dom_between
         dom_tops = B * 2e6 * LAYER_MMAC[7] / (dom_ms * 1e-3) / 1e12
         fused = not args.no_fuse_front and layer_ms[1] < 0.2 * layer_ms[0]     # slot 0 then holds conv1 + conv2 (one launch)
+        # conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip): slot 2 holds the pair, slot 3 reads ~0
+        pair3 = have_k and kernel_ms[2] > 0 and kernel_ms[3] == 0
+        knames = ((["conv1+conv2 (fused front end)"] if fused else ["conv1"]) + LAYER_NAMES[1:] +
+                  ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
+        if pair3:
+            knames[2] = "conv3_1+conv3_2 (fused pair)"
         layers = {}
         for i, n in enumerate(LAYER_NAMES):
+            if pair3 and i == 2:
+                layers["conv3_1+conv3_2 (fused pair)"] = dict(
+                    ms=round(float(layer_ms[2] + layer_ms[3]), 4),
+                    tops=round(B * 2e6 * (LAYER_MMAC[2] + LAYER_MMAC[3]) / ((layer_ms[2] + layer_ms[3]) * 1e-3) / 1e12, 1))
+                continue
+            if pair3 and i == 3:
+                continue
             if fused and i == 0:
                 layers["conv1+conv2 (fused front end)"] = dict(
                     ms=round(float(layer_ms[0] + layer_ms[1]), 4),
@@ -960,14 +973,9 @@ def main():
                          "launch_ms_between_events": round(dom_between, 4),
                          "frac_between_events": round(B * 2e6 * LAYER_MMAC[7] / (dom_between * 1e-3) / PEAK_I8_DENSE, 4),
                          # every launch's own duration (ms): layers (the fused front end under "conv1"), then the head / NMS kernels
-                         "kernel_ms": {n: round(float(kernel_ms[i]), 4) for i, n in
-                                       enumerate((["conv1+conv2 (fused front end)"] if fused else ["conv1"]) + LAYER_NAMES[1:] +
-                                                 ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
-                                       if kernel_ms[i] > 0},
+                         "kernel_ms": {n: round(float(kernel_ms[i]), 4) for i, n in enumerate(knames) if kernel_ms[i] > 0},
                          "kernel_ms_sum": round(float(kernel_ms.sum()), 4),
-                         "kernel_ms_in_timed_region": ({n: round(float(kernel_ms_region[i]), 4) for i, n in
-                                                        enumerate((["conv1+conv2 (fused front end)"] if fused else ["conv1"]) + LAYER_NAMES[1:] +
-                                                                  ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
+                         "kernel_ms_in_timed_region": ({n: round(float(kernel_ms_region[i]), 4) for i, n in enumerate(knames)
                                                         if kernel_ms_region[i] > 0} if kernel_ms_region is not None else None),
                          # MFMA-only loop MEASURED IN THIS RUN (y355_mfma_peak_i8: v_mfma_i32_16x16x64_i8 back to back on register
                          # operands, two waves per SIMD on every CU, ~50 ms) and the in-kernel clock it held

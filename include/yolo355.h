@@ -85,6 +85,13 @@ int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
  * and the NMS pair walk on one workgroup per image instead of two (+1.3 %; a handle alone loses 3 % with it).  Results are
  * identical bit for bit in either mode. */
 #define Y355_OPT_RING_WORKGROUPS 2
+/* Y355_OPT_FUSE_PAIRS (default 1): run conv3_1, conv3_2 and pool3 (models/slim_yolo_v2.py:246-267; conv_normal calls 3 and 4 of
+ * c_embedding/yolo_forward.c:1214-1225) as one launch whose 64-channel intermediate map stays in LDS
+ * (y355_get_feature(h, 2, ...) returns Y355_ENOTREADY after such a forward); 0 = one launch per layer.  The fused launch is
+ * used where both layers qualify for the fp32-exact epilogue without an accumulator shift and the map is at most 104 pixels
+ * wide; calibration, statistics runs and guarded forwards (Y355_F_GUARD) always run layer by layer.
+ * Results are identical bit for bit either way. */
+#define Y355_OPT_FUSE_PAIRS 3
 int y355_set_option(y355_engine *h, int option, int value);
 
 /* replaces load_state_dict of the quantized checkpoint: integer weights as produced by

@@ -349,6 +349,60 @@ def test_deep_layers_clamp_on_the_ring_kernels():
     eng.close()
 
 
+@pytest.mark.parametrize("H,W,B,gain,bump", [(416, 416, 3, 1.0, 0), (96, 96, 2, 1.0, 0), (320, 416, 2, 1.0, 0), (240, 320, 2, 1.6, 0),
+                                              (112, 64, 1, 2.5, 0), (320, 608, 1, 1.0, 0), (416, 416, 2, 3.0, 0), (416, 416, 2, 1.0, 2),
+                                              (64, 416, 1, 1.0, 1), (416, 128, 5, 1.0, 0)])
+def test_fused_pairs_equal_layer_launches(H, W, B, gain, bump):
+    """conv3_1 -> conv3_2 + pool3 as ONE launch (csrc/pxpair.hip, the default; conv3_1's map never leaves LDS) against the
+    oracle's conv3_2 map and against the one-launch-per-layer route: identical int8 maps behind the pair, detections, and
+    PER-LAYER saturation counts (conv3_1's counted once although a band recomputes its neighbours' edge rows).  Sizes: bands
+    that start and end inside an image (B x H/8 pooled rows over 256 workgroups), maps narrower than a 16-pixel group row
+    allows (W / 4 = 16), a map too wide for the rings (W = 608: the launcher declines and the two layers run as before),
+    inputs beyond the calibration range, and `bump`: the exponents behind conv3_1 and conv3_2 raised so that BOTH phases take
+    their cold (clamping, counting) passes."""
+    from yolo355 import _ffi
+    ql = O.quantize_layers(synth.make_weights(seed=2, num_classes=2, pred_gain=400.0, obj_bias=-4.0))
+    eng = Engine([H, W], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
+    eng.load_quantized(ql)
+    frames = synth.make_frames_u8(11, B, H, W, "blocks")
+    xc = synth.normalize_frames(frames)[:1]
+    eng.calibrate(xc, [RangeTracker() for _ in range(11)])
+    otr = [O.RangeTracker() for _ in range(11)]
+    O.detect(xc, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2)
+    if bump:
+        sa = list(eng.get_act_exponents())
+        for k in (3, 4):                         # trackers behind conv3_1 and conv3_2
+            sa[k] += bump
+            otr[k].scale = otr[k].scale * 2 ** bump
+        eng.set_act_exponents(sa)
+    x = synth.normalize_frames(frames) * np.float32(gain)
+    r = O.detect(x, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2, saturate=True, keep=True)
+    res = {}
+    for fuse in (1, 0):
+        eng.set_option(_ffi.OPT_FUSE_PAIRS, fuse)
+        dets = eng.forward(x)
+        res[fuse] = (dets, [eng.layer_stats(k)["saturated"] for k in range(10)], eng.get_feature(3, B).copy(), eng.get_feature(9, B).copy())
+        if fuse == 0:
+            assert np.array_equal(eng.get_feature(2, B), r["maps"][2].astype(np.int8))
+    eng.set_option(_ffi.OPT_FUSE_PAIRS, 1)
+    eng.forward(x)
+    if W // 4 <= 104:                            # the fused launch ran: conv3_1's map was not written
+        with pytest.raises(_ffi.Y355Error) as e:
+            eng.get_feature(2, B)
+        assert e.value.code == _ffi.ENOTREADY
+    assert np.array_equal(res[1][2], r["maps"][3].astype(np.int8)), "conv3_2's pooled map of the fused launch differs from the oracle"
+    assert np.array_equal(res[1][3], r["pred_q"].astype(np.int8))
+    assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][3], res[0][3])
+    assert res[1][1] == res[0][1], "per-layer saturation counts differ between the fused and the per-layer route: %s / %s" % (res[1][1], res[0][1])
+    assert res[1][1][2:4] == list(r["sat_out"])[2:4], (res[1][1], r["sat_out"])
+    if bump:
+        assert res[1][1][2] > 0 and res[1][1][3] > 0, "the fixture must clamp in both layers of the pair"
+    for a, b in zip(res[1][0], res[0][0]):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    eng.close()
+
+
 @pytest.mark.parametrize("H,W,B,gain", [(416, 416, 3, 1.0), (96, 96, 2, 1.0), (320, 416, 2, 1.0), (240, 320, 2, 1.6),
                                          (112, 64, 1, 2.5), (320, 608, 1, 1.0), (416, 416, 2, 3.0)])   # W = 608: input rows wider than 8 DMA pieces (convpx)
 def test_fused_front_end_equals_layer_launches(H, W, B, gain):

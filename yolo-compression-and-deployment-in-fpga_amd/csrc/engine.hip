@@ -54,6 +54,7 @@ struct Layer {
     std::vector<int32_t> q_b;
     int8_t *w_dev = nullptr;
     int8_t *wpx_dev = nullptr;      // conv3_1 .. conv4_2: the same weights in convpx.hip's fragment order
+    int8_t *wpair_dev = nullptr;    // conv3_1: the same weights in pxpair.hip's fragment order (fused conv3_1 -> conv3_2 + pool)
     long long wabs = 0;             // max over output channels of sum |q_w| (0: not loaded): the tight bound of |acc| / 127
     int *bias_dev = nullptr;
     long long *bias_w_dev = nullptr;
@@ -75,6 +76,8 @@ int y355_prepare_kernels() {
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(head): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_ring())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(ring): ") + hipGetErrorString((hipError_t)e));
+    if (int e = y355_prepare_pair3())
+        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(pair3): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_px())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(px): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_convg())
@@ -187,6 +190,8 @@ struct y355_engine {
     int stamp_layer = -1;
     int profile = 0;
     int fuse_front = 1;             // conv1 + pool1 + conv2 + pool2 as one launch (front.hip) where eligible
+    int fuse_pairs = 1;             // conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip) where eligible
+    int l2_batch = 0;               // images of conv3_1's map that the last launches left valid in L[2].out_dev (the fused pair writes none)
     int l0_batch = 0;               // images of conv1's pooled map that the last launches left valid in L[0].out_dev (the fused
                                     // front end keeps that map on chip: 0 after a fused forward)
     int ring_wgs = 0;               // persistent workgroups per ring launch (0 = one per CU)
@@ -330,6 +335,7 @@ extern "C" int y355_set_option(y355_engine *h, int option, int value) {
     if (!h) return fail(Y355_EINVAL, "null engine");
     switch (option) {
     case Y355_OPT_FUSE_FRONT: h->fuse_front = value ? 1 : 0; return 0;
+    case Y355_OPT_FUSE_PAIRS: h->fuse_pairs = value ? 1 : 0; return 0;
     case Y355_OPT_RING_WORKGROUPS:
         if (value < 0 || value > 4096) return fail(Y355_EINVAL, "workgroups per launch out of range");
         h->ring_wgs = value;
@@ -393,6 +399,14 @@ extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const
             }
             HIPCHK(hipMemcpy(L.wpx_dev, px.data(), px.size(), hipMemcpyHostToDevice));
         }
+    }
+    if (idx == 2 && cin == 32 && cout == 64) {
+        std::vector<int8_t> pw(y355_pair3_packed_bytes());
+        y355_pack_pair3(q_w, pw.data());
+        if (!L.wpair_dev) {
+            if (int rc = dmalloc(h, (void **)&L.wpair_dev, pw.size(), false)) return rc;
+        }
+        HIPCHK(hipMemcpy(L.wpair_dev, pw.data(), pw.size(), hipMemcpyHostToDevice));
     }
     L.q_b.assign(q_b, q_b + cout);
     L.e_w = e_w;
@@ -515,6 +529,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
 #else
         constexpr int no_ring_mask = 0, no_px_mask = 0;
 #endif
+        if (k == 2 && mode == 0) h->l2_batch = B;
         if (L.wpx_dev && !((no_px_mask >> k) & 1)) {
             ConvParams q = p;
             q.w = L.wpx_dev;
@@ -581,6 +596,9 @@ extern "C" int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst)
     if (idx == 0 && batch > h->l0_batch)
         return fail(Y355_ENOTREADY, "conv1's map of the last forward was not written (fused front end): "
                                     "run with y355_set_option(h, Y355_OPT_FUSE_FRONT, 0) to tap it");
+    if (idx == 2 && batch > h->l2_batch)
+        return fail(Y355_ENOTREADY, "conv3_1's map of the last forward was not written (fused conv3_1 -> conv3_2 + pool): "
+                                    "run with y355_set_option(h, Y355_OPT_FUSE_PAIRS, 0) to tap it");
     const Layer &L = h->L[idx];
     const int Hp = L.Hout + 2 * L.halo, Wp = L.Wout + 2 * L.halo, CS = L.cout_pad;
     std::vector<int8_t> tmp((size_t)batch * Hp * Wp * CS);
@@ -670,6 +688,38 @@ int y355_zero_counters(Counters *c, int n, hipStream_t s) {
     return (int)hipGetLastError();                   // a failed launch must not leave the previous forward's counts in place
 }
 
+// conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip): 1 = launched, 0 = not eligible (the caller runs the two layers), < 0 error
+static int launch_pair3(y355_engine *h, int B) {
+    Layer &A = h->L[2], &Bl = h->L[3];
+    if (!A.wpair_dev || !Bl.wpx_dev || A.cin != 32 || A.cout_pad != 64 || Bl.cout_pad != 64 || !Bl.pool || A.pool) return 0;
+#ifdef Y355_EXPERIMENTS
+    static const bool no_pair = getenv("Y355_NO_PAIR3") != nullptr;
+    if (no_pair) return 0;
+#endif
+    PairParams p{};
+    p.in = h->L[1].out_dev;
+    p.out = Bl.out_dev;
+    p.w1 = A.wpair_dev;
+    p.w2 = Bl.wpx_dev;
+    p.bias1 = A.bias_dev;
+    p.bias2 = Bl.bias_dev;
+    p.ctr1 = h->ctr_dev + 2;
+    p.ctr2 = h->ctr_dev + 3;
+    p.rq1 = A.rq;
+    p.rq2 = Bl.rq;
+    p.B = B;
+    p.H = A.Hin;
+    p.W = A.Win;
+    p.grid_limit = h->ring_wgs;
+    h->kev_set[2] = h->kev_set[3] = false;
+    if (h->profile == 2) { p.ev_start = h->kev[2][0]; p.ev_stop = h->kev[2][1]; }
+    if (!y355_launch_pair3(p, h->stream)) return 0;
+    HIPCHK(hipGetLastError());
+    h->kev_set[2] = p.ev_start != nullptr;
+    h->l2_batch = 0;
+    return 1;
+}
+
 // enqueue one forward on `s` (refresh_layer must have run)
 static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
                            int32_t *cls_dev, int32_t *count_dev, bool prof) {
@@ -678,6 +728,7 @@ static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int fl
     // the fused front end covers the 32-bit epilogue without the head-room guard; conv2's packed weights must be the
     // resident-weight layout (one n-block of 32 channels), which they are for this network
     const bool fused = h->fuse_front && !guard && y355_front_eligible(h->L[0].rq, h->L[1].rq) && h->L[1].cout_pad == 32;
+    bool pair3 = false;
     for (int k = 0; k < 10; ++k) {
         if (prof) HIPCHK(hipEventRecord(h->ev[k], h->stream));
         if (fused && k == 0) {
@@ -686,6 +737,13 @@ static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int fl
             continue;
         }
         if (fused && k == 1) continue;                    // timer slot 1 reads ~0: slot 0 holds conv1 + conv2
+        if (k == 2 && h->fuse_pairs && !guard) {          // conv3_1 -> conv3_2 + pool3 in one launch; slot 3 then reads ~0
+            const int rc = launch_pair3(h, batch);
+            if (rc < 0) return rc;
+            pair3 = rc == 1;
+            if (pair3) continue;
+        }
+        if (pair3 && k == 3) continue;
         if (int rc = launch_layer(h, k, batch, 0, guard, x_dev)) return rc;
     }
     if (prof) HIPCHK(hipEventRecord(h->ev[10], h->stream));

@@ -1,0 +1,477 @@
+// yolo355 -- conv3_1 -> conv3_2 + pool3 of the q_bf path in ONE launch (models/slim_yolo_v2.py:246-267: conv3_1, a_tracker3_1,
+// conv3_2, a_tracker3_2, pool3 are a straight chain with no other consumer; the FPGA's conv_normal calls 3 and 4,
+// c_embedding/yolo_forward.c:1214-1225).  Round 5.
+//
+// convpx.hip runs the two layers as two launches: conv3_1's 64-channel map (44 MB at B = 64) goes out to HBM and comes back
+// through an LDS-DMA ring, and each launch pays its own weights-into-registers prologue and drain.  Here a workgroup owns a
+// BAND of pooled output rows of one image and alternates two phases per step of <= 4 pooled rows:
+//   A  conv3_1 for the 2 x rows + 2 rows of its map the step needs (8 new rows per step; a band recomputes one row above and
+//      one below itself), straight into an LDS ring of 16 map rows -- int8, requantised, exactly the bytes the unfused path
+//      stores; the map never exists in HBM;
+//   B  conv3_2 + 2x2 max-pool over those rows (convpx's pooled form: the 4x4 neighbourhood of a window read once and fed to
+//      the four conv outputs of the window), stored to HBM.
+// Every wave does both phases (no producer / consumer roles: the wave-role microbenchmark of this round says a SIMD gains
+// nothing from them) and keeps BOTH layers' weights of its 32-channel block in registers: 10 + 18 fragments = 112 VGPRs.
+//
+// Layouts this kernel owns on both sides, so they are built for its access patterns:
+//   * the map ring is PLANAR: a row is four planes of 16-byte chunks (plane c = channels 16 c .. 16 c + 15 of every pixel),
+//     slot of padded column x = x ^ ((x >> 4) & 1).  Phase B's lanes (16 windows = every second pixel, one chunk each) and
+//     phase A's (16 consecutive pixels) both touch 16 distinct 16-byte bank groups: no LDS bank conflicts (convpx's pooled
+//     layers, whose rows arrive by LDS-DMA as whole 64-byte pixels, measure 0.50);
+//   * phase A walks ROWS: a wave takes consecutive 16-pixel groups of a row, so every LDS address is (per-row VGPR) +
+//     immediate -- 5 vector adds per row instead of ~70 address instructions per group in convpx's flat walk;
+//   * input rows (32-byte pixels) arrive by LDS-DMA into a ring of 12 rows, one step ahead: the rows of step s + 1 are issued
+//     behind the barrier that ends phase A of step s and have all of phase B to land; the step boundary waits with a counted
+//     vmcnt that leaves phase B's own output stores in flight.
+// Epilogues: front.hip's fp32 form on exact integers, FOLD 1 / 2 per layer; the hot passes do not clamp and
+// track the LeakyReLU branches' extremes, a cold pass redoes a wave's share of the phase clamped and counts (per layer, and for
+// conv3_1 only on the rows the band owns) when a value left [-127, 127].  Integer semantics bit for bit those of convpx.hip.
+#include "y355_common.h"
+#include <cstring>
+#include <type_traits>
+
+namespace {
+constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23
+constexpr float QLO = 12582785.0f, QHI = 12583039.0f;
+constexpr int RMID = 16;                             // map ring, rows (power of two: phase B's lanes mask)
+constexpr int RIN = 12;                              // input ring, rows (scalar modulo)
+constexpr int PBMAX = 4;                             // pooled rows per step: 2 * 4 + 2 = 10 map rows live <= RMID; a band's first step reads 12 input rows <= RIN
+constexpr int NGMAX = 7;                             // 16-pixel groups per map row: W <= 112
+
+__device__ __forceinline__ void qglds16(const void *g, void *lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+__device__ __forceinline__ float qvmax(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float qvmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float qvmin3(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <int B>
+__device__ __forceinline__ void qmax_to_byte(unsigned int &w, float a, float b) {
+    if constexpr (B == 0)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 1)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else if constexpr (B == 2)
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+    else
+        asm("v_max_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ unsigned int qpack4(float a, float b, float c, float d) {
+    const unsigned int ab = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x0c0c0400u);
+    const unsigned int cd = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x04000c0cu);
+    return ab | cd;
+}
+__device__ __forceinline__ void qwait_vmcnt(int n) {              // s_waitcnt needs an immediate; n is wave-uniform
+#define QW_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        QW_CASE(0) QW_CASE(1) QW_CASE(2) QW_CASE(3) QW_CASE(4) QW_CASE(5) QW_CASE(6) QW_CASE(7) QW_CASE(8)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef QW_CASE
+}
+// the fp32 epilogue's constants of one layer (VGPR operands: an SGPR source takes a vector instruction off the fast issue path)
+struct Epi {
+    float sp, sn, cp, cn;
+};
+template <int FOLD>
+__device__ __forceinline__ Epi make_epi(const Requant &rq) {
+    const float s_pos = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, rq.lk - rq.sh))));
+    const float s_neg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)rq.neg_mul * ldexpf(1.0f, -rq.sh))));
+    Epi e;
+    e.sp = s_pos;
+    e.sn = s_neg;
+    e.cp = FOLD == 2 ? MAGIC - MAGIC * s_pos : MAGIC;
+    e.cn = FOLD == 2 ? MAGIC - MAGIC * s_neg : MAGIC;
+    asm volatile("" : "+v"(e.sp), "+v"(e.sn), "+v"(e.cp), "+v"(e.cn));
+    return e;
+}
+}  // namespace
+
+template <int F1, int F2>
+__global__ __launch_bounds__(512, 2) void pxpair3_kernel(const PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave & 1, ps = wave >> 1;            // 32-channel block of both layers; pixel / window stream 0 .. 3
+    const int li = lane & 15, g = lane >> 4;
+    const int H = p.H, W = p.W, Ho = H >> 1, Wo = W >> 1;
+    const int NG = (W + 15) >> 4;                        // 16-pixel groups per map row
+    const int MS = W + 2, PLANE = MS * 16, MPITCH = 4 * PLANE;
+    const int PPR = (W + 2 + 31) >> 5, IPITCH = PPR * 1024;
+    char *const mid = smem;                              // [RMID][4 planes][MS] 16-byte chunks
+    char *const inp = smem + RMID * MPITCH;              // [RIN][PPR] 1 KiB pieces of 32 pixels x 32 bytes
+
+    // ---- both layers' weights of this wave's channel block: A fragments, registers for the whole launch
+    v4i wf1[5][2], wf2[9][2];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) wf1[ks][n] = *(const v4i *)(p.w1 + ((size_t)(cb * 5 + ks) * 2 + n) * 1024 + lane * 16);
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) wf2[ks][n] = *(const v4i *)(p.w2 + ((size_t)(cb * 9 + ks) * 2 + n) * 1024 + lane * 16);
+    // accumulator register r of n-tile n of lane group g = channel 32 cb + 8 g + 4 n + r (convpx.hip, NTN = 2)
+    v4i cin1[2], cin2[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const v4i b1 = *(const v4i *)(p.bias1 + cb * 32 + 8 * g + 4 * n), b2 = *(const v4i *)(p.bias2 + cb * 32 + 8 * g + 4 * n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cin1[n][r] = F1 == 2 ? b1[r] + 0x4B400000 : b1[r];
+            cin2[n][r] = F2 == 2 ? b2[r] + 0x4B400000 : b2[r];
+        }
+    }
+    const Epi e1 = make_epi<F1>(p.rq1), e2 = make_epi<F2>(p.rq2);
+    const float invWo = 1.0f / (float)Wo;
+
+    // ---- lane constants of phase A.  k-step ks of conv3_1 = taps 2 ks, 2 ks + 1 (lane groups 0-1 / 2-3; tap 9 multiplies zero
+    // weights and reads tap 8's bytes), 16 channels per lane: byte offset inside an input row of the lane's operand for pixel li
+    // of group 0 (group k adds 512).  Only k-step 1 (taps 2 | 3) reads different rows in the two lane halves.
+    int cl[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int tap = min(2 * ks + (g >> 1), 8);
+        cl[ks] = (li + tap % 3) * 32 + 16 * (g & 1);
+    }
+    // the map ring's slot of padded column xp = 16 k + li + 1 is xp ^ ((xp >> 4) & 1): for even / odd k
+    //   li <= 14: 16 k + (li + 1) / 16 k + ((li + 1) ^ 1);   li = 15: 16 k + 17 / 16 k + 16
+    // byte offset inside a map row of this lane's 8 channels (chunk 2 cb + (g >> 1), half g & 1) of group 0's pixel, k even / odd
+    int wc[2];
+    wc[0] = (2 * cb + (g >> 1)) * PLANE + 8 * (g & 1) + 16 * (li < 15 ? li + 1 : 17);
+    wc[1] = (2 * cb + (g >> 1)) * PLANE + 8 * (g & 1) + 16 * (li < 15 ? ((li + 1) ^ 1) : 16);
+    const bool lastok = 16 * (NG - 1) + li < W;          // the row's last group: lanes past the row's end store nothing
+
+    // ---- the ring starts as zeros: the halo columns (slots of padded columns 0 and W + 1) are never written afterwards
+    for (int i = tid * 16; i < RMID * MPITCH; i += 512 * 16) *(v4i *)(mid + i) = (v4i){0, 0, 0, 0};
+
+    // absolute padded input rows [ra, rb) of image b -> ring slots row % RIN; piece q = 32 pixels of one row, by wave q % 8
+    auto dma_rows = [&](int b, int ra, int rb) {
+        const int np = (rb - ra) * PPR;
+        int n = 0;
+        for (int q = wave; q < np; q += 8) {
+            const int rr = q / PPR, pc = q - rr * PPR, row = ra + rr;
+            const int px = min(pc * 32 + (lane >> 1), W + 1);
+            const int8_t *src = p.in + ((size_t)(b * (H + 2) + row) * (W + 2) + px) * 32 + (lane & 1) * 16;
+            qglds16(src, inp + (row % RIN) * IPITCH + pc * 1024);
+            ++n;
+        }
+        return n;
+    };
+
+    const int G_ = gridDim.x, Rtot = p.B * Ho;
+    const int rbeg = (int)((long long)Rtot * blockIdx.x / G_), rend = (int)((long long)Rtot * (blockIdx.x + 1) / G_);
+    unsigned int nsat1 = 0, nsat2 = 0;
+    for (int r0 = rbeg; r0 < rend;) {
+        // ---- one band: pooled rows [j0, j1) of image b
+        const int b = r0 / Ho, j0 = r0 - b * Ho, j1 = min(Ho, j0 + (rend - r0));
+        const int nrows = j1 - j0, nsteps = (nrows + PBMAX - 1) / PBMAX;
+        r0 += nrows;
+        int js = j0, je = j0 + nrows / nsteps;
+        int in_hi;                                       // input rows below in_hi are in the ring or in flight
+        {
+            const int pa = max(2 * js, 1), pb = min(2 * je + 2, H + 1);       // map rows (padded) the first step computes
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // everybody is done with the previous band's rings (and the zero fill)
+            dma_rows(b, pa - 1, pb + 1);
+            in_hi = pb + 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        int8_t *const outb = p.out + (((size_t)b * (Ho + 2) + 1) * (Wo + 2) + 1) * 64 + cb * 32;     // wave-uniform
+        for (int s = 0; s < nsteps; ++s) {
+            je = j0 + nrows * (s + 1) / nsteps;
+            // ================= phase A: map rows [PA, PB) (padded) into the ring; rows 0 and H + 1 are the map's zero halo
+            const int PA = s == 0 ? 2 * js : 2 * js + 2, PB = 2 * je + 2;
+            if (PA == 0 && tid * 16 < MPITCH) *(v4i *)(mid + tid * 16) = (v4i){0, 0, 0, 0};
+            if (PB == H + 2 && tid * 16 < MPITCH) *(v4i *)(mid + ((H + 1) & (RMID - 1)) * MPITCH + tid * 16) = (v4i){0, 0, 0, 0};
+            const int pa = max(PA, 1), pb = min(PB, H + 1);
+            const int N = (pb - pa) * NG;                // (row, group) items, row-major; stream ps takes a contiguous quarter
+            const int it0 = N * ps / 4, it1 = N * (ps + 1) / 4;
+            float ymx = MAGIC, ymn = MAGIC;
+            auto phase_a = [&](auto coldc) {
+                constexpr bool COLD = decltype(coldc)::value;
+                for (int row = it0 / NG; row * NG < it1; ++row) {
+                    const int P = pa + row;
+                    const int kb = max(it0 - row * NG, 0), ke = min(it1 - row * NG, NG);
+                    // conv3_1's output row P - 1 reads padded input rows P - 1, P, P + 1
+                    const int rb0 = ((P - 1) % RIN) * IPITCH, rb1 = (P % RIN) * IPITCH, rb2 = ((P + 1) % RIN) * IPITCH;
+                    const int a0 = rb0 + cl[0], a1 = (g < 2 ? rb0 : rb1) + cl[1], a2 = rb1 + cl[2], a3 = rb2 + cl[3], a4 = rb2 + cl[4];
+                    const int wrow = (P & (RMID - 1)) * MPITCH;
+                    const int w0 = wrow + wc[0], w1 = wrow + wc[1];
+                    const bool owned = P >= 2 * j0 + 1 && P < 2 * j1 + 1;      // the rows above / below belong to the neighbouring bands
+#pragma unroll
+                    for (int k = 0; k < NGMAX; ++k) {
+                        if (k < kb || k >= ke) continue;                       // wave-uniform
+                        v4i bq[5];
+                        bq[0] = *(const v4i *)(inp + a0 + k * 512);
+                        bq[1] = *(const v4i *)(inp + a1 + k * 512);
+                        bq[2] = *(const v4i *)(inp + a2 + k * 512);
+                        bq[3] = *(const v4i *)(inp + a3 + k * 512);
+                        bq[4] = *(const v4i *)(inp + a4 + k * 512);
+                        v4i acc[2] = {cin1[0], cin1[1]};
+#pragma unroll
+                        for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) acc[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf1[ks][n], bq[ks], acc[n], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);     // every read of the group, then its MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+                        unsigned int word[2];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            float pos[4], neg[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float tf = F1 == 2 ? __int_as_float(acc[n][r]) : (float)acc[n][r];
+                                pos[r] = fmaf(tf, e1.sp, e1.cp);
+                                neg[r] = fmaf(tf, e1.sn, e1.cn);
+                            }
+                            if constexpr (!COLD) {
+                                ymx = qvmax3(qvmax3(ymx, pos[0], pos[1]), pos[2], pos[3]);
+                                ymn = qvmin3(qvmin3(ymn, neg[0], neg[1]), neg[2], neg[3]);
+                                qmax_to_byte<0>(word[n], pos[0], neg[0]);
+                                qmax_to_byte<1>(word[n], pos[1], neg[1]);
+                                qmax_to_byte<2>(word[n], pos[2], neg[2]);
+                                qmax_to_byte<3>(word[n], pos[3], neg[3]);
+                            } else {
+                                float yc[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float y = qvmax(pos[r], neg[r]);
+                                    yc[r] = __builtin_amdgcn_fmed3f(y, QLO, QHI);
+                                    nsat1 += (owned && 16 * k + li < W && y != yc[r]) ? 1u : 0u;
+                                }
+                                word[n] = qpack4(yc[0], yc[1], yc[2], yc[3]);
+                            }
+                        }
+                        if (k < NG - 1 || lastok) *(uint2 *)(mid + ((k & 1) ? w1 : w0) + k * 256) = make_uint2(word[0], word[1]);
+                    }
+                }
+            };
+            phase_a(std::false_type{});
+            if (__builtin_amdgcn_ballot_w64(ymx > QHI || ymn < QLO) != 0ull) phase_a(std::true_type{});    // cold: same rows, clamped
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- the next step's new input rows: in flight under phase B (phase A is done with every row but the last two)
+            if (s + 1 < nsteps) {
+                const int je2 = j0 + nrows * (s + 2) / nsteps, pb2 = min(2 * je2 + 2, H + 1);
+                dma_rows(b, in_hi, pb2 + 1);
+                in_hi = pb2 + 1;
+            }
+            // ================= phase B: conv3_2 + pool over the step's windows, flat in groups of 16, stream ps takes every 4th
+            const int nwin = (je - js) * Wo, ngb = (nwin + 15) >> 4;
+            float zmx = MAGIC, zmn = MAGIC;
+            auto locate = [&](int grp, int &oyr, int &ox) {
+                const int wi = min(grp * 16 + li, nwin - 1);           // padding lanes of the step's last group repeat its last window
+                oyr = (int)(((float)wi + 0.5f) * invWo);               // wi / Wo (exact: wi < 2^16)
+                ox = wi - oyr * Wo;
+            };
+            auto issue = [&](int grp, v4i (&acc)[4][2]) {
+                int oyr, ox;
+                locate(grp, oyr, ox);
+                const int ar = 2 * (js + oyr), x0 = 2 * ox;            // padded map row / column of the neighbourhood's corner
+                int xoff[4], roff[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int x = x0 + c;
+                    xoff[c] = g * PLANE + ((x ^ ((x >> 4) & 1)) << 4);
+                    roff[c] = ((ar + c) & (RMID - 1)) * MPITCH;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[v][n] = cin2[n];
+                // neighbourhood row r feeds conv output (dy, dx) with filter tap (r - dy, c - dx); order pinned as in convpx.hip:
+                // rows 0 and 1 are read, then row r's MFMAs run over the reads of row r + 2
+                v4i bq[4][4];
+                auto rd = [&](int r) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bq[r][c] = *(const v4i *)(mid + roff[r] + xoff[c]);
+                };
+                auto mm = [&](int r) {
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int ty = r - dy;
+                        if (ty < 0 || ty > 2) continue;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int tx = c - dx;
+                                if (tx < 0 || tx > 2) continue;
+#pragma unroll
+                                for (int n = 0; n < 2; ++n)
+                                    acc[2 * dy + dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf2[ty * 3 + tx][n], bq[r][c], acc[2 * dy + dx][n], 0, 0, 0);
+                            }
+                    }
+                };
+                rd(0);
+                rd(1);
+                mm(0);
+                rd(2);
+                mm(1);
+                rd(3);
+                mm(2);
+                mm(3);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
+            };
+            auto finish = [&](int grp, const v4i (&acc)[4][2], auto coldc) {
+                constexpr bool COLD = decltype(coldc)::value;
+                int oyr, ox;
+                locate(grp, oyr, ox);
+                unsigned int word[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    float pos[4], neg[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = max(max(acc[0][n][r], acc[1][n][r]), max(acc[2][n][r], acc[3][n][r]));
+                        const float tf = F2 == 2 ? __int_as_float(m) : (float)m;
+                        pos[r] = fmaf(tf, e2.sp, e2.cp);
+                        neg[r] = fmaf(tf, e2.sn, e2.cn);
+                    }
+                    if constexpr (!COLD) {
+                        zmx = qvmax3(qvmax3(zmx, pos[0], pos[1]), pos[2], pos[3]);
+                        zmn = qvmin3(qvmin3(zmn, neg[0], neg[1]), neg[2], neg[3]);
+                        qmax_to_byte<0>(word[n], pos[0], neg[0]);
+                        qmax_to_byte<1>(word[n], pos[1], neg[1]);
+                        qmax_to_byte<2>(word[n], pos[2], neg[2]);
+                        qmax_to_byte<3>(word[n], pos[3], neg[3]);
+                    } else {
+                        float yc[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float y = qvmax(pos[r], neg[r]);
+                            yc[r] = __builtin_amdgcn_fmed3f(y, QLO, QHI);
+                            nsat2 += (grp * 16 + li < nwin && y != yc[r]) ? 1u : 0u;
+                        }
+                        word[n] = qpack4(yc[0], yc[1], yc[2], yc[3]);
+                    }
+                }
+                // unconditional: the padding lanes rewrite the step's last window with the same bytes, so the number of stores a wave
+                // has in flight is a function of its group count (the counted wait below)
+                int8_t *dst = outb + (((js + oyr) * (Wo + 2) + ox) * 64 + 8 * g);
+                *(uint2 *)dst = make_uint2(word[0], word[1]);
+            };
+            int nstores = 0;
+            {
+                v4i acc[4][2];
+#pragma unroll 1
+                for (int grp = ps; grp < ngb; grp += 4) {
+                    issue(grp, acc);
+                    finish(grp, acc, std::false_type{});
+                    ++nstores;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(zmx > QHI || zmn < QLO) != 0ull) {   // cold: the rows are still in the ring
+                v4i accC[4][2];
+#pragma unroll 1
+                for (int grp = ps; grp < ngb; grp += 4) {
+                    issue(grp, accC);
+                    finish(grp, accC, std::true_type{});
+                }
+                nstores = -1;
+            }
+            // the next step's input rows were issued BEFORE this phase's stores: a counted wait leaves the stores in flight
+            qwait_vmcnt(nstores);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            js = je;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsat1) atomicAdd(&p.ctr1->sat, (unsigned long long)nsat1);
+    if (nsat2) atomicAdd(&p.ctr2->sat, (unsigned long long)nsat2);
+}
+
+// ------------------------------------------------------------------------------------------
+size_t y355_pair3_packed_bytes(void) { return (size_t)2 * 5 * 2 * 1024; }
+
+// conv3_1's weights q_w [64][32][3][3] in this kernel's fragment order (convpx.hip's with 16 NTN = 32 channels per block):
+// fragment ((cb * 5 + ks) * 2 + n), lane (i = l & 15, g = l >> 4), 16 bytes: row i = output channel 32 cb + 8 (i >> 2) + 4 n + (i & 3),
+// k = tap 2 ks + (g >> 1) (tap 9: zeros), input channels 16 (g & 1) .. + 15
+void y355_pack_pair3(const int8_t *q_w, int8_t *dst) {
+    memset(dst, 0, y355_pair3_packed_bytes());
+    for (int cb = 0; cb < 2; ++cb)
+        for (int ks = 0; ks < 5; ++ks)
+            for (int n = 0; n < 2; ++n)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, g = l >> 4;
+                    const int ch = cb * 32 + 8 * (i >> 2) + 4 * n + (i & 3);
+                    const int tap = 2 * ks + (g >> 1), c0 = 16 * (g & 1);
+                    if (tap > 8) continue;
+                    for (int kk = 0; kk < 16; ++kk)
+                        dst[(((size_t)cb * 5 + ks) * 2 + n) * 1024 + l * 16 + kk] = q_w[((size_t)ch * 32 + c0 + kk) * 9 + tap];
+                }
+}
+
+namespace {
+size_t pair_lds(int W) {
+    const int MPITCH = 4 * (W + 2) * 16, IPITCH = ((W + 2 + 31) >> 5) * 1024;
+    return (size_t)RMID * MPITCH + (size_t)RIN * IPITCH;
+}
+int fold_of(const Requant &rq) {
+    if (rq.shl != 0) return 0;
+    return (rq.tmax_log2 <= 22 && rq.sh <= 22 && rq.sh - rq.lk >= -8) ? 2 : 1;
+}
+template <int F1, int F2>
+void launch_(const PairParams &p, int grid, size_t lds, hipStream_t s) {
+    PairParams q = p;
+    q.ev_start = q.ev_stop = nullptr;
+    Y355_LAUNCH((pxpair3_kernel<F1, F2>), dim3(grid), dim3(512), lds, s, p.ev_start, p.ev_stop, q);
+}
+}  // namespace
+
+int y355_prepare_pair3(void) {
+    int e = (int)hipFuncSetAttribute((const void *)pxpair3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!e) e = (int)hipFuncSetAttribute((const void *)pxpair3_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!e) e = (int)hipFuncSetAttribute((const void *)pxpair3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!e) e = (int)hipFuncSetAttribute((const void *)pxpair3_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+}
+
+// what the two layers' own launches would have to be for the fused one to stand in: plain runs on the fp32-exact epilogue
+// with the accumulator shift 0, a map narrow enough for the two rings
+bool y355_pair3_eligible(const Requant &rq1, const Requant &rq2, int H, int W) {
+    for (const Requant *rq : {&rq1, &rq2}) {
+        if (rq->wide || rq->tmax_log2 > 24 || fold_of(*rq) == 0) return false;
+        if (rq->neg_mul < 0 || rq->neg_mul > (1 << rq->lk)) return false;
+    }
+    if ((H | W) & 1 || W < 16 || W > 16 * NGMAX || H < 2) return false;
+    return pair_lds(W) <= 160 * 1024;
+}
+
+// false = not available for this launch: the caller runs the two layers' own launches
+bool y355_launch_pair3(const PairParams &p, hipStream_t s) {
+    if (!y355_pair3_eligible(p.rq1, p.rq2, p.H, p.W)) return false;
+    if ((long long)p.B * (p.H + 2) * (p.W + 2) * 32 >= (1ll << 31)) return false;      // 32-bit row arithmetic
+    const int total = p.B * (p.H / 2);
+    int grid = 256;                                                // one 8-wave workgroup per CU
+    if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;
+    if (grid > total) grid = total;
+    const size_t lds = pair_lds(p.W);
+    const int f1 = fold_of(p.rq1), f2 = fold_of(p.rq2);
+    if (f1 == 2 && f2 == 2) launch_<2, 2>(p, grid, lds, s);
+    else if (f1 == 2) launch_<2, 1>(p, grid, lds, s);
+    else if (f2 == 2) launch_<1, 2>(p, grid, lds, s);
+    else launch_<1, 1>(p, grid, lds, s);
+    return true;
+}

@@ -249,6 +249,25 @@ bool y355_launch_conv_px(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_px(void);
 size_t y355_px_packed_bytes(int kid);           // 0: the layer has no such kernel
 bool y355_pack_px(int kid, const int8_t *q_w, int cout, int cin, int8_t *dst);
+// conv3_1 -> conv3_2 + pool in one launch (pxpair.hip): conv3_1's map stays in LDS
+struct PairParams {
+    const int8_t *in;     // conv3_1's input: int8 NHWC32 with halo [B][H+2][W+2][32]
+    int8_t *out;          // conv3_2's pooled output: int8 NHWC64 with halo [B][H/2+2][W/2+2][64]
+    const int8_t *w1;     // conv3_1's weights, y355_pack_pair3 layout
+    const int8_t *w2;     // conv3_2's weights, y355_pack_px(Y355_K_CONV3_2) layout
+    const int *bias1;     // [64]
+    const int *bias2;     // [64]
+    Counters *ctr1, *ctr2;
+    Requant rq1, rq2;
+    int B, H, W;          // conv3_1's map (= its input's size, unpadded)
+    void *ev_start, *ev_stop;     // host side only: see ConvParams
+    int grid_limit;       // host side only: persistent workgroups per launch (0 = one per CU)
+};
+bool y355_pair3_eligible(const Requant &rq1, const Requant &rq2, int H, int W);
+bool y355_launch_pair3(const PairParams &p, hipStream_t s);      // false: not eligible, run the two layers' own launches
+int y355_prepare_pair3(void);
+size_t y355_pair3_packed_bytes(void);
+void y355_pack_pair3(const int8_t *q_w /*[64][32][3][3]*/, int8_t *dst);
 // deep-prefetch ring kernels (conv3x3_ring.hip), layers with >= 64 input channels
 bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_ring(void);

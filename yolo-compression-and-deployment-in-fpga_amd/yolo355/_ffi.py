@@ -18,6 +18,7 @@ F_GUARD, F_TAP = 1, 2
 OP_LEAKY, OP_POOL, OP_RELU = 1, 2, 4
 OPT_FUSE_FRONT = 1
 OPT_RING_WORKGROUPS = 2
+OPT_FUSE_PAIRS = 3
 NET_OPT_WORKGROUPS = 1
 EINVAL, EHIP, ENOTREADY = -1, -2, -3
 
