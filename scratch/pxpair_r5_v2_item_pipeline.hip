@@ -36,7 +36,7 @@ constexpr float QLO = 12582785.0f, QHI = 12583039.0f;
 constexpr int RMID = 16;                             // map ring, rows (power of two: phase B's lanes mask)
 constexpr int RIN = 12;                              // input ring, rows (scalar modulo)
 constexpr int NGMAX = 7;                             // 16-pixel groups per map row: W <= 112
-constexpr int SROWS = 4;                             // pooled rows per step of a band
+constexpr int SGRP = 12;                             // groups of 16 windows per step of a band
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));     // (a uint2 store into LDS gets an s_waitcnt vmcnt(0) in front of it: the
                                                                   // compiler cannot tell it from an LDS-DMA destination; an ext_vector store does not)
 
@@ -192,11 +192,9 @@ __global__ __launch_bounds__(512, 2) void pxpair3_kernel(const PairParams p) {
     const int G_ = gridDim.x, Rtot = p.B * Ho;
     const int rbeg = (int)((long long)Rtot * blockIdx.x / G_), rend = (int)((long long)Rtot * (blockIdx.x + 1) / G_);
     unsigned int nsat1 = 0, nsat2 = 0;
-    // A band = pooled rows [j0, j1) of image b, walked in steps of SROWS = 4 pooled rows: phase A adds the 8 map rows they need
-    // (whole rows, two per wave of a channel block; 10 in a band's first step), phase B takes the band's windows, flat and
-    // row-major, in groups of 16 -- a multiple of four groups per step (one to four windows' worth of groups wait for the next
-    // step), so that both phases are balanced over the four streams.  At most 12 map rows are live in the ring of 16, at most 12
-    // input rows in the ring of 12.
+    // A band = pooled rows [j0, j1) of image b.  Its windows, flat and row-major, are walked in steps of SGRP groups of 16 (three
+    // per wave of a channel block: phase B is balanced whatever the row width); a step needs the map rows of the pooled rows its
+    // windows touch: at most 5 = 12 map rows in the ring of 16, of which at most 8 are new = 10 input rows in the ring of 12.
     struct Band { int b, j0, j1; };
     auto band_at = [&](int r0) {
         Band q;
@@ -205,16 +203,22 @@ __global__ __launch_bounds__(512, 2) void pxpair3_kernel(const PairParams p) {
         q.j1 = min(Ho, q.j0 + (rend - r0));
         return q;
     };
+    auto step_rows = [&](const Band &q, int s, int &ya, int &ye) {      // pooled rows [ya, ye) that step s of the band touches
+        const int nwb = (q.j1 - q.j0) * Wo, wlo = s * (16 * SGRP), whi = min(wlo + 16 * SGRP, nwb);
+        ya = q.j0 + wlo / Wo;
+        ye = q.j0 + (whi - 1) / Wo + 1;
+    };
     auto first_rows = [&](const Band &q) {               // input rows of the band's first step: issued one phase B ahead
-        const int je = min(q.j0 + SROWS, q.j1), hi = min(2 * je + 2, H + 1) + 1;
-        dma_rows(q.b, max(2 * q.j0, 1) - 1, hi);
-        return hi;
+        int ya, ye;
+        step_rows(q, 0, ya, ye);
+        dma_rows(q.b, max(2 * ya, 1) - 1, min(2 * ye + 2, H + 1) + 1);
+        return min(2 * ye + 2, H + 1) + 1;
     };
     Band bd = band_at(rbeg);
     int in_hi = first_rows(bd);                          // input rows of the band below in_hi are in the ring or in flight
     for (int r0 = rbeg; r0 < rend;) {
         const int b = bd.b, j0 = bd.j0, j1 = bd.j1;
-        const int nsteps = (j1 - j0 + SROWS - 1) / SROWS;
+        const int nwb = (j1 - j0) * Wo, nsteps = (nwb + 16 * SGRP - 1) / (16 * SGRP);
         r0 += j1 - j0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -222,35 +226,59 @@ __global__ __launch_bounds__(512, 2) void pxpair3_kernel(const PairParams p) {
         stamp();
         int8_t *const outb = p.out + (((size_t)b * (Ho + 2) + 1) * (Wo + 2) + 1) * 64 + cb * 32;     // wave-uniform
         int PA = 2 * j0;                                 // map rows (padded) of this band below PA are in the ring
-        int wdone = 0;                                   // windows of this band already pooled and stored
         for (int s = 0; s < nsteps; ++s) {
-            const int je = min(j0 + SROWS * (s + 1), j1);
+            int ya, ye;
+            step_rows(bd, s, ya, ye);
             // ================= phase A: map rows [PA, PB) (padded) into the ring; rows 0 and H + 1 are the map's zero halo
-            const int PB = 2 * je + 2;
+            const int PB = 2 * ye + 2;
             if (PA == 0 && tid * 16 < MPITCH) *(v4i *)(mid + tid * 16) = (v4i){0, 0, 0, 0};
-            if (PB == H + 2 && tid * 16 < MPITCH) *(v4i *)(mid + ((H + 1) & (RMID - 1)) * MPITCH + tid * 16) = (v4i){0, 0, 0, 0};
+            if (PB == H + 2 && PA < PB && tid * 16 < MPITCH) *(v4i *)(mid + ((H + 1) & (RMID - 1)) * MPITCH + tid * 16) = (v4i){0, 0, 0, 0};
             const int pa = max(PA, 1), pb = min(PB, H + 1);
+            const int N = max(pb - pa, 0) * NG;          // (row, group) items, row-major; stream ps takes a contiguous quarter
+            const int it0 = N * ps / 4, it1 = N * (ps + 1) / 4;
             PA = PB;
             float ymx = MAGIC, ymn = MAGIC;
-            // One row = NG items of 16 pixels, software-pipelined with everything static: the operands of item k + 1 are read, and
-            // item k - 1 is requantised and stored, under the MFMAs of item k; every LDS address is a per-row VGPR + an immediate.
-            // (v1: read -> wait -> 10 MFMAs -> wait -> 32 VALU -> store per item; v2: the same pipeline over a flat item list
-            // with run-time addresses, 60 VALU + 25 SALU per item: both ~440 cycles per item and SIMD for 160 of MFMA --
-            // profiles/r05_notes.md.)
-            auto row_a = [&](int P, auto coldc) {
+            // Software pipeline over the wave's items: the B operands of item i + 1 are read, and item i - 1 is requantised and
+            // stored, under the MFMAs of item i (two operand / accumulator sets).  First version: read -> wait -> 10 MFMAs -> wait ->
+            // 32 VALU -> store per item: 760 cycles per item and wave for 160 of MFMA (phase stamps, profiles/r05_notes.md).
+            auto phase_a = [&](auto coldc) {
                 constexpr bool COLD = decltype(coldc)::value;
-                // conv3_1's output row P - 1 reads padded input rows P - 1, P, P + 1
-                const int rb0 = ((P - 1) % RIN) * IPITCH, rb1 = (P % RIN) * IPITCH, rb2 = ((P + 1) % RIN) * IPITCH;
-                const int a0 = rb0 + cl[0], a1 = (g < 2 ? rb0 : rb1) + cl[1], a2 = rb1 + cl[2], a3 = rb2 + cl[3], a4 = rb2 + cl[4];
-                const int wrow = (P & (RMID - 1)) * MPITCH;
-                const int w0 = wrow + wc[0], w1 = wrow + wc[1];
-                const bool owned = P >= 2 * j0 + 1 && P < 2 * j1 + 1;      // the rows above / below belong to the neighbouring bands
-                auto rd = [&](v4i (&bq)[5], int k) {
-                    bq[0] = *(const v4i *)(inp + a0 + k * 512);
-                    bq[1] = *(const v4i *)(inp + a1 + k * 512);
-                    bq[2] = *(const v4i *)(inp + a2 + k * 512);
-                    bq[3] = *(const v4i *)(inp + a3 + k * 512);
-                    bq[4] = *(const v4i *)(inp + a4 + k * 512);
+                const int n = it1 - it0;
+                if (n <= 0) return;
+                int row = it0 / NG, k = it0 - row * NG;
+                int a0, a1, a2, a3, a4, w0, w1;
+                bool owned;
+                auto setrow = [&]() {
+                    const int P = pa + row;
+                    // conv3_1's output row P - 1 reads padded input rows P - 1, P, P + 1
+                    const int rb0 = ((P - 1) % RIN) * IPITCH, rb1 = (P % RIN) * IPITCH, rb2 = ((P + 1) % RIN) * IPITCH;
+                    a0 = rb0 + cl[0];
+                    a1 = (g < 2 ? rb0 : rb1) + cl[1];
+                    a2 = rb1 + cl[2];
+                    a3 = rb2 + cl[3];
+                    a4 = rb2 + cl[4];
+                    const int wrow = (P & (RMID - 1)) * MPITCH;
+                    w0 = wrow + wc[0];
+                    w1 = wrow + wc[1];
+                    owned = P >= 2 * j0 + 1 && P < 2 * j1 + 1;      // the rows above / below belong to the neighbouring bands
+                };
+                setrow();
+                // the reads of the current item (row, k), where and whether its lanes store / count; then on to the next item
+                auto fetch = [&](v4i (&bq)[5], int &wad, bool &wok, bool &cok) {
+                    const int o = k * 512;
+                    bq[0] = *(const v4i *)(inp + a0 + o);
+                    bq[1] = *(const v4i *)(inp + a1 + o);
+                    bq[2] = *(const v4i *)(inp + a2 + o);
+                    bq[3] = *(const v4i *)(inp + a3 + o);
+                    bq[4] = *(const v4i *)(inp + a4 + o);
+                    wad = ((k & 1) ? w1 : w0) + k * 256;
+                    wok = k < NG - 1 || lastok;
+                    cok = owned && wok;
+                    if (++k == NG) {
+                        k = 0;
+                        ++row;
+                        setrow();
+                    }
                 };
                 // outputs (n, 2 rr) and (n, 2 rr + 1) of an item: the LeakyReLU branches, their extremes, the bytes
                 auto out2 = [&](const v4i (&acc)[2], unsigned int (&word)[2], int n_, int rr, bool cok) {
@@ -282,65 +310,76 @@ __global__ __launch_bounds__(512, 2) void pxpair3_kernel(const PairParams p) {
                         }
                     }
                 };
-                auto wr = [&](int k, const unsigned int (&word)[2]) {        // item k's 8 channels -> the ring
-                    *(v2u *)(mid + ((k & 1) ? w1 : w0) + k * 256) = (v2u){word[0], word[1]};
-                };
-                // the MFMAs of item k (bq -> acc); in their shadow (k > 0) the epilogue of item k - 1 (pacc), which is never the
-                // row's last item here, so all its lanes are real pixels
-                auto stage = [&](int k, const v4i (&bq)[5], v4i (&acc)[2], const v4i (&pacc)[2]) {
+                // the MFMAs of the item in (bq, acc); in their shadow (PREV) the epilogue of the item before it: pacc -> LDS at pwad
+                auto stage = [&](const v4i (&bq)[5], v4i (&acc)[2], auto prevc, const v4i (&pacc)[2], int pwad, bool pwok, bool pcok) {
+                    constexpr bool PREV = decltype(prevc)::value;
                     acc[0] = cin1[0];
                     acc[1] = cin1[1];
                     unsigned int word[2] = {0u, 0u};
 #pragma unroll
                     for (int ks = 0; ks < 5; ++ks) {
 #pragma unroll
-                        for (int n_ = 0; n_ < 2; ++n_) acc[n_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf1[ks][n_], bq[ks], acc[n_], 0, 0, 0);
+                        for (int n_ = 0; n_ < 2; ++n_) {
+                            if (PAIR_ABL & 1) acc[n_] = acc[n_] + bq[ks] + wf1[ks][n_];
+                            else acc[n_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf1[ks][n_], bq[ks], acc[n_], 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
-                        if (k > 0 && ks < 4) {
-                            out2(pacc, word, ks >> 1, ks & 1, owned);                // two MFMAs, two outputs of the item before
+                        if constexpr (PREV) {
+                            if (ks < 4 && !(PAIR_ABL & 2)) out2(pacc, word, ks >> 1, ks & 1, pcok);      // two MFMAs, two outputs of the item before
+                            if (ks < 4 && (PAIR_ABL & 2)) word[ks >> 1] ^= (unsigned int)pacc[ks >> 1][ks & 1];
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (k > 0) wr(k - 1, word);
+                    if constexpr (PREV) {
+                        if (pwok) *(v2u *)(mid + pwad) = (v2u){word[0], word[1]};
+                    }
                 };
-                v4i bq[2][5], acc[2][2];
-                if constexpr (COLD) {                                             // rare: one item at a time
+                auto drain = [&](const v4i (&pacc)[2], int pwad, bool pwok, bool pcok) {      // the last item's epilogue
+                    unsigned int word[2] = {0u, 0u};
 #pragma unroll
-                    for (int k = 0; k < NGMAX; ++k) {
-                        if (k >= NG) break;
-                        rd(bq[0], k);
-                        stage(0, bq[0], acc[0], acc[0]);
-                        unsigned int word[2] = {0u, 0u};
-                        const bool cok = owned && (k + 1 < NG || lastok);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) out2(acc[0], word, q >> 1, q & 1, cok);
-                        if (k + 1 < NG || lastok) wr(k, word);
+                    for (int q = 0; q < 4; ++q) out2(pacc, word, q >> 1, q & 1, pcok);
+                    if (pwok) *(v2u *)(mid + pwad) = (v2u){word[0], word[1]};
+                };
+                v4i bqA[5], accA[2];
+                int wadA = 0;
+                bool wokA = false, cokA = false;
+                if constexpr (COLD) {                                             // rare: one item at a time (fewer live registers)
+                    for (int j = 0; j < n; ++j) {
+                        fetch(bqA, wadA, wokA, cokA);
+                        stage(bqA, accA, std::false_type{}, accA, 0, false, false);
+                        drain(accA, wadA, wokA, cokA);
                     }
                     return;
                 }
-                rd(bq[0], 0);
-#pragma unroll
-                for (int k = 0; k < NGMAX; ++k) {
-                    if (k >= NG) break;                                            // wave-uniform
-                    if (k + 1 < NGMAX && k + 1 < NG) rd(bq[(k + 1) & 1], k + 1);
-                    stage(k, bq[k & 1], acc[k & 1], acc[(k + 1) & 1]);
-                }
-                {   // the row's last item: lanes past the row's end store nothing
-                    unsigned int word[2] = {0u, 0u};
-                    if ((NG - 1) & 1) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) out2(acc[1], word, q >> 1, q & 1, false);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) out2(acc[0], word, q >> 1, q & 1, false);
+                v4i bqB[5], accB[2];
+                int wadB = 0;
+                bool wokB = false, cokB = false;
+                fetch(bqA, wadA, wokA, cokA);                                     // item 0
+                if (n > 1) fetch(bqB, wadB, wokB, cokB);                          // item 1
+                stage(bqA, accA, std::false_type{}, accA, 0, false, false);
+                int j = 1;
+                while (j < n) {
+                    {   // j odd: item j in B, item j - 1 in A (its operand registers take item j + 1)
+                        const int pw = wadA;
+                        const bool po = wokA, pc = cokA;
+                        if (j + 1 < n) fetch(bqA, wadA, wokA, cokA);
+                        stage(bqB, accB, std::true_type{}, accA, pw, po, pc);
+                        ++j;
                     }
-                    if (lastok) *(v2u *)(mid + (((NG - 1) & 1) ? w1 : w0) + (NG - 1) * 256) = (v2u){word[0], word[1]};
+                    if (j >= n) break;
+                    {   // j even: item j in A, item j - 1 in B
+                        const int pw = wadB;
+                        const bool po = wokB, pc = cokB;
+                        if (j + 1 < n) fetch(bqB, wadB, wokB, cokB);
+                        stage(bqA, accA, std::true_type{}, accB, pw, po, pc);
+                        ++j;
+                    }
                 }
+                if ((n - 1) & 1) drain(accB, wadB, wokB, cokB);
+                else drain(accA, wadA, wokA, cokA);
             };
-            if (!(PAIR_ABL & 16))
-                for (int P = pa + ps; P < pb; P += 4) row_a(P, std::false_type{});
-            if (__builtin_amdgcn_ballot_w64(ymx > QHI || ymn < QLO) != 0ull)          // cold: the same rows, clamped and counted
-                for (int P = pa + ps; P < pb; P += 4) row_a(P, std::true_type{});
+            if (!(PAIR_ABL & 16)) phase_a(std::false_type{});
+            if (__builtin_amdgcn_ballot_w64(ymx > QHI || ymn < QLO) != 0ull) phase_a(std::true_type{});    // cold: same rows, clamped
             stamp();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -348,22 +387,17 @@ __global__ __launch_bounds__(512, 2) void pxpair3_kernel(const PairParams p) {
             // ---- the next step's new input rows (or the next band's first ones): in flight under phase B -- phase A is done
             // with every row but the last two, the next band's rows are another image's or further down
             if (s + 1 < nsteps) {
-                const int hi = min(2 * min(j0 + SROWS * (s + 2), j1) + 2, H + 1) + 1;
+                int ya2, ye2;
+                step_rows(bd, s + 1, ya2, ye2);
+                const int hi = min(2 * ye2 + 2, H + 1) + 1;
                 dma_rows(b, in_hi, hi);
                 in_hi = max(in_hi, hi);
             } else if (r0 < rend) {
                 bd = band_at(r0);
                 in_hi = first_rows(bd);
             }
-            // the band's windows that have all their map rows and are not done: a multiple of four groups of 16 now, the rest
-            // (less than a row) with the next step; the band's last step takes what is left
-            // (narrow maps take everything at once: there 63 waiting windows would be more than the two rows the ring has room for)
-            const int avail = (je - j0) * Wo - wdone;
-            const bool all = s + 1 == nsteps || Wo < 32;
-            const int ngb = all ? (avail + 15) >> 4 : ((avail >> 4) & ~3);
-            const int nwin = all ? avail : ngb * 16, wlo = wdone;
-            wdone += nwin;
-            // ================= phase B: conv3_2 + pool over these windows, groups of 16, stream ps takes every 4th
+            // ================= phase B: conv3_2 + pool over the step's windows, groups of 16, stream ps takes every 4th
+            const int wlo = s * (16 * SGRP), nwin = min(16 * SGRP, nwb - wlo), ngb = (nwin + 15) >> 4;
             float zmx = MAGIC, zmn = MAGIC;
             auto locate = [&](int grp, int &oyr, int &ox) {
                 const int wi = wlo + min(grp * 16 + li, nwin - 1);     // padding lanes of the band's last group repeat its last window

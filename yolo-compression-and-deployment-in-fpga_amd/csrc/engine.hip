@@ -711,6 +711,7 @@ static int launch_pair3(y355_engine *h, int B) {
     p.H = A.Hin;
     p.W = A.Win;
     p.grid_limit = h->ring_wgs;
+    p.stamps = (h->stamp_layer == 2) ? h->stamps_dev : nullptr;
     h->kev_set[2] = h->kev_set[3] = false;
     if (h->profile == 2) { p.ev_start = h->kev[2][0]; p.ev_stop = h->kev[2][1]; }
     if (!y355_launch_pair3(p, h->stream)) return 0;

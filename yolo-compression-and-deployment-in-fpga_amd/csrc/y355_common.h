@@ -262,6 +262,7 @@ struct PairParams {
     int B, H, W;          // conv3_1's map (= its input's size, unpadded)
     void *ev_start, *ev_stop;     // host side only: see ConvParams
     int grid_limit;       // host side only: persistent workgroups per launch (0 = one per CU)
+    unsigned long long *stamps;   // diagnostic builds only (-DPAIR_DIAG=1)
 };
 bool y355_pair3_eligible(const Requant &rq1, const Requant &rq2, int H, int W);
 bool y355_launch_pair3(const PairParams &p, hipStream_t s);      // false: not eligible, run the two layers' own launches
