@@ -544,6 +544,9 @@ def main():
     ap.add_argument("--no-fuse-front", action="store_true",
                     help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
+    ap.add_argument("--fuse-pairs", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="A/B: conv3_1 -> conv3_2 + pool3 (Y355_OPT_FUSE_PAIRS): 0 one launch per layer, 1 fused, the layers on different waves of "
+                         "every SIMD (the default), 2 fused, every wave alternating between them; -1 = the engine's default.  Same results")
     ap.add_argument("--gather-max-det", type=int, default=256,
                     help="multi-GPU: detections per image in the all-gather records (SURVEY.md 8e: fixed-cap records, 6.1 KB per image "
                          "at 256; 0 = the engine's max_det, i.e. full records); the per-GPU forward and its outputs are unchanged. "
@@ -613,6 +616,8 @@ def main():
             e.load_quantized(quantized_layers(2))
             if args.no_fuse_front:
                 e.set_option(1, 0)                       # Y355_OPT_FUSE_FRONT
+            if args.fuse_pairs >= 0:
+                e.set_option(3, args.fuse_pairs)         # Y355_OPT_FUSE_PAIRS
         engines.append(e)
     eng = engines[0]
     # calibrate once (first-call semantics, slim_yolo_v2.py:25-27) on the seed-1 image, rank 0;

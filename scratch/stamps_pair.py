@@ -12,6 +12,7 @@ eng = Engine([416,416], 2, synth.ANCHOR_SIZE_MASK, max_batch=B)
 eng.load_quantized(bench.quantized_layers(2))
 eng.calibrate(synth.make_images(1,1,416,416), [prep.RangeTracker() for _ in range(11)])
 if len(sys.argv) > 1: eng.set_option(_ffi.OPT_RING_WORKGROUPS, int(sys.argv[1]))
+if len(sys.argv) > 2: eng.set_option(_ffi.OPT_FUSE_PAIRS, int(sys.argv[2]))
 x = torch.from_numpy(synth.make_images(1000,B,416,416)).cuda()
 lib=_ffi.lib()
 lib.y355_debug_stamps.argtypes=[C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -23,6 +24,13 @@ buf = np.zeros((1024,32), np.uint64)
 lib.y355_debug_stamps(eng._h, -1, buf.ctypes.data, 1024)
 t = buf.astype(np.int64)[:256]
 t = t[t[:, 0] > 0]
+if len(sys.argv) <= 2 or sys.argv[2] == "1":     # role-split kernel (the default): stamps 0-15 of thread 0 (a conv3_1 wave), 16-31 of thread 256 (a conv3_2 wave)
+    t0 = t[:, 0].min()
+    for name, tt in (("conv3_1 wave 0", t[:, :16]), ("conv3_2 wave 4", t[:, 16:])):
+        n = int((tt[0] > 0).sum())
+        d = np.diff(tt[:, :n], axis=1) / 100.0
+        print(name, "stamps", n, "median intervals (us):", np.round(np.median(d, axis=0), 2).tolist(), "last stamp since entry p50 %.2f" % (np.median(tt[:, n - 1] - t[:, 0]) / 100))
+    sys.exit(0)
 n = int((t[0] > 0).sum())
 t0 = t[:, 0].min()
 print("workgroups", len(t), "stamps per workgroup:", n, " kernel span (us): %.2f" % ((t[:, :n].max() - t0) / 100.0))

@@ -404,12 +404,17 @@ def test_fused_pairs_equal_layer_launches(H, W, B, gain, bump):
     x = synth.normalize_frames(frames) * np.float32(gain)
     r = O.detect(x, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2, saturate=True, keep=True)
     res = {}
-    for fuse in (1, 0):
+    for fuse in (1, 2, 0):                       # 1: the layers on different waves of every SIMD (production); 2: every wave alternates between them
         eng.set_option(_ffi.OPT_FUSE_PAIRS, fuse)
         dets = eng.forward(x)
         res[fuse] = (dets, [eng.layer_stats(k)["saturated"] for k in range(10)], eng.get_feature(3, B).copy(), eng.get_feature(9, B).copy())
         if fuse == 0:
             assert np.array_equal(eng.get_feature(2, B), r["maps"][2].astype(np.int8))
+    for a, b in zip(res[2][0], res[0][0]):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    assert np.array_equal(res[2][2], res[0][2]) and np.array_equal(res[2][3], res[0][3]), "second schedule: maps differ"
+    assert res[2][1] == res[0][1], "second schedule: per-layer saturation counts differ: %s / %s" % (res[2][1], res[0][1])
     eng.set_option(_ffi.OPT_FUSE_PAIRS, 1)
     eng.forward(x)
     if W // 4 <= 104:                            # the fused launch ran: conv3_1's map was not written

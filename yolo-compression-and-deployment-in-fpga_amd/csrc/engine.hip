@@ -191,6 +191,7 @@ struct y355_engine {
     int profile = 0;
     int fuse_front = 1;             // conv1 + pool1 + conv2 + pool2 as one launch (front.hip) where eligible
     int fuse_pairs = 1;             // conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip) where eligible
+    int pair_variant = 1;           // pxpair.hip: 1 the two layers on different waves of every SIMD (default), 0 every wave alternates between them
     int l2_batch = 0;               // images of conv3_1's map that the last launches left valid in L[2].out_dev (the fused pair writes none)
     int l0_batch = 0;               // images of conv1's pooled map that the last launches left valid in L[0].out_dev (the fused
                                     // front end keeps that map on chip: 0 after a fused forward)
@@ -335,7 +336,7 @@ extern "C" int y355_set_option(y355_engine *h, int option, int value) {
     if (!h) return fail(Y355_EINVAL, "null engine");
     switch (option) {
     case Y355_OPT_FUSE_FRONT: h->fuse_front = value ? 1 : 0; return 0;
-    case Y355_OPT_FUSE_PAIRS: h->fuse_pairs = value ? 1 : 0; return 0;
+    case Y355_OPT_FUSE_PAIRS: h->fuse_pairs = value ? 1 : 0; h->pair_variant = value == 2 ? 0 : 1; return 0;
     case Y355_OPT_RING_WORKGROUPS:
         if (value < 0 || value > 4096) return fail(Y355_EINVAL, "workgroups per launch out of range");
         h->ring_wgs = value;
@@ -691,7 +692,7 @@ int y355_zero_counters(Counters *c, int n, hipStream_t s) {
 // conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip): 1 = launched, 0 = not eligible (the caller runs the two layers), < 0 error
 static int launch_pair3(y355_engine *h, int B) {
     Layer &A = h->L[2], &Bl = h->L[3];
-    if (!A.wpair_dev || !Bl.wpx_dev || A.cin != 32 || A.cout_pad != 64 || Bl.cout_pad != 64 || !Bl.pool || A.pool) return 0;
+    if (!A.wpair_dev || !A.wpx_dev || !Bl.wpx_dev || A.cin != 32 || A.cout_pad != 64 || Bl.cout_pad != 64 || !Bl.pool || A.pool) return 0;
 #ifdef Y355_EXPERIMENTS
     static const bool no_pair = getenv("Y355_NO_PAIR3") != nullptr;
     if (no_pair) return 0;
@@ -699,7 +700,8 @@ static int launch_pair3(y355_engine *h, int B) {
     PairParams p{};
     p.in = h->L[1].out_dev;
     p.out = Bl.out_dev;
-    p.w1 = A.wpair_dev;
+    p.variant = h->pair_variant;
+    p.w1 = p.variant == 1 ? A.wpx_dev : A.wpair_dev;
     p.w2 = Bl.wpx_dev;
     p.bias1 = A.bias_dev;
     p.bias2 = Bl.bias_dev;

@@ -253,7 +253,7 @@ bool y355_pack_px(int kid, const int8_t *q_w, int cout, int cin, int8_t *dst);
 struct PairParams {
     const int8_t *in;     // conv3_1's input: int8 NHWC32 with halo [B][H+2][W+2][32]
     int8_t *out;          // conv3_2's pooled output: int8 NHWC64 with halo [B][H/2+2][W/2+2][64]
-    const int8_t *w1;     // conv3_1's weights, y355_pack_pair3 layout
+    const int8_t *w1;     // conv3_1's weights: variant 0 y355_pack_pair3 layout, variant 1 y355_pack_px(Y355_K_CONV3_1) layout
     const int8_t *w2;     // conv3_2's weights, y355_pack_px(Y355_K_CONV3_2) layout
     const int *bias1;     // [64]
     const int *bias2;     // [64]
@@ -263,6 +263,7 @@ struct PairParams {
     void *ev_start, *ev_stop;     // host side only: see ConvParams
     int grid_limit;       // host side only: persistent workgroups per launch (0 = one per CU)
     unsigned long long *stamps;   // diagnostic builds only (-DPAIR_DIAG=1)
+    int variant;          // 0: every wave runs both layers, phase by phase; 1: conv3_1 and conv3_2 on different waves of every SIMD
 };
 bool y355_pair3_eligible(const Requant &rq1, const Requant &rq2, int H, int W);
 bool y355_launch_pair3(const PairParams &p, hipStream_t s);      // false: not eligible, run the two layers' own launches
