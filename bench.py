@@ -544,9 +544,10 @@ def main():
     ap.add_argument("--no-fuse-front", action="store_true",
                     help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
-    ap.add_argument("--fuse-pairs", type=int, default=-1, choices=[-1, 0, 1, 2],
+    ap.add_argument("--fuse-pairs", type=int, default=-1, choices=[-1, 0, 1, 2, 4],
                     help="A/B: conv3_1 -> conv3_2 + pool3 (Y355_OPT_FUSE_PAIRS): 0 one launch per layer, 1 fused, the layers on different waves of "
-                         "every SIMD (the default), 2 fused, every wave alternating between them; -1 = the engine's default.  Same results")
+                         "every SIMD (the default), 2 fused, every wave alternating between them, 4 = 1 plus conv4_1 -> conv4_2 + pool4 fused (measured "
+                         "no faster); -1 = the engine's default.  Same results")
     ap.add_argument("--gather-max-det", type=int, default=256,
                     help="multi-GPU: detections per image in the all-gather records (SURVEY.md 8e: fixed-cap records, 6.1 KB per image "
                          "at 256; 0 = the engine's max_det, i.e. full records); the per-GPU forward and its outputs are unchanged. "
@@ -913,16 +914,19 @@ def main():
         pair3 = have_k and kernel_ms[2] > 0 and kernel_ms[3] == 0
         knames = ((["conv1+conv2 (fused front end)"] if fused else ["conv1"]) + LAYER_NAMES[1:] +
                   ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
+        pair4 = have_k and kernel_ms[4] > 0 and kernel_ms[5] == 0
         if pair3:
             knames[2] = "conv3_1+conv3_2 (fused pair)"
+        if pair4:
+            knames[4] = "conv4_1+conv4_2 (fused pair)"
         layers = {}
         for i, n in enumerate(LAYER_NAMES):
-            if pair3 and i == 2:
-                layers["conv3_1+conv3_2 (fused pair)"] = dict(
-                    ms=round(float(layer_ms[2] + layer_ms[3]), 4),
-                    tops=round(B * 2e6 * (LAYER_MMAC[2] + LAYER_MMAC[3]) / ((layer_ms[2] + layer_ms[3]) * 1e-3) / 1e12, 1))
+            if (pair3 and i == 2) or (pair4 and i == 4):
+                layers[knames[i]] = dict(
+                    ms=round(float(layer_ms[i] + layer_ms[i + 1]), 4),
+                    tops=round(B * 2e6 * (LAYER_MMAC[i] + LAYER_MMAC[i + 1]) / ((layer_ms[i] + layer_ms[i + 1]) * 1e-3) / 1e12, 1))
                 continue
-            if pair3 and i == 3:
+            if (pair3 and i == 3) or (pair4 and i == 5):
                 continue
             if fused and i == 0:
                 layers["conv1+conv2 (fused front end)"] = dict(

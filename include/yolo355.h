@@ -92,7 +92,10 @@ int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
  * wide; calibration, statistics runs and guarded forwards (Y355_F_GUARD) always run layer by layer.
  * Value 1 = the production schedule: conv3_1 on the first wave of every SIMD, conv3_2 + pool on the second, one interval apart
  * (+4.5 % images/s against two launches, three handles); 2 = the first schedule built (every wave alternates between the two
- * layers, barrier to barrier: +2.2 %), kept for comparison.  Results are identical bit for bit in all three settings. */
+ * layers, barrier to barrier: +2.2 %), kept for comparison; 4 = 1 plus conv4_1, conv4_2 and pool4 (:268-289; calls 5 and 6,
+ * :1226-1236; maps 16 .. 64 pixels wide) fused the same way -- built, bit-exact, measured NO faster than their two launches (42.4
+ * against 16.4 + 25.1 us: every wave of a role reads every pixel, the LDS is the bound), so it is off unless asked for
+ * (y355_get_feature(h, 4, ...) returns Y355_ENOTREADY then).  Results are identical bit for bit in all settings. */
 #define Y355_OPT_FUSE_PAIRS 3
 int y355_set_option(y355_engine *h, int option, int value);
 

@@ -18,7 +18,8 @@ lib=_ffi.lib()
 lib.y355_debug_stamps.argtypes=[C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 np.set_printoptions(linewidth=250)
 for it in range(3): eng.forward_device(x)
-lib.y355_debug_stamps(eng._h, 2, None, 0)
+LAYER = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # 2: conv3 pair, 4: conv4 pair
+lib.y355_debug_stamps(eng._h, LAYER, None, 0)
 eng.forward_device(x); eng.sync()
 buf = np.zeros((1024,32), np.uint64)
 lib.y355_debug_stamps(eng._h, -1, buf.ctypes.data, 1024)

@@ -397,38 +397,48 @@ def test_fused_pairs_equal_layer_launches(H, W, B, gain, bump):
     O.detect(xc, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2)
     if bump:
         sa = list(eng.get_act_exponents())
-        for k in (3, 4):                         # trackers behind conv3_1 and conv3_2
+        for k in (3, 4, 5, 6):                   # trackers behind conv3_1, conv3_2, conv4_1, conv4_2
             sa[k] += bump
             otr[k].scale = otr[k].scale * 2 ** bump
         eng.set_act_exponents(sa)
     x = synth.normalize_frames(frames) * np.float32(gain)
     r = O.detect(x, ql, otr, [H, W], synth.ANCHOR_SIZE_MASK, 2, saturate=True, keep=True)
     res = {}
-    for fuse in (1, 2, 0):                       # 1: the layers on different waves of every SIMD (production); 2: every wave alternates between them
+    for fuse in (4, 1, 2, 0):                    # 4: both pairs fused, the layers on different waves of every SIMD (1, the default: the conv3
+                                                 # pair only); 2: the conv3 pair, every wave alternating between its layers
         eng.set_option(_ffi.OPT_FUSE_PAIRS, fuse)
         dets = eng.forward(x)
-        res[fuse] = (dets, [eng.layer_stats(k)["saturated"] for k in range(10)], eng.get_feature(3, B).copy(), eng.get_feature(9, B).copy())
+        res[fuse] = (dets, [eng.layer_stats(k)["saturated"] for k in range(10)], eng.get_feature(3, B).copy(), eng.get_feature(9, B).copy(),
+                     eng.get_feature(5, B).copy())
         if fuse == 0:
             assert np.array_equal(eng.get_feature(2, B), r["maps"][2].astype(np.int8))
-    for a, b in zip(res[2][0], res[0][0]):
-        for u, v in zip(a, b):
-            assert np.array_equal(u, v)
-    assert np.array_equal(res[2][2], res[0][2]) and np.array_equal(res[2][3], res[0][3]), "second schedule: maps differ"
-    assert res[2][1] == res[0][1], "second schedule: per-layer saturation counts differ: %s / %s" % (res[2][1], res[0][1])
-    eng.set_option(_ffi.OPT_FUSE_PAIRS, 1)
+            assert np.array_equal(eng.get_feature(4, B), r["maps"][4].astype(np.int8))
+    for alt in (1, 2):
+        for a, b in zip(res[alt][0], res[0][0]):
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v)
+        assert np.array_equal(res[alt][2], res[0][2]) and np.array_equal(res[alt][3], res[0][3]), "setting %d: maps differ" % alt
+        assert res[alt][1] == res[0][1], "setting %d: per-layer saturation counts differ: %s / %s" % (alt, res[alt][1], res[0][1])
+    eng.set_option(_ffi.OPT_FUSE_PAIRS, 4)
     eng.forward(x)
     if W // 4 <= 104:                            # the fused launch ran: conv3_1's map was not written
         with pytest.raises(_ffi.Y355Error) as e:
             eng.get_feature(2, B)
         assert e.value.code == _ffi.ENOTREADY
-    assert np.array_equal(res[1][2], r["maps"][3].astype(np.int8)), "conv3_2's pooled map of the fused launch differs from the oracle"
-    assert np.array_equal(res[1][3], r["pred_q"].astype(np.int8))
-    assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][3], res[0][3])
-    assert res[1][1] == res[0][1], "per-layer saturation counts differ between the fused and the per-layer route: %s / %s" % (res[1][1], res[0][1])
-    assert res[1][1][2:] == list(r["sat_out"])[2:], (res[1][1], r["sat_out"])
+    if 16 <= W // 8 <= 64:                       # ... and neither was conv4_1's (maps of 16 .. 64 pixels' width take the fused launch)
+        with pytest.raises(_ffi.Y355Error) as e:
+            eng.get_feature(4, B)
+        assert e.value.code == _ffi.ENOTREADY
+    assert np.array_equal(res[4][4], r["maps"][5].astype(np.int8)), "conv4_2's pooled map of the fused launch differs from the oracle"
+    assert np.array_equal(res[4][4], res[0][4]) and np.array_equal(res[2][4], res[0][4])
+    assert np.array_equal(res[4][2], r["maps"][3].astype(np.int8)), "conv3_2's pooled map of the fused launch differs from the oracle"
+    assert np.array_equal(res[4][3], r["pred_q"].astype(np.int8))
+    assert np.array_equal(res[4][2], res[0][2]) and np.array_equal(res[4][3], res[0][3])
+    assert res[4][1] == res[0][1], "per-layer saturation counts differ between the fused and the per-layer route: %s / %s" % (res[4][1], res[0][1])
+    assert res[4][1][2:] == list(r["sat_out"])[2:], (res[4][1], r["sat_out"])
     if bump:
-        assert res[1][1][2] > 0 and res[1][1][3] > 0, "the fixture must clamp in both layers of the pair"
-    for a, b in zip(res[1][0], res[0][0]):
+        assert min(res[4][1][2:6]) > 0, "the fixture must clamp in both layers of both pairs"
+    for a, b in zip(res[4][0], res[0][0]):
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
     eng.close()

@@ -76,6 +76,8 @@ int y355_prepare_kernels() {
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(head): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_ring())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(ring): ") + hipGetErrorString((hipError_t)e));
+    if (int e = y355_prepare_pair4())
+        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(pair4): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_pair3())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(pair3): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_px())
@@ -193,6 +195,7 @@ struct y355_engine {
     int fuse_pairs = 1;             // conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip) where eligible
     int pair_variant = 1;           // pxpair.hip: 1 the two layers on different waves of every SIMD (default), 0 every wave alternates between them
     int l2_batch = 0;               // images of conv3_1's map that the last launches left valid in L[2].out_dev (the fused pair writes none)
+    int l4_batch = 0;               // the same for conv4_1's map (L[4].out_dev)
     int l0_batch = 0;               // images of conv1's pooled map that the last launches left valid in L[0].out_dev (the fused
                                     // front end keeps that map on chip: 0 after a fused forward)
     int ring_wgs = 0;               // persistent workgroups per ring launch (0 = one per CU)
@@ -336,7 +339,7 @@ extern "C" int y355_set_option(y355_engine *h, int option, int value) {
     if (!h) return fail(Y355_EINVAL, "null engine");
     switch (option) {
     case Y355_OPT_FUSE_FRONT: h->fuse_front = value ? 1 : 0; return 0;
-    case Y355_OPT_FUSE_PAIRS: h->fuse_pairs = value ? 1 : 0; h->pair_variant = value == 2 ? 0 : 1; return 0;
+    case Y355_OPT_FUSE_PAIRS: h->fuse_pairs = value ? (value == 4 ? 2 : 1) : 0; h->pair_variant = value == 2 ? 0 : 1; return 0;
     case Y355_OPT_RING_WORKGROUPS:
         if (value < 0 || value > 4096) return fail(Y355_EINVAL, "workgroups per launch out of range");
         h->ring_wgs = value;
@@ -400,6 +403,14 @@ extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const
             }
             HIPCHK(hipMemcpy(L.wpx_dev, px.data(), px.size(), hipMemcpyHostToDevice));
         }
+    }
+    if (idx == 4 && cin == 64 && cout == 128) {
+        std::vector<int8_t> pw(y355_pair4_packed_bytes());
+        y355_pack_pair4(q_w, pw.data());
+        if (!L.wpair_dev) {
+            if (int rc = dmalloc(h, (void **)&L.wpair_dev, pw.size(), false)) return rc;
+        }
+        HIPCHK(hipMemcpy(L.wpair_dev, pw.data(), pw.size(), hipMemcpyHostToDevice));
     }
     if (idx == 2 && cin == 32 && cout == 64) {
         std::vector<int8_t> pw(y355_pair3_packed_bytes());
@@ -531,6 +542,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         constexpr int no_ring_mask = 0, no_px_mask = 0;
 #endif
         if (k == 2 && mode == 0) h->l2_batch = B;
+        if (k == 4 && mode == 0) h->l4_batch = B;
         if (L.wpx_dev && !((no_px_mask >> k) & 1)) {
             ConvParams q = p;
             q.w = L.wpx_dev;
@@ -599,6 +611,9 @@ extern "C" int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst)
                                     "run with y355_set_option(h, Y355_OPT_FUSE_FRONT, 0) to tap it");
     if (idx == 2 && batch > h->l2_batch)
         return fail(Y355_ENOTREADY, "conv3_1's map of the last forward was not written (fused conv3_1 -> conv3_2 + pool): "
+                                    "run with y355_set_option(h, Y355_OPT_FUSE_PAIRS, 0) to tap it");
+    if (idx == 4 && batch > h->l4_batch)
+        return fail(Y355_ENOTREADY, "conv4_1's map of the last forward was not written (fused conv4_1 -> conv4_2 + pool): "
                                     "run with y355_set_option(h, Y355_OPT_FUSE_PAIRS, 0) to tap it");
     const Layer &L = h->L[idx];
     const int Hp = L.Hout + 2 * L.halo, Wp = L.Wout + 2 * L.halo, CS = L.cout_pad;
@@ -723,6 +738,40 @@ static int launch_pair3(y355_engine *h, int B) {
     return 1;
 }
 
+// conv4_1 -> conv4_2 + pool4 as one launch (pxpair.hip): 1 = launched, 0 = not eligible, < 0 error
+static int launch_pair4(y355_engine *h, int B) {
+    Layer &A = h->L[4], &Bl = h->L[5];
+    if (!A.wpair_dev || !Bl.wpx_dev || A.cin != 64 || A.cout_pad != 128 || Bl.cout_pad != 128 || !Bl.pool || A.pool) return 0;
+#ifdef Y355_EXPERIMENTS
+    static const bool no_pair = getenv("Y355_NO_PAIR4") != nullptr;
+    if (no_pair) return 0;
+#endif
+    PairParams p{};
+    p.variant = 1;
+    p.in = h->L[3].out_dev;
+    p.out = Bl.out_dev;
+    p.w1 = A.wpair_dev;
+    p.w2 = Bl.wpx_dev;
+    p.bias1 = A.bias_dev;
+    p.bias2 = Bl.bias_dev;
+    p.ctr1 = h->ctr_dev + 4;
+    p.ctr2 = h->ctr_dev + 5;
+    p.rq1 = A.rq;
+    p.rq2 = Bl.rq;
+    p.B = B;
+    p.H = A.Hin;
+    p.W = A.Win;
+    p.grid_limit = h->ring_wgs;
+    p.stamps = (h->stamp_layer == 4) ? h->stamps_dev : nullptr;
+    h->kev_set[4] = h->kev_set[5] = false;
+    if (h->profile == 2) { p.ev_start = h->kev[4][0]; p.ev_stop = h->kev[4][1]; }
+    if (!y355_launch_pair4(p, h->stream)) return 0;
+    HIPCHK(hipGetLastError());
+    h->kev_set[4] = p.ev_start != nullptr;
+    h->l4_batch = 0;
+    return 1;
+}
+
 // enqueue one forward on `s` (refresh_layer must have run)
 static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
                            int32_t *cls_dev, int32_t *count_dev, bool prof) {
@@ -731,7 +780,7 @@ static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int fl
     // the fused front end covers the 32-bit epilogue without the head-room guard; conv2's packed weights must be the
     // resident-weight layout (one n-block of 32 channels), which they are for this network
     const bool fused = h->fuse_front && !guard && y355_front_eligible(h->L[0].rq, h->L[1].rq) && h->L[1].cout_pad == 32;
-    bool pair3 = false;
+    bool pair3 = false, pair4 = false;
     for (int k = 0; k < 10; ++k) {
         if (prof) HIPCHK(hipEventRecord(h->ev[k], h->stream));
         if (fused && k == 0) {
@@ -747,6 +796,13 @@ static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int fl
             if (pair3) continue;
         }
         if (pair3 && k == 3) continue;
+        if (k == 4 && h->fuse_pairs == 2 && !guard) {     // (measured no faster than the two launches: off unless asked for)          // conv4_1 -> conv4_2 + pool4 in one launch; slot 5 then reads ~0
+            const int rc = launch_pair4(h, batch);
+            if (rc < 0) return rc;
+            pair4 = rc == 1;
+            if (pair4) continue;
+        }
+        if (pair4 && k == 5) continue;
         if (int rc = launch_layer(h, k, batch, 0, guard, x_dev)) return rc;
     }
     if (prof) HIPCHK(hipEventRecord(h->ev[10], h->stream));

@@ -925,6 +925,382 @@ __global__ __launch_bounds__(512, 2) void pxpair3r_kernel(const PairParams p) {
     if (nsat) atomicAdd(roleA ? &p.ctr1->sat : &p.ctr2->sat, (unsigned long long)nsat);
 }
 
+// ==========================================================================================
+// conv4_1 -> conv4_2 + pool4 (models/slim_yolo_v2.py:268-289; conv_normal calls 5 and 6, c_embedding/yolo_forward.c:1226-1236) in
+// one launch, the same schedule: the two layers on different waves of every SIMD.  Only this schedule fits the pair: a wave
+// that ran both layers would need 18 + 36 fragments of its 32-channel block = 216 VGPRs of weights.
+//   * waves 0-3 run conv4_1 (64 -> 128 at 52 x 52): wave w holds output channels 32 w .. 32 w + 31 (9 taps x 2 n-tiles = 18
+//     fragments) and walks ALL four map rows of the interval, row by row in groups of 16 pixels (a 52-pixel row = 3 full groups
+//     and a quarter: this role has the lighter load, 18 MFMAs per item against the other's 144 per group);
+//   * waves 4-7 run conv4_2 + pool (128 -> 128): wave 4 + w holds output channels 32 w .. 32 w + 31 (9 taps x 2 k-halves x 2
+//     n-tiles = 36 fragments = 144 VGPRs) and takes ALL the interval's pooling windows in groups of 16.
+// Map ring: 16 rows x 8 planes of 16-byte chunks (slot = x ^ ((x >> 4) & 1)); input ring: 12 rows of 64-byte pixels by LDS-DMA,
+// XOR-swizzled on the source side as in convpx.hip (chunk ^ 2 ((x >> 2) & 1)).  Everything else as pxpair3r_kernel.
+template <int F1, int F2>
+__global__ __launch_bounds__(512, 2) void pxpair4r_kernel(const PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    int nstamp = 0;
+    auto stamp = [&]() {
+#if PAIR_DIAG
+        if (p.stamps && (tid == 0 || tid == 256) && nstamp < 16) p.stamps[(size_t)blockIdx.x * 32 + (tid >> 8) * 16 + nstamp++] = __builtin_amdgcn_s_memrealtime();
+#endif
+    };
+    (void)nstamp;
+    stamp();
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool roleA = wave < 4;
+    const int cb = wave & 3;                              // 32-channel block of this wave's layer
+    const int li = lane & 15, g = lane >> 4;
+    const int H = p.H, W = p.W, Ho = H >> 1, Wo = W >> 1;
+    const int NG = (W + 15) >> 4;                         // 16-pixel groups per map row (<= 4)
+    const int MS = W + 2, PLANE = MS * 16, MPITCH = 8 * PLANE;
+    const int PPR = (W + 2 + 15) >> 4, IPITCH = PPR * 1024;
+    char *const mid = smem;                               // [RMID][8 planes][MS] 16-byte chunks
+    char *const inp = smem + RMID * MPITCH;               // [RIN][PPR] 1 KiB pieces of 16 pixels x 64 bytes
+    auto dma_rows = [&](int b, int ra, int rb) {          // role A only: piece q by wave q % 4
+        const int np = (rb - ra) * PPR;
+        for (int q = cb; q < np; q += 4) {
+            const int rr = q / PPR, pc = q - rr * PPR, row = ra + rr;
+            const int col = pc * 16 + (lane >> 2);
+            const int sch = (lane & 3) ^ (((col >> 2) & 1) << 1);
+            const int8_t *src = p.in + ((size_t)(b * (H + 2) + row) * (W + 2) + min(col, W + 1)) * 64 + sch * 16;
+            qglds16(src, inp + (row % RIN) * IPITCH + pc * 1024);
+        }
+    };
+    const int G_ = gridDim.x, Rtot = p.B * Ho;
+    const int rbeg = (int)((long long)Rtot * blockIdx.x / G_), rend = (int)((long long)Rtot * (blockIdx.x + 1) / G_);
+    struct Band { int b, j0, j1; };
+    auto band_at = [&](int r0) {
+        Band q;
+        q.b = r0 / Ho;
+        q.j0 = r0 - q.b * Ho;
+        q.j1 = min(Ho, q.j0 + (rend - r0));
+        return q;
+    };
+    auto je_of = [&](const Band &q, int t) { return min(q.j0 + 1 + 2 * t, q.j1); };
+    auto first_rows = [&](const Band &q) {
+        const int hi = min(2 * je_of(q, 0) + 2, H + 1) + 1;
+        dma_rows(q.b, max(2 * q.j0, 1) - 1, hi);
+        return hi;
+    };
+    Band bd = band_at(rbeg);
+    int in_hi = 0;
+    if (roleA) in_hi = first_rows(bd);
+    unsigned int nsat = 0;
+
+    for (int i = tid * 16; i < RMID * MPITCH; i += 512 * 16) *(v4i *)(mid + i) = (v4i){0, 0, 0, 0};
+
+    if (roleA) {
+        // ---- conv4_1's weights of this wave's 32 channels: [tap][n-tile]
+        v4i wfa[9][2], cina[2];
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) wfa[ks][n] = *(const v4i *)(p.w1 + ((size_t)(cb * 9 + ks) * 2 + n) * 1024 + lane * 16);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {                     // accumulator register r of n-tile n of lane group g = channel 32 cb + 8 g + 4 n + r
+            const v4i b1 = *(const v4i *)(p.bias1 + cb * 32 + 8 * g + 4 * n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cina[n][r] = F1 == 2 ? b1[r] + 0x4B400000 : b1[r];
+        }
+        const Epi e1 = make_epi<F1>(p.rq1);
+        // byte offset inside an input row of chunk g of pixel li + tx of group 0 (group k adds 1024): the swizzle bit of a pixel is
+        // bit 2 of its column, which 16 k does not touch
+        int cx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) cx[tx] = (li + tx) * 64 + 16 * (g ^ ((((li + tx) >> 2) & 1) << 1));
+        // byte offset inside a map row of this lane's 8 channels (chunk 2 cb + (g >> 1), half g & 1) of group 0's pixel, k even / odd
+        int wc[2];
+        wc[0] = (2 * cb + (g >> 1)) * PLANE + 8 * (g & 1) + 16 * (li < 15 ? li + 1 : 17);
+        wc[1] = (2 * cb + (g >> 1)) * PLANE + 8 * (g & 1) + 16 * (li < 15 ? ((li + 1) ^ 1) : 16);
+        const bool lastok = 16 * (NG - 1) + li < W;
+        for (int r0 = rbeg; r0 < rend;) {
+            const int b = bd.b, j0 = bd.j0, j1 = bd.j1;
+            const int nA = 1 + (j1 - j0) / 2;
+            r0 += j1 - j0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stamp();
+            for (int t = 0; t <= nA; ++t) {
+                if (t < nA) {
+                    const int PA = t == 0 ? 2 * j0 : 2 * je_of(bd, t - 1) + 2, PB = 2 * je_of(bd, t) + 2;
+                    if (t + 1 < nA) {
+                        const int hi = min(2 * je_of(bd, t + 1) + 2, H + 1) + 1;
+                        dma_rows(b, in_hi, hi);
+                        in_hi = max(in_hi, hi);
+                    }
+                    float ymx = MAGIC, ymn = MAGIC;
+                    // one map row: NG items of 16 pixels, pipelined as in pxpair3r_kernel (operands of item k + 1 read, item k - 1
+                    // requantised and stored, under the 18 MFMAs of item k)
+                    auto row_a = [&](int P, auto coldc) {
+                        constexpr bool COLD = decltype(coldc)::value;
+                        int a[3][3];
+#pragma unroll
+                        for (int ty = 0; ty < 3; ++ty) {
+                            const int rb = ((P - 1 + ty) % RIN) * IPITCH;
+#pragma unroll
+                            for (int tx = 0; tx < 3; ++tx) a[ty][tx] = rb + cx[tx];
+                        }
+                        const int wrow = (P & (RMID - 1)) * MPITCH;
+                        const int w0 = wrow + wc[0], w1 = wrow + wc[1];
+                        const bool owned = P >= 2 * j0 + 1 && P < 2 * j1 + 1;
+                        auto rd = [&](v4i (&bq)[9], int k) {
+#pragma unroll
+                            for (int tap = 0; tap < 9; ++tap) bq[tap] = *(const v4i *)(inp + a[tap / 3][tap % 3] + k * 1024);
+                        };
+                        auto out2 = [&](const v4i (&acc)[2], unsigned int (&word)[2], int n_, int rr, bool cok) {
+                            float pos[2], neg[2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int v = acc[n_][2 * rr + u];
+                                const float tf = F1 == 2 ? __int_as_float(v) : (float)v;
+                                pos[u] = fmaf(tf, e1.sp, e1.cp);
+                                neg[u] = fmaf(tf, e1.sn, e1.cn);
+                            }
+                            if constexpr (!COLD) {
+                                ymx = qvmax3(ymx, pos[0], pos[1]);
+                                ymn = qvmin3(ymn, neg[0], neg[1]);
+                                if (rr == 0) {
+                                    qmax_to_byte<0>(word[n_], pos[0], neg[0]);
+                                    qmax_to_byte<1>(word[n_], pos[1], neg[1]);
+                                } else {
+                                    qmax_to_byte<2>(word[n_], pos[0], neg[0]);
+                                    qmax_to_byte<3>(word[n_], pos[1], neg[1]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    const float y = qvmax(pos[u], neg[u]), yc = __builtin_amdgcn_fmed3f(y, QLO, QHI);
+                                    nsat += (cok && y != yc) ? 1u : 0u;
+                                    const unsigned int by = __float_as_uint(yc) & 0xffu;
+                                    word[n_] = (rr == 0 && u == 0) ? by : (word[n_] | (by << (8 * (2 * rr + u))));
+                                }
+                            }
+                        };
+                        auto wr = [&](int k, const unsigned int (&word)[2]) {
+                            *(v2u *)(mid + ((k & 1) ? w1 : w0) + k * 256) = (v2u){word[0], word[1]};
+                        };
+                        auto stage = [&](int k, const v4i (&bq)[9], v4i (&acc)[2], const v4i (&pacc)[2]) {
+                            acc[0] = cina[0];
+                            acc[1] = cina[1];
+                            unsigned int word[2] = {0u, 0u};
+#pragma unroll
+                            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                                for (int n_ = 0; n_ < 2; ++n_) acc[n_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wfa[tap][n_], bq[tap], acc[n_], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (k > 0 && (tap & 1) && tap < 8) {               // behind MFMA pairs 1, 3, 5, 7: two outputs of the item before
+                                    out2(pacc, word, tap >> 2, (tap >> 1) & 1, owned);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                            if (k > 0) wr(k - 1, word);
+                        };
+                        v4i bq[2][9], acc[2][2];
+                        if constexpr (COLD) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (k >= NG) break;
+                                rd(bq[0], k);
+                                stage(0, bq[0], acc[0], acc[0]);
+                                unsigned int word[2] = {0u, 0u};
+                                const bool cok = owned && (k + 1 < NG || lastok);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) out2(acc[0], word, q >> 1, q & 1, cok);
+                                if (k + 1 < NG || lastok) wr(k, word);
+                            }
+                            return;
+                        }
+                        rd(bq[0], 0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (k >= NG) break;
+                            if (k + 1 < 4 && k + 1 < NG) rd(bq[(k + 1) & 1], k + 1);
+                            stage(k, bq[k & 1], acc[k & 1], acc[(k + 1) & 1]);
+                        }
+                        {
+                            unsigned int word[2] = {0u, 0u};
+                            if ((NG - 1) & 1) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) out2(acc[1], word, q >> 1, q & 1, false);
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) out2(acc[0], word, q >> 1, q & 1, false);
+                            }
+                            if (lastok) *(v2u *)(mid + (((NG - 1) & 1) ? w1 : w0) + (NG - 1) * 256) = (v2u){word[0], word[1]};
+                        }
+                    };
+                    for (int P = PA; P < PB; ++P) {
+                        if (P == 0 || P == H + 1) {                                // the map's zero halo rows: each wave its own planes
+                            for (int o = lane * 16; o < 2 * PLANE; o += 1024)
+                                *(v4i *)(mid + (P & (RMID - 1)) * MPITCH + 2 * cb * PLANE + o) = (v4i){0, 0, 0, 0};
+                        } else {
+                            row_a(P, std::false_type{});
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(ymx > QHI || ymn < QLO) != 0ull)
+                        for (int P = max(PA, 1); P < min(PB, H + 1); ++P) row_a(P, std::true_type{});
+                } else if (r0 < rend) {
+                    bd = band_at(r0);
+                    in_hi = first_rows(bd);
+                }
+                stamp();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stamp();
+            }
+        }
+    } else {
+        // ---- conv4_2's weights of this wave's 32 channels: [tap * 2 + k-half][n-tile]
+        v4i wfb[18][2], cinb[2];
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) wfb[ks][n] = *(const v4i *)(p.w2 + ((size_t)(cb * 18 + ks) * 2 + n) * 1024 + lane * 16);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const v4i b2 = *(const v4i *)(p.bias2 + cb * 32 + 8 * g + 4 * n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cinb[n][r] = F2 == 2 ? b2[r] + 0x4B400000 : b2[r];
+        }
+        const Epi e2 = make_epi<F2>(p.rq2);
+        const float invWo = 1.0f / (float)Wo;
+        for (int r0 = rbeg; r0 < rend;) {
+            const int b = bd.b, j0 = bd.j0, j1 = bd.j1;
+            const int nA = 1 + (j1 - j0) / 2;
+            r0 += j1 - j0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stamp();
+            int8_t *const outb = p.out + (((size_t)b * (Ho + 2) + 1) * (Wo + 2) + 1) * 128 + cb * 32;
+            int wdone = 0;
+            for (int t = 0; t <= nA; ++t) {
+                if (t == nA && r0 < rend) bd = band_at(r0);
+                if (t >= 1) {
+                    const int je = je_of(Band{b, j0, j1}, t - 1);
+                    const int avail = (je - j0) * Wo - wdone;
+                    const bool all = t == nA || Wo < 16;
+                    const int ngb = all ? (avail + 15) >> 4 : (avail >> 4);        // whole groups; the rest (less than a row) waits
+                    const int nwin = all ? avail : ngb * 16, wlo = wdone;
+                    wdone += nwin;
+                    float zmx = MAGIC, zmn = MAGIC;
+                    auto locate = [&](int grp, int &oyr, int &ox) {
+                        const int wi = wlo + min(grp * 16 + li, nwin - 1);
+                        oyr = (int)(((float)wi + 0.5f) * invWo);
+                        ox = wi - oyr * Wo;
+                    };
+                    auto issue = [&](int grp, v4i (&acc)[4][2]) {
+                        int oyr, ox;
+                        locate(grp, oyr, ox);
+                        const int ar = 2 * (j0 + oyr), x0 = 2 * ox;
+                        int xoff[4], roff[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int x = x0 + c;
+                            xoff[c] = g * PLANE + ((x ^ ((x >> 4) & 1)) << 4);
+                            roff[c] = ((ar + c) & (RMID - 1)) * MPITCH;
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) acc[v][n] = cinb[n];
+                        // neighbourhood row r: 4 columns x 2 channel halves read, then its MFMAs (a row at a time: 144 VGPRs of weights
+                        // leave room for one row of operands)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v4i bq[4][2];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) bq[c][h] = *(const v4i *)(mid + roff[r] + xoff[c] + h * 4 * PLANE);
+#pragma unroll
+                            for (int dy = 0; dy < 2; ++dy) {
+                                const int ty = r - dy;
+                                if (ty < 0 || ty > 2) continue;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                    for (int dx = 0; dx < 2; ++dx) {
+                                        const int tx = c - dx;
+                                        if (tx < 0 || tx > 2) continue;
+#pragma unroll
+                                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                            for (int n = 0; n < 2; ++n)
+                                                acc[2 * dy + dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wfb[(ty * 3 + tx) * 2 + h][n], bq[c][h], acc[2 * dy + dx][n], 0, 0, 0);
+                                    }
+                            }
+                        }
+                    };
+                    auto finish = [&](int grp, const v4i (&acc)[4][2], auto coldc) {
+                        constexpr bool COLD = decltype(coldc)::value;
+                        int oyr, ox;
+                        locate(grp, oyr, ox);
+                        unsigned int word[2];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            float pos[4], neg[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int m = max(max(acc[0][n][r], acc[1][n][r]), max(acc[2][n][r], acc[3][n][r]));
+                                const float tf = F2 == 2 ? __int_as_float(m) : (float)m;
+                                pos[r] = fmaf(tf, e2.sp, e2.cp);
+                                neg[r] = fmaf(tf, e2.sn, e2.cn);
+                            }
+                            if constexpr (!COLD) {
+                                zmx = qvmax3(qvmax3(zmx, pos[0], pos[1]), pos[2], pos[3]);
+                                zmn = qvmin3(qvmin3(zmn, neg[0], neg[1]), neg[2], neg[3]);
+                                qmax_to_byte<0>(word[n], pos[0], neg[0]);
+                                qmax_to_byte<1>(word[n], pos[1], neg[1]);
+                                qmax_to_byte<2>(word[n], pos[2], neg[2]);
+                                qmax_to_byte<3>(word[n], pos[3], neg[3]);
+                            } else {
+                                float yc[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float y = qvmax(pos[r], neg[r]);
+                                    yc[r] = __builtin_amdgcn_fmed3f(y, QLO, QHI);
+                                    nsat += (grp * 16 + li < nwin && y != yc[r]) ? 1u : 0u;
+                                }
+                                word[n] = qpack4(yc[0], yc[1], yc[2], yc[3]);
+                            }
+                        }
+                        int8_t *dst = outb + (((j0 + oyr) * (Wo + 2) + ox) * 128 + 8 * g);
+                        *(v2u *)dst = (v2u){word[0], word[1]};
+                    };
+                    {
+                        v4i acc[4][2];
+#pragma unroll 1
+                        for (int grp = 0; grp < ngb; ++grp) {
+                            issue(grp, acc);
+                            finish(grp, acc, std::false_type{});
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(zmx > QHI || zmn < QLO) != 0ull) {
+                        v4i accC[4][2];
+#pragma unroll 1
+                        for (int grp = 0; grp < ngb; ++grp) {
+                            issue(grp, accC);
+                            finish(grp, accC, std::true_type{});
+                        }
+                    }
+                }
+                stamp();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stamp();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsat) atomicAdd(roleA ? &p.ctr1->sat : &p.ctr2->sat, (unsigned long long)nsat);
+}
+
 // ------------------------------------------------------------------------------------------
 size_t y355_pair3_packed_bytes(void) { return (size_t)2 * 5 * 2 * 1024; }
 
@@ -1001,5 +1377,64 @@ bool y355_launch_pair3(const PairParams &p, hipStream_t s) {
     else if (f1 == 2) launch_<2, 1>(p, grid, lds, s);
     else if (f2 == 2) launch_<1, 2>(p, grid, lds, s);
     else launch_<1, 1>(p, grid, lds, s);
+    return true;
+}
+
+// ---- conv4_1 -> conv4_2 + pool4 (pxpair4r_kernel)
+size_t y355_pair4_packed_bytes(void) { return (size_t)4 * 9 * 2 * 1024; }
+// conv4_1's weights q_w [128][64][3][3]: fragment ((cb * 9 + tap) * 2 + n), lane (i = l & 15, g = l >> 4), 16 bytes:
+// row i = output channel 32 cb + 8 (i >> 2) + 4 n + (i & 3), input channels 16 g .. + 15 of tap
+void y355_pack_pair4(const int8_t *q_w, int8_t *dst) {
+    memset(dst, 0, y355_pair4_packed_bytes());
+    for (int cb = 0; cb < 4; ++cb)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int n = 0; n < 2; ++n)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, g = l >> 4;
+                    const int ch = cb * 32 + 8 * (i >> 2) + 4 * n + (i & 3);
+                    for (int kk = 0; kk < 16; ++kk)
+                        dst[(((size_t)cb * 9 + tap) * 2 + n) * 1024 + l * 16 + kk] = q_w[((size_t)ch * 64 + 16 * g + kk) * 9 + tap];
+                }
+}
+namespace {
+size_t pair4_lds(int W) {
+    const int MPITCH = 8 * (W + 2) * 16, IPITCH = ((W + 2 + 15) >> 4) * 1024;
+    return (size_t)RMID * MPITCH + (size_t)RIN * IPITCH;
+}
+template <int F1, int F2>
+void launch4_(const PairParams &p, int grid, size_t lds, hipStream_t s) {
+    PairParams q = p;
+    q.ev_start = q.ev_stop = nullptr;
+    Y355_LAUNCH((pxpair4r_kernel<F1, F2>), dim3(grid), dim3(512), lds, s, p.ev_start, p.ev_stop, q);
+}
+}  // namespace
+int y355_prepare_pair4(void) {
+    int e = (int)hipFuncSetAttribute((const void *)pxpair4r_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!e) e = (int)hipFuncSetAttribute((const void *)pxpair4r_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!e) e = (int)hipFuncSetAttribute((const void *)pxpair4r_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!e) e = (int)hipFuncSetAttribute((const void *)pxpair4r_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+}
+bool y355_pair4_eligible(const Requant &rq1, const Requant &rq2, int H, int W) {
+    for (const Requant *rq : {&rq1, &rq2}) {
+        if (rq->wide || rq->tmax_log2 > 24 || fold_of(*rq) == 0) return false;
+        if (rq->neg_mul < 0 || rq->neg_mul > (1 << rq->lk)) return false;
+    }
+    if ((H | W) & 1 || W < 16 || W > 64 || H < 2) return false;
+    return pair4_lds(W) <= 160 * 1024;
+}
+bool y355_launch_pair4(const PairParams &p, hipStream_t s) {
+    if (!y355_pair4_eligible(p.rq1, p.rq2, p.H, p.W)) return false;
+    if ((long long)p.B * (p.H + 2) * (p.W + 2) * 64 >= (1ll << 31)) return false;
+    const int total = p.B * (p.H / 2);
+    int grid = 256;
+    if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;
+    if (grid > total) grid = total;
+    const size_t lds = pair4_lds(p.W);
+    const int f1 = fold_of(p.rq1), f2 = fold_of(p.rq2);
+    if (f1 == 2 && f2 == 2) launch4_<2, 2>(p, grid, lds, s);
+    else if (f1 == 2) launch4_<2, 1>(p, grid, lds, s);
+    else if (f2 == 2) launch4_<1, 2>(p, grid, lds, s);
+    else launch4_<1, 1>(p, grid, lds, s);
     return true;
 }

@@ -270,6 +270,12 @@ bool y355_launch_pair3(const PairParams &p, hipStream_t s);      // false: not e
 int y355_prepare_pair3(void);
 size_t y355_pair3_packed_bytes(void);
 void y355_pack_pair3(const int8_t *q_w /*[64][32][3][3]*/, int8_t *dst);
+// conv4_1 -> conv4_2 + pool4 (PairParams: in = [B][H+2][W+2][64], out = [B][H/2+2][W/2+2][128], w1 = y355_pack_pair4, w2 = y355_pack_px(Y355_K_CONV4_2))
+bool y355_pair4_eligible(const Requant &rq1, const Requant &rq2, int H, int W);
+bool y355_launch_pair4(const PairParams &p, hipStream_t s);
+int y355_prepare_pair4(void);
+size_t y355_pair4_packed_bytes(void);
+void y355_pack_pair4(const int8_t *q_w /*[128][64][3][3]*/, int8_t *dst);
 // deep-prefetch ring kernels (conv3x3_ring.hip), layers with >= 64 input channels
 bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_ring(void);
