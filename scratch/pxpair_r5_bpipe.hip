@@ -104,6 +104,9 @@ __device__ __forceinline__ Epi make_epi(const Requant &rq) {
 #ifndef PAIR_ABL
 #define PAIR_ABL 0                 // timing ablations (WRONG RESULTS): 1 phase A without MFMAs, 2 phase A without the epilogue's arithmetic,
 #endif                             // 4 phase B without MFMAs, 8 phase B without the epilogue's arithmetic, 16 no phase A at all, 32 no phase B at all
+#ifndef PAIR_BPIPE
+#define PAIR_BPIPE 1               // pxpair3r_kernel: the conv3_2 waves' hot pass software-pipelined inside the wave (0: group by group)
+#endif
 #ifndef PAIR_DIAG
 #define PAIR_DIAG 0                // 1: s_memrealtime stamps (100 MHz) of thread 0 at the phase boundaries (y355_debug_stamps, layer 2)
 #endif
@@ -896,10 +899,144 @@ __global__ __launch_bounds__(512, 2) void pxpair3r_kernel(const PairParams p) {
                         int8_t *dst = outb + (((j0 + oyr) * (Wo + 2) + ox) * 64 + 8 * g);
                         *(v2u *)dst = (v2u){word[0], word[1]};
                     };
-                    {
-                        // (the hot pass software-pipelined INSIDE the wave -- the finish of group i - 1 and the addresses of group i + 1 in
-                        // slots between the MFMA pairs of group i, two accumulator sets -- is bit-exact and SLOWER: 39.5 against 37.8 us,
-                        // scratch/pxpair_r5_bpipe.hip, profiles/r05_notes.md section 7)
+                    if (PAIR_BPIPE) {
+                        // ---- hot pass, software-pipelined inside the wave: this role is alone on its SIMD's matrix pipe, and a wave cannot
+                        // issue past an MFMA that waits for the pipe -- vector work that sits in a block of its own leaves the pipe idle.
+                        // Under the 72 MFMAs of group i: the pooling / requantisation / store of group i - 1 (rows 0 and 1), the addresses
+                        // of group i + 1 (row 2, once row 3's reads have used the current ones), and every neighbourhood row is read one
+                        // row of MFMAs ahead (two rows of operands live).  Two accumulator sets.
+                        v4i bq[4][4];
+                        int xo[4], ro[4];
+                        int n_oyr = 0, n_ox = 0;                           // the group whose addresses are in xo / ro
+                        int c_oyr = 0, c_ox = 0;                           // the group whose MFMAs run
+                        int p_oyr = 0, p_ox = 0;                           // the group being finished
+                        unsigned int pword[2] = {0u, 0u};
+                        auto addr = [&](int grp, int piece) {              // group `grp` -> xo / ro, in four pieces
+                            if (piece == 0) {
+                                const int wi = wlo + min(grp * 16 + li, nwin - 1);
+                                n_oyr = (int)(((float)wi + 0.5f) * invWo);
+                                n_ox = wi - n_oyr * Wo;
+                            } else if (piece == 1) {
+                                const int ar = 2 * (j0 + n_oyr);            // even: row + 1 never wraps in the ring
+                                ro[0] = (ar & (RMID - 1)) * MPITCH;
+                                ro[1] = ro[0] + MPITCH;
+                                ro[2] = ((ar + 2) & (RMID - 1)) * MPITCH;
+                                ro[3] = ro[2] + MPITCH;
+                            } else if (piece == 2) {
+                                const int x = 2 * n_ox;                     // even: x and x + 1 share bit 4, their slots differ in bit 0
+                                xo[0] = g * PLANE + ((x ^ ((x >> 4) & 1)) << 4);
+                                xo[1] = xo[0] ^ 16;
+                            } else if (piece == 3) {
+                                const int x = 2 * n_ox + 2;
+                                xo[2] = g * PLANE + ((x ^ ((x >> 4) & 1)) << 4);
+                                xo[3] = xo[2] ^ 16;
+                            }
+                        };
+                        auto rdrow = [&](int r) {
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) bq[r][c] = *(const v4i *)(mid + ro[r] + xo[c]);
+                        };
+                        // outputs 2 rr and 2 rr + 1 of n-tile n_ of the finished group: pool, the LeakyReLU branches, extremes, bytes
+                        auto fin2 = [&](const v4i (&pacc)[4][2], int n_, int rr) {
+                            float pos[2], neg[2];
+    #pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int r = 2 * rr + u;
+                                const int m = max(max(pacc[0][n_][r], pacc[1][n_][r]), max(pacc[2][n_][r], pacc[3][n_][r]));
+                                const float tf = F2 == 2 ? __int_as_float(m) : (float)m;
+                                pos[u] = fmaf(tf, e2.sp, e2.cp);
+                                neg[u] = fmaf(tf, e2.sn, e2.cn);
+                            }
+                            zmx = qvmax3(zmx, pos[0], pos[1]);
+                            zmn = qvmin3(zmn, neg[0], neg[1]);
+                            if (rr == 0) {
+                                qmax_to_byte<0>(pword[n_], pos[0], neg[0]);
+                                qmax_to_byte<1>(pword[n_], pos[1], neg[1]);
+                            } else {
+                                qmax_to_byte<2>(pword[n_], pos[0], neg[0]);
+                                qmax_to_byte<3>(pword[n_], pos[1], neg[1]);
+                            }
+                        };
+                        auto store_prev = [&]() {
+                            int8_t *dst = outb + (((j0 + p_oyr) * (Wo + 2) + p_ox) * 64 + 8 * g);
+                            *(v2u *)dst = (v2u){pword[0], pword[1]};
+                        };
+                        // the MFMA pairs of neighbourhood row r of the group in `acc`; `slot(i)` runs behind pair i
+                        auto mmrow = [&](int r, v4i (&acc)[4][2], auto slot) {
+                            int i = 0;
+    #pragma unroll
+                            for (int dy = 0; dy < 2; ++dy) {
+                                const int ty = r - dy;
+                                if (ty < 0 || ty > 2) continue;
+    #pragma unroll
+                                for (int c = 0; c < 4; ++c)
+    #pragma unroll
+                                    for (int dx = 0; dx < 2; ++dx) {
+                                        const int tx = c - dx;
+                                        if (tx < 0 || tx > 2) continue;
+    #pragma unroll
+                                        for (int n = 0; n < 2; ++n)
+                                            acc[2 * dy + dx][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wfb[ty * 3 + tx][n], bq[r][c], acc[2 * dy + dx][n], 0, 0, 0);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        slot(i);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        ++i;
+                                    }
+                            }
+                        };
+                        // one group (its addresses in xo / ro, its row 0 already read) in `acc`; `havep`: the group before waits in `pacc`;
+                        // `nxt` >= 0: the group after
+                        auto group = [&](v4i (&acc)[4][2], const v4i (&pacc)[4][2], bool havep, int nxt) {
+    #pragma unroll
+                            for (int v = 0; v < 4; ++v)
+    #pragma unroll
+                                for (int n = 0; n < 2; ++n) acc[v][n] = cinb[n];
+                            c_oyr = n_oyr;
+                            c_ox = n_ox;
+                            rdrow(1);
+                            mmrow(0, acc, [&](int i) {                         // 6 pairs
+                                if (havep && i == 0) fin2(pacc, 0, 0);
+                                if (havep && i == 2) fin2(pacc, 0, 1);
+                                if (havep && i == 4) fin2(pacc, 1, 0);
+                            });
+                            rdrow(2);
+                            mmrow(1, acc, [&](int i) {                         // 12 pairs
+                                if (havep && i == 0) fin2(pacc, 1, 1);
+                                if (havep && i == 2) store_prev();
+                            });
+                            rdrow(3);                                          // the last use of this group's addresses
+                            mmrow(2, acc, [&](int i) {                         // 12 pairs: the next group's addresses
+                                if (nxt >= 0 && i < 8 && !(i & 1)) addr(nxt, i >> 1);
+                            });
+                            if (nxt >= 0) rdrow(0);
+                            mmrow(3, acc, [&](int) {});
+                            p_oyr = c_oyr;
+                            p_ox = c_ox;
+                        };
+                        const int ngw = ngb > st ? (ngb - st + 1) >> 1 : 0;       // this wave's groups: st, st + 2, ...
+                        if (ngw > 0) {
+                            v4i accX[4][2], accY[4][2];
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) addr(st, i);
+                            rdrow(0);
+                            int k = 0;
+                            while (k < ngw) {
+                                group(accX, accY, k > 0, k + 1 < ngw ? st + 2 * (k + 1) : -1);
+                                ++k;
+                                if (k >= ngw) break;
+                                group(accY, accX, true, k + 1 < ngw ? st + 2 * (k + 1) : -1);
+                                ++k;
+                            }
+                            if (ngw & 1) {                                     // the last group's epilogue
+    #pragma unroll
+                                for (int q = 0; q < 4; ++q) fin2(accX, q >> 1, q & 1);
+                            } else {
+    #pragma unroll
+                                for (int q = 0; q < 4; ++q) fin2(accY, q >> 1, q & 1);
+                            }
+                            store_prev();
+                        }
+                    } else {
                         v4i acc[4][2];
     #pragma unroll 1
                         for (int grp = st; grp < ngb; grp += 2) {
