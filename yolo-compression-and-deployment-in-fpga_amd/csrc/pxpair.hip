@@ -812,13 +812,16 @@ __global__ __launch_bounds__(512, 2) void pxpair3r_kernel(const PairParams p) {
                         int oyr, ox;
                         locate(grp, oyr, ox);
                         const int ar = 2 * (j0 + oyr), x0 = 2 * ox;
+                        // (ar and x0 are even: row + 1 never wraps in the ring, columns x and x + 1 share bit 4 and their slots differ in bit 0)
                         int xoff[4], roff[4];
-    #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int x = x0 + c;
-                            xoff[c] = g * PLANE + ((x ^ ((x >> 4) & 1)) << 4);
-                            roff[c] = ((ar + c) & (RMID - 1)) * MPITCH;
-                        }
+                        roff[0] = (ar & (RMID - 1)) * MPITCH;
+                        roff[1] = roff[0] + MPITCH;
+                        roff[2] = ((ar + 2) & (RMID - 1)) * MPITCH;
+                        roff[3] = roff[2] + MPITCH;
+                        xoff[0] = g * PLANE + ((x0 ^ ((x0 >> 4) & 1)) << 4);
+                        xoff[1] = xoff[0] ^ 16;
+                        xoff[2] = g * PLANE + (((x0 + 2) ^ (((x0 + 2) >> 4) & 1)) << 4);
+                        xoff[3] = xoff[2] ^ 16;
     #pragma unroll
                         for (int v = 0; v < 4; ++v)
     #pragma unroll
