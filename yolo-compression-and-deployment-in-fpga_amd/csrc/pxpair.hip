@@ -634,8 +634,6 @@ __global__ __launch_bounds__(512, 2) void pxpair3r_kernel(const PairParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                    // the band's first input rows (and, the first time, the zero fill) have landed
             stamp();
-            int8_t *const outb = p.out + (((size_t)b * (Ho + 2) + 1) * (Wo + 2) + 1) * 64 + cb * 32;
-            int wdone = 0;
             for (int t = 0; t <= nA; ++t) {
                 if (t < nA) {
                     // ---- the input rows of step t + 1, then the map rows [PA, PB) of step t: wave aw takes row PA + aw
