@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from yolo355 import prep, shard, synth
-from yolo355.engine import Engine
+from yolo355.engine import Engine, Pipeline
 
 H = W = 416
 NUM_CLASSES = 2
@@ -91,42 +91,36 @@ def quantized_layers(seed=2, **kw):
     return out
 
 
-def sparse_fixture(args, dev, streams, x):
+def sparse_fixture(args, dev, nstreams, x):
     """The same path on the 'sparse' fixture of SURVEY.md 8d / G4 (objectness bias -4, conf 0.1: a few detections per
     image instead of every anchor) -- the NMS load of a trained model rather than the random-weight worst case the
-    headline `value` is quoted on.  Same batch, streams, kernels; reported beside `value`, never instead of it."""
+    headline `value` is quoted on.  Same batch, pipeline, kernels; reported beside `value`, never instead of it."""
     B = args.batch
-    engines = []
-    for st in streams:
-        with torch.cuda.stream(st):
-            e = Engine([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.1, nms_thresh=0.5, max_batch=B, device=dev)
-            e.load_quantized(quantized_layers(2, pred_gain=400.0, obj_bias=-4.0))
-            if len(streams) > 1:
-                e.set_option(2, args.ring_workgroups)    # Y355_OPT_RING_WORKGROUPS, as the headline's timed region
-        engines.append(e)
-    sa = engines[0].calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
-    for e in engines:
-        e.set_act_exponents(sa)
-    bufs = [tuple(torch.empty_like(t) for t in engines[0]._buffers(B)) for _ in range(2 * len(engines))]
+    pipe = Pipeline([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.1, nms_thresh=0.5, max_batch=B, device=dev,
+                    handles=nstreams, ring_workgroups=args.ring_workgroups)
+    pipe.load_quantized(quantized_layers(2, pred_gain=400.0, obj_bias=-4.0))
+    pipe.calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
     torch.cuda.synchronize()
     out = None
 
-    def run(i):
-        with torch.cuda.stream(streams[i % len(engines)]):
-            return engines[i % len(engines)].forward_device(x, 0, bufs[i % len(bufs)])
-    for i in range(args.warmup):
-        out = run(i)
+    def run(n):
+        t = None
+        for _ in range(n):
+            t = pipe.submit(x, 0, ordered=False)
+        return pipe.outputs(t)
+    out = run(max(args.warmup, 1))
     times = []
     for _ in range(5 if args.repeats <= 0 else min(args.repeats, 5)):       # median of a few regions of exactly `steps` steps, like `value`
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = run(i)
+        out = run(args.steps)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
-    return {"value": round(B * args.steps / dt, 1), "unit": "images/sec", "conf_thresh": 0.1,
-            "weights": "make_weights(2, pred_gain=400, obj_bias=-4)", "detections_per_step": int(out[3][:B].sum().item())}
+    res = {"value": round(B * args.steps / dt, 1), "unit": "images/sec", "conf_thresh": 0.1,
+           "weights": "make_weights(2, pred_gain=400, obj_bias=-4)", "detections_per_step": int(out[3][:B].sum().item())}
+    pipe.close()
+    return res
 
 
 def effective_cores():
@@ -544,10 +538,9 @@ def main():
     ap.add_argument("--no-fuse-front", action="store_true",
                     help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
     ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
-    ap.add_argument("--fuse-pairs", type=int, default=-1, choices=[-1, 0, 1, 2, 4],
+    ap.add_argument("--fuse-pairs", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: conv3_1 -> conv3_2 + pool3 (Y355_OPT_FUSE_PAIRS): 0 one launch per layer, 1 fused, the layers on different waves of "
-                         "every SIMD (the default), 2 fused, every wave alternating between them, 4 = 1 plus conv4_1 -> conv4_2 + pool4 fused (measured "
-                         "no faster); -1 = the engine's default.  Same results")
+                         "every SIMD (the default); -1 = the engine's default.  Same results")
     ap.add_argument("--gather-max-det", type=int, default=256,
                     help="multi-GPU: detections per image in the all-gather records (SURVEY.md 8e: fixed-cap records, 6.1 KB per image "
                          "at 256; 0 = the engine's max_det, i.e. full records); the per-GPU forward and its outputs are unchanged. "
@@ -565,6 +558,9 @@ def main():
     ap.add_argument("--ring-workgroups", type=int, default=128,
                     help="persistent workgroups per launch of the deep convolutions while several handles share the GPU "
                          "(Y355_OPT_RING_WORKGROUPS; 0 = one per CU; a handle running alone always gets one per CU)")
+    ap.add_argument("--ordered-submit", action="store_true",
+                    help="A/B: Pipeline.submit(ordered=True): every forward is ordered behind torch's current stream with an event "
+                         "(what a caller whose input is produced right before the submit uses); the default submits resident inputs")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32 = the headline configuration (fp32 NCHW tensor resident in HBM); u8 = uint8 HWC BGR "
                          "frames with BaseTransform fused into the first layer (SURVEY 8f-1), same detections")
@@ -602,34 +598,30 @@ def main():
     cdev = torch.device("cpu") if gloo else dev          # where the small control tensors of the collectives live
     B = args.batch
 
-    # Engine handles per GPU, each on its own HIP stream; steps alternate between them, so the
-    # detection head / NMS of one batch (few, latency-bound workgroups) and the kernel-boundary
-    # bubbles of one stream are filled by the convolutions of the next batch on the other stream.
-    # Handles are independent by contract (include/yolo355.h); every step is still one whole pass
-    # over one batch of B images and all K steps complete inside the timed region.
+    # The product's throughput regime (y355_pipeline, include/yolo355.h): `--streams` engine handles per GPU, each on its own HIP
+    # stream; the submitted batches are dealt to them round-robin, so the detection head / NMS of one batch (few, latency-bound
+    # workgroups) and the kernel-boundary bubbles of one stream are filled by the convolutions of the next batch on another
+    # stream.  The timed region below calls Pipeline.submit -- the entry point models.SlimYOLOv2_quantize_bnfuse.forward_batch
+    # and the batched evaluators run; every step is still one whole pass over one batch of B images and all
+    # K steps complete inside the timed region.  `engines` are views of the pipeline's handles for the diagnostic passes.
     nstreams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    engines = []
-    for st in streams:
-        with torch.cuda.stream(st):
-            e = Engine([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.01, nms_thresh=0.5,
-                       max_batch=B, device=dev)
-            e.load_quantized(quantized_layers(2))
-            if args.no_fuse_front:
-                e.set_option(1, 0)                       # Y355_OPT_FUSE_FRONT
-            if args.fuse_pairs >= 0:
-                e.set_option(3, args.fuse_pairs)         # Y355_OPT_FUSE_PAIRS
-        engines.append(e)
+    pipe = Pipeline([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.01, nms_thresh=0.5, max_batch=B, device=dev,
+                    handles=nstreams, ring_workgroups=args.ring_workgroups)
+    pipe.load_quantized(quantized_layers(2))
+    if args.no_fuse_front:
+        pipe.set_option(1, 0)                            # Y355_OPT_FUSE_FRONT
+    if args.fuse_pairs >= 0:
+        pipe.set_option(3, args.fuse_pairs)              # Y355_OPT_FUSE_PAIRS
+    engines = [pipe.engine(i) for i in range(nstreams)]
+    streams = [e._stream for e in engines]               # the handles' own HIP streams (torch views)
     eng = engines[0]
-    # calibrate once (first-call semantics, slim_yolo_v2.py:25-27) on the seed-1 image, rank 0;
-    # every rank gets the same 11 exponents
+    # calibrate once (first-call semantics, slim_yolo_v2.py:25-27) on the seed-1 image, rank 0 (y355_pipeline_calibrate);
+    # every rank and handle gets the same 11 exponents
     sa = None
     if rank == 0:
-        with torch.cuda.stream(streams[0]):
-            sa = eng.calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
+        sa = pipe.calibrate(synth.make_images(1, 1, H, W), [prep.RangeTracker() for _ in range(11)])
     sa = shard.broadcast_exponents(sa, 0, cdev)
-    for e in engines:
-        e.set_act_exponents(sa)
+    pipe.set_act_exponents(sa)
 
     # rank r owns global images [r*B, (r+1)*B): the seed-1000 batch rolled r pixels along W (every rank can rebuild any
     # other rank's shard on its own GPU: the verification below).  The timed loop rotates N_INPUTS distinct batches (the shard
@@ -677,24 +669,35 @@ def main():
         return [w] if async_op else []
     torch.cuda.synchronize()
 
+    direct = [False]      # True: rounds 2-5's scheduler (bench.py deals the steps to the handles itself) instead of Pipeline.submit
+
     def step(i, pending, ns, rotate=True, g=None, solo=False):
         g = G if g is None else g
         k = i % nbuf
         j = i % N_INPUTS if rotate else 0
-        with torch.cuda.stream(streams[i % ns]):      # the engine's own stream: no cross-stream waits are inserted
-            if dist_on and not solo and pending[k] is not None:    # buffer reuse: its gather (2 x streams steps ago) must be done
-                for w in pending[k]:
-                    w.wait()
+        if ns == nstreams and not direct[0]:
+            # ---- the product entry point: one Pipeline.submit per step (the inputs are resident and complete: ordered=False)
+            inp = fs[j] if fs is not None else xs[j]
+            if not (dist_on and not solo):
+                pipe.submit(inp, 0, out=bufs[k], frames=fs is not None, ordered=args.ordered_submit)
+                return bufs[k]
+            with torch.cuda.stream(pipe.stream(pipe.next_ticket)):      # the stream of the handle this ticket goes to
+                if pending[k] is not None:               # buffer reuse: its gather (2 x streams steps ago) must be done
+                    for w in pending[k]:
+                        w.wait()
+                pipe.submit(inp, 0, out=bufs[k], frames=fs is not None, ordered=False)
+                # ONE packed all-gather per batch: one pack launch on the handle's stream, then the collective,
+                # which orders itself after that stream and runs on RCCL's own -- asynchronous, no other stream involved
+                # (packing with torch ops on the default stream and waiting across streams halved the per-GPU rate)
+                shard.pack_detections_kernel(*[t[:B] for t in bufs[k]], B, g["send"][k], g["md"])
+                pending[k] = gather(g, k, True)
+            return bufs[k]
+        # ---- `ns` handles driven directly (ns = 1: one handle on one stream, the latency of a batch)
+        with torch.cuda.stream(streams[i % ns]):
             if fs is not None:
                 out = engines[i % ns].forward_frames_device(fs[j], 0, bufs[k])
             else:
                 out = engines[i % ns].forward_device(xs[j], 0, bufs[k])
-            if dist_on and not solo:
-                # ONE packed all-gather per batch: one pack launch on the engine's stream, then the collective,
-                # which orders itself after that stream and runs on RCCL's own -- asynchronous, no other stream involved
-                # (packing with torch ops on the default stream and waiting across streams halved the per-GPU rate)
-                shard.pack_detections_kernel(*[t[:B] for t in out], B, g["send"][k], g["md"])
-                pending[k] = gather(g, k, True)
         return out
 
     own_times = []        # this rank's OWN clock around its steps of every region of the headline run (before the barrier)
@@ -765,6 +768,14 @@ def main():
                          "note": "rank 0 alone in the same process: no barrier, no pack, no gather, the other ranks idle -- the N = 1 "
                                  "line of the scaling curve measured inside the N = %d run" % world}
         dist.barrier()
+    # the same region with the steps dealt to the handles by this script (rounds 2-5's measurement) instead of Pipeline.submit:
+    # the product entry point must not cost throughput (within 2 %)
+    hand = None
+    if nstreams > 1 and not dist_on:
+        direct[0] = True
+        t_hand, _ = timed(nstreams, args.steps, min(args.warmup, 5), 7)
+        direct[0] = False
+        hand = float(np.median(t_hand))
     # the same with ONE input batch fed to every step (what rounds 1 and 2 reported: part of it stays in the Infinity Cache)
     t_same, _ = timed(nstreams, args.steps, min(args.warmup, 5), 5, False)
     dt_same = float(np.median(t_same))
@@ -914,19 +925,16 @@ def main():
         pair3 = have_k and kernel_ms[2] > 0 and kernel_ms[3] == 0
         knames = ((["conv1+conv2 (fused front end)"] if fused else ["conv1"]) + LAYER_NAMES[1:] +
                   ["decode_kernel", "head_kernel", "pairs_kernel", "resolve_emit_kernel"])
-        pair4 = have_k and kernel_ms[4] > 0 and kernel_ms[5] == 0
         if pair3:
             knames[2] = "conv3_1+conv3_2 (fused pair)"
-        if pair4:
-            knames[4] = "conv4_1+conv4_2 (fused pair)"
         layers = {}
         for i, n in enumerate(LAYER_NAMES):
-            if (pair3 and i == 2) or (pair4 and i == 4):
+            if pair3 and i == 2:
                 layers[knames[i]] = dict(
                     ms=round(float(layer_ms[i] + layer_ms[i + 1]), 4),
                     tops=round(B * 2e6 * (LAYER_MMAC[i] + LAYER_MMAC[i + 1]) / ((layer_ms[i] + layer_ms[i + 1]) * 1e-3) / 1e12, 1))
                 continue
-            if (pair3 and i == 3) or (pair4 and i == 5):
+            if pair3 and i == 3:
                 continue
             if fused and i == 0:
                 layers["conv1+conv2 (fused front end)"] = dict(
@@ -1001,6 +1009,13 @@ def main():
             "value": round(world * B * args.steps / dt_same, 1), "unit": "images/sec", "ms_per_step": round(dt_same / args.steps * 1e3, 4),
             "note": "ONE input batch fed to every step (rounds 1 / 2): part of its 133 MB stays in the 256 MB Infinity Cache; "
                     "`value` rotates %d distinct batches" % N_INPUTS}
+        res["config"]["entry_point"] = ("Pipeline.submit -> y355_pipeline_submit%s (include/yolo355.h), %d handles, outputs in caller buffers"
+                                        % ("_u8" if args.input == "u8" else "", nstreams))
+        if hand is not None:
+            res["hand_scheduled"] = {"value": round(world * B * args.steps / hand, 1), "unit": "images/sec",
+                                     "ms_per_step": round(hand / args.steps * 1e3, 4),
+                                     "note": "the same region with bench.py dealing the steps to the handles itself (y355_forward per handle on its "
+                                             "stream: what rounds 2-5 measured); `value` goes through the pipeline entry point"}
         if gather_info is not None:
             res.update(gather_info)
         if one is not None:
@@ -1009,7 +1024,7 @@ def main():
                                  "whole_path_frac": round(v1 / world * OPS_PER_IMAGE / PEAK_I8_DENSE, 4),
                                  "note": "one engine handle on one stream: ms_per_step is the latency of a batch"}
         if world == 1 and not args.no_sparse:
-            res["sparse_fixture"] = sparse_fixture(args, dev, streams, x)
+            res["sparse_fixture"] = sparse_fixture(args, dev, nstreams, x)
         if world == 1 and not args.no_sparse and args.input == "f32":
             # the same workload fed as uint8 HWC BGR frames (BaseTransform fused into the first layer): a quarter of
             # the input bytes, same kernels behind the front end, same detections (tests/test_gpu_parity.py)
@@ -1020,8 +1035,7 @@ def main():
 
             def run_u8(n):
                 for i in range(n):
-                    with torch.cuda.stream(streams[i % nstreams]):
-                        engines[i % nstreams].forward_frames_device(frs[i % N_INPUTS], 0, bufs[i % nbuf])
+                    pipe.submit(frs[i % N_INPUTS], 0, out=bufs[i % nbuf], frames=True, ordered=False)
             run_u8(max(5, nstreams))
             tu = []
             for _ in range(5):
@@ -1073,6 +1087,8 @@ def main():
             pass
         print(json.dumps(res), flush=True)
     failed = gather_info is not None and not gather_info["gather_verified"]
+    torch.cuda.synchronize()
+    pipe.close()
     if dist_on:
         if world > 1:
             flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=cdev)

@@ -89,13 +89,12 @@ int y355_set_thresholds(y355_engine *h, float conf_thresh, float nms_thresh);
  * c_embedding/yolo_forward.c:1214-1225) as one launch whose 64-channel intermediate map stays in LDS
  * (y355_get_feature(h, 2, ...) returns Y355_ENOTREADY after such a forward); 0 = one launch per layer.  The fused launch is
  * used where both layers qualify for the fp32-exact epilogue without an accumulator shift and the map is at most 104 pixels
- * wide; calibration, statistics runs and guarded forwards (Y355_F_GUARD) always run layer by layer.
- * Value 1 = the production schedule: conv3_1 on the first wave of every SIMD, conv3_2 + pool on the second, one interval apart
- * (+4.5 % images/s against two launches, three handles); 2 = the first schedule built (every wave alternates between the two
- * layers, barrier to barrier: +2.2 %), kept for comparison; 4 = 1 plus conv4_1, conv4_2 and pool4 (:268-289; calls 5 and 6,
- * :1226-1236; maps 16 .. 64 pixels wide) fused the same way -- built, bit-exact, measured NO faster than their two launches (42.4
- * against 16.4 + 25.1 us: every wave of a role reads every pixel, the LDS is the bound), so it is off unless asked for
- * (y355_get_feature(h, 4, ...) returns Y355_ENOTREADY then).  Results are identical bit for bit in all settings. */
+ * wide (network input up to 416 wide; wider maps fall back to the two launches); calibration, statistics runs and guarded
+ * forwards (Y355_F_GUARD) always run layer by layer.  Schedule: conv3_1 on the first wave of every SIMD, conv3_2 + pool on the
+ * second, one interval apart (+4.5 % images/s against two launches, three handles).  Round 5's two other schedules (every wave
+ * alternating between the layers: +2.2 %; conv4_1 -> conv4_2 + pool4 fused the same way: bit-exact, no faster than its two
+ * launches) left the library in round 6 -- scratch/pxpair_r5_all_three_kernels.hip, profiles/r05_notes.md sections 3-5.
+ * Results are identical bit for bit in both settings.  Values other than 0 / 1: Y355_EINVAL. */
 #define Y355_OPT_FUSE_PAIRS 3
 int y355_set_option(y355_engine *h, int option, int value);
 
@@ -121,6 +120,21 @@ int y355_input_absmax(y355_engine *h, const float *x_dev, int batch, float *out_
  * conv+bias+leaky+requant(+pool).  mode 1: statistics only (fills absmax_t, writes nothing).
  * Layer 0 reads x_dev (fp32 NCHW) and quantises it with sa[0]; other layers ignore x_dev. */
 int y355_run_layer(y355_engine *h, int idx, int batch, int mode, const float *x_dev);
+/* --- calibration in one call: AveragedRangeTracker.quantize_activation's state machine (models/slim_yolo_v2.py:16-38) for the 11
+ * trackers of the path, kept in the handle in the reference's float32 arithmetic (scale = reciprocal(max) * 127 as Python's
+ * int / tensor computes it; first call ever: scale += 127 / max even when frozen, :25-27; frozen: unchanged, :28-29; else
+ * scale = scale * (1 - momentum) + 127 / max * momentum, :30-31; exponent = floor(log2(scale)), :33).
+ *   y355_set_trackers / y355_get_trackers: the checkpoint buffers a_tracker*.scale / first_a (:13-14), 11 each, host arrays
+ *   y355_calibrate: one step on a batch = what forward(x, quantization=True) does to the trackers -- layer by layer on the
+ *     GPU, every tracker seeing max|activation| of its layer run with the exponents updated in front of it; leaves the 11
+ *     exponents set in the handle (and in sa_out[11] / the maxima seen in max_out[11], either may be NULL).  freeze = the
+ *     reference's eval mode (trackers only change on their first call), momentum = AveragedRangeTracker.momentum (0.1, :10).
+ *     x_dev fp32 NCHW [B,3,H,W] device pointer; synchronous.
+ *   y355_tracker_step: the update of ONE tracker as a host utility (no GPU): the arithmetic y355_calibrate applies. */
+int y355_set_trackers(y355_engine *h, const float *scale, const int32_t *first_a);
+int y355_get_trackers(y355_engine *h, float *scale, int32_t *first_a);
+int y355_calibrate(y355_engine *h, const float *x_dev, int batch, int freeze, double momentum, int32_t *sa_out, float *max_out);
+int y355_tracker_step(float *scale, int32_t *first_a, float max_abs, int freeze, double momentum, int32_t *exponent);
 /* synchronous read-back of a layer's counters */
 int y355_layer_stats_get(y355_engine *h, int idx, y355_layer_stats *out);
 /* parity tap: copy layer idx's int8 output [B][C][Ho][Wo] (NCHW, halo stripped) to host. */
@@ -264,8 +278,69 @@ int y355_pack_dets_capped(const float *boxes_dev, const float *scores_dev, const
 int y355_unpack_dets(const void *packed_dev, const int32_t *slot_dev, int records, int max_det, float *boxes_dev,
                      float *scores_dev, int32_t *cls_dev, int32_t *count_dev, void *stream);
 
+/* --- y355_pipeline: the throughput regime as a product entry point (csrc/pipeline.hip).  The reference's callers hand the
+ * network one batch after another (test.py:84; the evaluator loops utils/vocapi_evaluator_mask.py:57-82,
+ * utils/cocoapi_evaluator.py:70-98).  A pipeline owns `handles` engines, each on its own HIP stream, and deals the submitted
+ * batches to them round-robin, so that the detection head / NMS of batch i runs beside the convolutions of batch i + 1
+ * (+50 % images/s over one handle on one MI355X, profiles/).  Every ticket's result equals a stand-alone y355_forward's bit
+ * for bit.  One pipeline is single-threaded like a handle.
+ *   create      handles: 1..8, 0 = the measured optimum (3); ring_workgroups: Y355_OPT_RING_WORKGROUPS of the handles while
+ *               more than one shares the GPU, < 0 = the measured optimum (128).  cfg->stream / own_stream are ignored: every
+ *               handle gets its own non-blocking stream (y355_pipeline_create) or the caller's (y355_pipeline_create_on).
+ *   load_layer / set_act_exponents / set_retune / set_thresholds / set_normalization / set_option / set_trackers: the engine
+ *               call of the same name on every handle
+ *   calibrate   y355_calibrate on handle 0, then the same trackers and exponents on every handle
+ *   submit      enqueue one forward (asynchronous), ticket numbers count from 0.  flags: Y355_F_* | Y355_PIPE_AFTER_STREAM (the
+ *               input is produced on `caller_stream`: the forward is ordered behind what is queued there; without the flag the
+ *               input must already be complete and caller_stream is ignored).  Outputs: the caller's four device buffers (shapes
+ *               as y355_forward) or, all four NULL, pipeline-owned ones read with y355_pipeline_outputs.  A ticket and its
+ *               pipeline-owned outputs live until y355_pipeline_depth() (= 2 x handles) further submits.
+ *   wait        on_stream = 0: block the host until the ticket is done; 1: make `caller_stream` wait for it (no host block)
+ *   release     optional: tell the pipeline that work queued on `caller_stream` so far is the last reader of the ticket's
+ *               outputs -- the submit that reuses the ticket's slot is ordered behind it
+ *   fetch       wait + copy the detections to host arrays [B][max_det][4] / [B][max_det] / [B][max_det] / [B]; synchronous
+ *   scale_boxes y355_scale_boxes on the ticket's outputs (call right after its submit)
+ *   counters    y355_forward_counters summed over the handles' last forwards
+ *   engine(i)   handle i for the taps / statistics calls of the engine ABI (do not run forwards on it while tickets are in flight)
+ *   stream      the HIP stream of the handle that runs `ticket` */
+typedef struct y355_pipeline y355_pipeline;
+#define Y355_PIPE_AFTER_STREAM 0x100
+int y355_pipeline_create(const y355_config *cfg, int handles, int ring_workgroups, y355_pipeline **out);
+/* the same on `handles` HIP streams of the caller (streams[i] for handle i; `handles` >= 1 here): for hosts whose allocator tracks
+ * memory per stream (PyTorch) and must therefore own, and outlive, every stream its tensors are used on */
+int y355_pipeline_create_on(const y355_config *cfg, int handles, int ring_workgroups, void *const *streams, y355_pipeline **out);
+void y355_pipeline_destroy(y355_pipeline *p);
+int y355_pipeline_handles(y355_pipeline *p);
+int y355_pipeline_depth(y355_pipeline *p);
+int y355_pipeline_max_det(y355_pipeline *p);
+y355_engine *y355_pipeline_engine(y355_pipeline *p, int i);
+void *y355_pipeline_stream(y355_pipeline *p, long long ticket);
+int y355_pipeline_load_layer(y355_pipeline *p, int idx, const int8_t *q_w, const int32_t *q_b, int cout, int cin, int e_w, int e_b);
+int y355_pipeline_set_act_exponents(y355_pipeline *p, const int32_t *sa);
+int y355_pipeline_set_retune(y355_pipeline *p, const int32_t *retune);
+int y355_pipeline_set_thresholds(y355_pipeline *p, float conf_thresh, float nms_thresh);
+int y355_pipeline_set_normalization(y355_pipeline *p, const float *mean_bgr, const float *std_bgr);
+int y355_pipeline_set_option(y355_pipeline *p, int option, int value);
+int y355_pipeline_set_trackers(y355_pipeline *p, const float *scale, const int32_t *first_a);
+int y355_pipeline_get_trackers(y355_pipeline *p, float *scale, int32_t *first_a);
+int y355_pipeline_calibrate(y355_pipeline *p, const float *x_dev, int batch, int freeze, double momentum, int32_t *sa_out,
+                            float *max_out);
+int y355_pipeline_submit(y355_pipeline *p, const float *x_dev, int batch, int flags, void *caller_stream, float *boxes_dev,
+                         float *scores_dev, int32_t *cls_dev, int32_t *count_dev, long long *ticket);
+int y355_pipeline_submit_u8(y355_pipeline *p, const uint8_t *frames_dev, int batch, int flags, void *caller_stream, float *boxes_dev,
+                            float *scores_dev, int32_t *cls_dev, int32_t *count_dev, long long *ticket);
+int y355_pipeline_wait(y355_pipeline *p, long long ticket, int on_stream, void *caller_stream);
+int y355_pipeline_outputs(y355_pipeline *p, long long ticket, float **boxes_dev, float **scores_dev, int32_t **cls_dev,
+                          int32_t **count_dev, int *batch);
+int y355_pipeline_release(y355_pipeline *p, long long ticket, void *caller_stream);
+int y355_pipeline_fetch(y355_pipeline *p, long long ticket, float *boxes, float *scores, int32_t *cls, int32_t *count);
+int y355_pipeline_scale_boxes(y355_pipeline *p, long long ticket, const float *wh_dev);
+int y355_pipeline_counters(y355_pipeline *p, int64_t *saturated, int64_t *guard);
+int y355_pipeline_sync(y355_pipeline *p);
+
 /* --- measurement helpers: HIP events on the engine's stream ------------------------------ */
 int y355_sync(y355_engine *h);
+void *y355_stream(y355_engine *h);           /* the hipStream_t the handle launches on */
 /* per-kernel device time of the last forward run with profiling enabled (ms);
  * slots 0..9 = layers, 10 = head decode, 11 = NMS.  y355_profile(h, 1) turns recording on. */
 #define Y355_NUM_TIMERS 12

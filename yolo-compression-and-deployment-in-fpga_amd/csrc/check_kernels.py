@@ -18,7 +18,7 @@ SIGFILE = os.path.join(HERE, "ring_signature.json")
 
 def signatures(build):
     """Per counted-wait kernel of build/*.s: {LDS-DMA instructions, global stores, MFMAs, histogram of `s_waitcnt vmcnt(N)`}.
-    The waits of conv3x3_ring.hip / convpx.hip / convr.hip / pxpair.hip (pxpair3_kernel) are constants derived from how many LDS-DMA pieces and output stores a wave
+    The waits of conv3x3_ring.hip / convpx.hip / convr.hip / pxpair.hip (pxpair3r_kernel) are constants derived from how many LDS-DMA pieces and output stores a wave
     has issued since the data it waits for (vmcnt retires in issue order): if a compiler or a source edit changes any of
     these counts, the constants must be re-derived and the kernels re-validated under load before the signature is updated
     (`python3 check_kernels.py build --record`)."""
@@ -28,7 +28,7 @@ def signatures(build):
         for line in open(f, errors="replace"):
             m = re.match(r"^(_Z\w+):", line)
             if m:
-                name = m.group(1) if any(g in m.group(1) for g in ("conv3x3_i8_ring_kernel", "convpx_kernel", "convr_kernel", "pxpair3_kernel")) else None
+                name = m.group(1) if any(g in m.group(1) for g in ("conv3x3_i8_ring_kernel", "convpx_kernel", "convr_kernel", "pxpair3r_kernel")) else None
                 if name:
                     out[name] = {"lds_dma": 0, "stores": 0, "mfma": 0, "vmcnt": {}}
                 continue

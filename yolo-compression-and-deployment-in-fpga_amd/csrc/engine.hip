@@ -54,7 +54,6 @@ struct Layer {
     std::vector<int32_t> q_b;
     int8_t *w_dev = nullptr;
     int8_t *wpx_dev = nullptr;      // conv3_1 .. conv4_2: the same weights in convpx.hip's fragment order
-    int8_t *wpair_dev = nullptr;    // conv3_1: the same weights in pxpair.hip's fragment order (fused conv3_1 -> conv3_2 + pool)
     long long wabs = 0;             // max over output channels of sum |q_w| (0: not loaded): the tight bound of |acc| / 127
     int *bias_dev = nullptr;
     long long *bias_w_dev = nullptr;
@@ -76,8 +75,6 @@ int y355_prepare_kernels() {
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(head): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_ring())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(ring): ") + hipGetErrorString((hipError_t)e));
-    if (int e = y355_prepare_pair4())
-        return fail(Y355_EHIP, std::string("hipFuncSetAttribute(pair4): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_pair3())
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(pair3): ") + hipGetErrorString((hipError_t)e));
     if (int e = y355_prepare_conv_px())
@@ -86,6 +83,19 @@ int y355_prepare_kernels() {
         return fail(Y355_EHIP, std::string("hipFuncSetAttribute(convg): ") + hipGetErrorString((hipError_t)e));
     kernels_prepared = 1;
     return 0;
+}
+// compute units of the current device: the grid of the one-workgroup-per-CU launches (not the literal 256, so that a
+// partitioned or smaller part does not serialise 157 KiB-of-LDS workgroups in waves)
+int y355_cu_count(void) {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
 }
 namespace {
 int prepare_kernels() { return y355_prepare_kernels(); }
@@ -149,23 +159,16 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
 }
 }  // namespace
 
-struct GraphKey {
-    const void *x, *boxes, *scores, *cls, *count;
-    int batch, flags;
-    float conf, nms;
-};
-struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
-
 struct y355_engine {
     y355_config cfg{};
-    std::vector<GraphEntry> graphs;
-    hipStream_t cap_stream = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     Layer L[10];
     int sa[11];
     bool sa_set[11];
     int retune[10];
+    float trk_scale[11] = {};       // AveragedRangeTracker.scale / first_a of the 11 trackers (models/slim_yolo_v2.py:13-14), y355_calibrate
+    int trk_first[11] = {};
     float nmean[3] = {0.485f, 0.456f, 0.406f};   // BaseTransform constants, RGB order (data/__init__.py:50 lists BGR)
     float nstd[3] = {0.229f, 0.224f, 0.225f};
     const uint8_t *x_u8 = nullptr;  // uint8 frames of the forward being enqueued (y355_forward_u8)
@@ -175,7 +178,8 @@ struct y355_engine {
     int rs_src_h = 0, rs_src_w = 0;
     int8_t *w0_dev = nullptr;       // conv1 fragment
     int8_t *wf_dev = nullptr;       // weight fragments of the fused front end (y355_pack_front)
-    Counters *ctr_dev = nullptr;    // [10]
+    Counters *ctr_dev = nullptr;    // [10]: the set the last forward / layer run counted into (one of ctrs' two)
+    CounterSets ctrs;
     unsigned int *absmax_dev = nullptr;
     int8_t *sink_dev = nullptr;
     unsigned long long *stamps_dev = nullptr;
@@ -193,9 +197,7 @@ struct y355_engine {
     int profile = 0;
     int fuse_front = 1;             // conv1 + pool1 + conv2 + pool2 as one launch (front.hip) where eligible
     int fuse_pairs = 1;             // conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip) where eligible
-    int pair_variant = 1;           // pxpair.hip: 1 the two layers on different waves of every SIMD (default), 0 every wave alternates between them
     int l2_batch = 0;               // images of conv3_1's map that the last launches left valid in L[2].out_dev (the fused pair writes none)
-    int l4_batch = 0;               // the same for conv4_1's map (L[4].out_dev)
     int l0_batch = 0;               // images of conv1's pooled map that the last launches left valid in L[0].out_dev (the fused
                                     // front end keeps that map on chip: 0 after a fused forward)
     int ring_wgs = 0;               // persistent workgroups per ring launch (0 = one per CU)
@@ -225,8 +227,6 @@ extern "C" void y355_destroy(y355_engine *h) {
         for (auto &e : h->kev) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
 }
 
@@ -293,7 +293,10 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
     const size_t cap = Y355_NMS_CAP;
     if (!rc) rc = dmalloc(h, (void **)&h->w0_dev, 1024, true);
     if (!rc) rc = dmalloc(h, (void **)&h->wf_dev, 16384, true);
-    if (!rc) rc = dmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * 10, true);
+    if (!rc) rc = dmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * 20, true);
+    h->ctrs.base = h->ctr_dev;
+    h->ctrs.n = 10;
+    h->ctrs.clean[0] = h->ctrs.clean[1] = true;        // zeroed by the allocation
     if (!rc) rc = dmalloc(h, (void **)&h->absmax_dev, 16, true);
     if (!rc) rc = dmalloc(h, (void **)&h->sink_dev, 16384, true);
     if (!rc) rc = dmalloc(h, &h->ws.cbox, sizeof(float) * 4 * cap * B, false);
@@ -338,8 +341,14 @@ extern "C" int y355_create(const y355_config *cfg, y355_engine **out) {
 extern "C" int y355_set_option(y355_engine *h, int option, int value) {
     if (!h) return fail(Y355_EINVAL, "null engine");
     switch (option) {
-    case Y355_OPT_FUSE_FRONT: h->fuse_front = value ? 1 : 0; return 0;
-    case Y355_OPT_FUSE_PAIRS: h->fuse_pairs = value ? (value == 4 ? 2 : 1) : 0; h->pair_variant = value == 2 ? 0 : 1; return 0;
+    case Y355_OPT_FUSE_FRONT:
+        if (value != 0 && value != 1) return fail(Y355_EINVAL, "Y355_OPT_FUSE_FRONT takes 0 or 1");
+        h->fuse_front = value;
+        return 0;
+    case Y355_OPT_FUSE_PAIRS:
+        if (value != 0 && value != 1) return fail(Y355_EINVAL, "Y355_OPT_FUSE_PAIRS takes 0 or 1");
+        h->fuse_pairs = value;
+        return 0;
     case Y355_OPT_RING_WORKGROUPS:
         if (value < 0 || value > 4096) return fail(Y355_EINVAL, "workgroups per launch out of range");
         h->ring_wgs = value;
@@ -404,22 +413,6 @@ extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const
             HIPCHK(hipMemcpy(L.wpx_dev, px.data(), px.size(), hipMemcpyHostToDevice));
         }
     }
-    if (idx == 4 && cin == 64 && cout == 128) {
-        std::vector<int8_t> pw(y355_pair4_packed_bytes());
-        y355_pack_pair4(q_w, pw.data());
-        if (!L.wpair_dev) {
-            if (int rc = dmalloc(h, (void **)&L.wpair_dev, pw.size(), false)) return rc;
-        }
-        HIPCHK(hipMemcpy(L.wpair_dev, pw.data(), pw.size(), hipMemcpyHostToDevice));
-    }
-    if (idx == 2 && cin == 32 && cout == 64) {
-        std::vector<int8_t> pw(y355_pair3_packed_bytes());
-        y355_pack_pair3(q_w, pw.data());
-        if (!L.wpair_dev) {
-            if (int rc = dmalloc(h, (void **)&L.wpair_dev, pw.size(), false)) return rc;
-        }
-        HIPCHK(hipMemcpy(L.wpair_dev, pw.data(), pw.size(), hipMemcpyHostToDevice));
-    }
     L.q_b.assign(q_b, q_b + cout);
     L.e_w = e_w;
     L.e_b = e_b;
@@ -430,16 +423,22 @@ extern "C" int y355_load_layer(y355_engine *h, int idx, const int8_t *q_w, const
 
 extern "C" int y355_set_act_exponents(y355_engine *h, const int32_t *sa) {
     if (!h || !sa) return fail(Y355_EINVAL, "null argument");
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < 11; ++i)
         if (sa[i] < -64 || sa[i] > 64) return fail(Y355_EINVAL, "activation exponent out of range");
+    // only what changes makes a layer's epilogue stale (callers set the same frozen exponents before every forward: that must
+    // not cost ten bias uploads and stream synchronisations per call)
+    for (int i = 0; i < 11; ++i) {
+        if (h->sa_set[i] && h->sa[i] == sa[i]) continue;
         h->sa[i] = sa[i];
         h->sa_set[i] = true;
+        if (i < 10) h->L[i].bias_dirty = true;
+        if (i > 0) h->L[i - 1].bias_dirty = true;
     }
-    for (auto &L : h->L) L.bias_dirty = true;
     return 0;
 }
 
 static int set_one_exponent(y355_engine *h, int i, int v) {
+    if (h->sa_set[i] && h->sa[i] == v) return 0;
     h->sa[i] = v;
     h->sa_set[i] = true;
     if (i < 10) h->L[i].bias_dirty = true;
@@ -460,8 +459,11 @@ extern "C" int y355_get_act_exponents(y355_engine *h, int32_t *sa) {
 
 extern "C" int y355_set_retune(y355_engine *h, const int32_t *r) {
     if (!h || !r) return fail(Y355_EINVAL, "null argument");
-    for (int i = 0; i < 10; ++i) h->retune[i] = r[i];
-    for (auto &L : h->L) L.bias_dirty = true;
+    for (int i = 0; i < 10; ++i) {
+        if (h->retune[i] == r[i]) continue;
+        h->retune[i] = r[i];
+        h->L[i].bias_dirty = true;
+    }
     return 0;
 }
 
@@ -542,7 +544,6 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         constexpr int no_ring_mask = 0, no_px_mask = 0;
 #endif
         if (k == 2 && mode == 0) h->l2_batch = B;
-        if (k == 4 && mode == 0) h->l4_batch = B;
         if (L.wpx_dev && !((no_px_mask >> k) & 1)) {
             ConvParams q = p;
             q.w = L.wpx_dev;
@@ -602,6 +603,95 @@ extern "C" int y355_layer_stats_get(y355_engine *h, int idx, y355_layer_stats *o
     return 0;
 }
 
+// ---- AveragedRangeTracker.quantize_activation's state machine (models/slim_yolo_v2.py:16-38) for the 11 trackers of the
+// path, in the reference's float32 arithmetic:
+//   _max = activation.abs().max(); scale = 127 / _max        -- Python int / tensor = Tensor.__rtruediv__ = reciprocal() * 127: TWO
+//                                                               fp32 roundings, reproduced here
+//   first call ever (first_a == 0, even when frozen, :25-27): first_a = 1, self.scale += scale
+//   frozen (:28-29): unchanged;  else (:30-31) self.scale = self.scale * (1 - momentum) + scale * momentum, the Python doubles
+//   1 - momentum and momentum each rounded to fp32 by the tensor-scalar ops
+//   exponent = floor(log2(self.scale)) (:33), log2 in fp32
+static int tracker_update(float *scale, int *first, int i, float max_abs, int freeze, double momentum, int *exp_out) {
+    const float s = (1.0f / max_abs) * 127.0f;
+    if (!*first) {
+        *first = 1;
+        *scale = *scale + s;
+    } else if (!freeze) {
+        const float keep = (float)(1.0 - momentum), mom = (float)momentum;
+        *scale = *scale * keep + s * mom;
+    }
+    const float sc = *scale;
+    if (!(sc > 0.f) || !std::isfinite(sc)) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "tracker %d: scale %g is not a positive finite number (max|activation| = %g)", i, (double)sc, (double)max_abs);
+        return fail(Y355_ERANGE, buf);
+    }
+    const int e = (int)std::floor(std::log2(sc));
+    if (e < -64 || e > 64) return fail(Y355_ERANGE, "tracker exponent out of range");
+    *exp_out = e;
+    return 0;
+}
+
+// the update of ONE tracker as a host utility (no GPU): the arithmetic y355_calibrate applies, testable against torch on the CPU
+extern "C" int y355_tracker_step(float *scale, int32_t *first_a, float max_abs, int freeze, double momentum, int32_t *exponent) {
+    if (!scale || !first_a || !exponent) return fail(Y355_EINVAL, "null argument");
+    int first = *first_a ? 1 : 0, e = 0;
+    const int rc = tracker_update(scale, &first, 0, max_abs, freeze, momentum, &e);
+    *first_a = first;
+    if (!rc) *exponent = e;
+    return rc;
+}
+
+extern "C" int y355_set_trackers(y355_engine *h, const float *scale, const int32_t *first_a) {
+    if (!h || !scale || !first_a) return fail(Y355_EINVAL, "null argument");
+    for (int i = 0; i < 11; ++i) {
+        h->trk_scale[i] = scale[i];
+        h->trk_first[i] = first_a[i] ? 1 : 0;
+    }
+    return 0;
+}
+
+extern "C" int y355_get_trackers(y355_engine *h, float *scale, int32_t *first_a) {
+    if (!h || !scale || !first_a) return fail(Y355_EINVAL, "null argument");
+    for (int i = 0; i < 11; ++i) {
+        scale[i] = h->trk_scale[i];
+        first_a[i] = h->trk_first[i];
+    }
+    return 0;
+}
+
+// One calibration step on a batch: what forward(x, quantization=True) does to the trackers (:212-328), layer by layer on the
+// GPU -- every tracker sees max|activation| of its layer computed with the exponents just updated in front of it, and the
+// layer then runs for real so that the next one reads the reference's fake-quantised map.  Leaves the engine's exponents set.
+extern "C" int y355_calibrate(y355_engine *h, const float *x_dev, int batch, int freeze, double momentum, int32_t *sa_out,
+                              float *max_out) {
+    if (!h || !x_dev) return fail(Y355_EINVAL, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
+    if (!(momentum >= 0.0 && momentum <= 1.0)) return fail(Y355_EINVAL, "momentum outside [0, 1]");
+    float m = 0.f;
+    if (int rc = y355_input_absmax(h, x_dev, batch, &m)) return rc;
+    int e = 0;
+    if (int rc = tracker_update(&h->trk_scale[0], &h->trk_first[0], 0, m, freeze, momentum, &e)) return rc;
+    if (max_out) max_out[0] = m;
+    if (sa_out) sa_out[0] = e;
+    set_one_exponent(h, 0, e);
+    for (int k = 0; k < 10; ++k) {
+        const float *xp = k == 0 ? x_dev : nullptr;
+        if (int rc = y355_run_layer(h, k, batch, 1, xp)) return rc;
+        y355_layer_stats st;
+        if (int rc = y355_layer_stats_get(h, k, &st)) return rc;
+        // max|y| as the fp32 value the reference's activation.abs().max() returns: t' / 2^F' is exact in fp32 wherever the
+        // reference's own fp32 convolution is
+        const float ymax = (float)st.absmax_t * std::ldexp(1.0f, -st.frac_bits);
+        if (int rc = tracker_update(&h->trk_scale[k + 1], &h->trk_first[k + 1], k + 1, ymax, freeze, momentum, &e)) return rc;
+        if (max_out) max_out[k + 1] = ymax;
+        if (sa_out) sa_out[k + 1] = e;
+        set_one_exponent(h, k + 1, e);
+        if (int rc = y355_run_layer(h, k, batch, 0, xp)) return rc;
+    }
+    return 0;
+}
+
 extern "C" int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst) {
     if (!h || !dst || idx < 0 || idx >= 10) return fail(Y355_EINVAL, "bad argument");
     if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
@@ -611,9 +701,6 @@ extern "C" int y355_get_feature(y355_engine *h, int idx, int batch, int8_t *dst)
                                     "run with y355_set_option(h, Y355_OPT_FUSE_FRONT, 0) to tap it");
     if (idx == 2 && batch > h->l2_batch)
         return fail(Y355_ENOTREADY, "conv3_1's map of the last forward was not written (fused conv3_1 -> conv3_2 + pool): "
-                                    "run with y355_set_option(h, Y355_OPT_FUSE_PAIRS, 0) to tap it");
-    if (idx == 4 && batch > h->l4_batch)
-        return fail(Y355_ENOTREADY, "conv4_1's map of the last forward was not written (fused conv4_1 -> conv4_2 + pool): "
                                     "run with y355_set_option(h, Y355_OPT_FUSE_PAIRS, 0) to tap it");
     const Layer &L = h->L[idx];
     const int Hp = L.Hout + 2 * L.halo, Wp = L.Wout + 2 * L.halo, CS = L.cout_pad;
@@ -678,6 +765,8 @@ static int launch_front(y355_engine *h, int B, const float *x_dev) {
     p.bias1 = L0.bias_dev;
     p.bias2 = L1.bias_dev;
     p.ctr = h->ctr_dev;
+    p.zero_next = (unsigned long long *)h->ctrs.other_zeroed_by_front();
+    p.zero_n = 10 * (int)(sizeof(Counters) / 8);
     p.B = B;
     p.H = L0.Hin;
     p.W = L0.Win;
@@ -707,7 +796,7 @@ int y355_zero_counters(Counters *c, int n, hipStream_t s) {
 // conv3_1 -> conv3_2 + pool3 as one launch (pxpair.hip): 1 = launched, 0 = not eligible (the caller runs the two layers), < 0 error
 static int launch_pair3(y355_engine *h, int B) {
     Layer &A = h->L[2], &Bl = h->L[3];
-    if (!A.wpair_dev || !A.wpx_dev || !Bl.wpx_dev || A.cin != 32 || A.cout_pad != 64 || Bl.cout_pad != 64 || !Bl.pool || A.pool) return 0;
+    if (!A.wpx_dev || !Bl.wpx_dev || A.cin != 32 || A.cout_pad != 64 || Bl.cout_pad != 64 || !Bl.pool || A.pool) return 0;
 #ifdef Y355_EXPERIMENTS
     static const bool no_pair = getenv("Y355_NO_PAIR3") != nullptr;
     if (no_pair) return 0;
@@ -715,8 +804,7 @@ static int launch_pair3(y355_engine *h, int B) {
     PairParams p{};
     p.in = h->L[1].out_dev;
     p.out = Bl.out_dev;
-    p.variant = h->pair_variant;
-    p.w1 = p.variant == 1 ? A.wpx_dev : A.wpair_dev;
+    p.w1 = A.wpx_dev;
     p.w2 = Bl.wpx_dev;
     p.bias1 = A.bias_dev;
     p.bias2 = Bl.bias_dev;
@@ -738,49 +826,17 @@ static int launch_pair3(y355_engine *h, int B) {
     return 1;
 }
 
-// conv4_1 -> conv4_2 + pool4 as one launch (pxpair.hip): 1 = launched, 0 = not eligible, < 0 error
-static int launch_pair4(y355_engine *h, int B) {
-    Layer &A = h->L[4], &Bl = h->L[5];
-    if (!A.wpair_dev || !Bl.wpx_dev || A.cin != 64 || A.cout_pad != 128 || Bl.cout_pad != 128 || !Bl.pool || A.pool) return 0;
-#ifdef Y355_EXPERIMENTS
-    static const bool no_pair = getenv("Y355_NO_PAIR4") != nullptr;
-    if (no_pair) return 0;
-#endif
-    PairParams p{};
-    p.variant = 1;
-    p.in = h->L[3].out_dev;
-    p.out = Bl.out_dev;
-    p.w1 = A.wpair_dev;
-    p.w2 = Bl.wpx_dev;
-    p.bias1 = A.bias_dev;
-    p.bias2 = Bl.bias_dev;
-    p.ctr1 = h->ctr_dev + 4;
-    p.ctr2 = h->ctr_dev + 5;
-    p.rq1 = A.rq;
-    p.rq2 = Bl.rq;
-    p.B = B;
-    p.H = A.Hin;
-    p.W = A.Win;
-    p.grid_limit = h->ring_wgs;
-    p.stamps = (h->stamp_layer == 4) ? h->stamps_dev : nullptr;
-    h->kev_set[4] = h->kev_set[5] = false;
-    if (h->profile == 2) { p.ev_start = h->kev[4][0]; p.ev_stop = h->kev[4][1]; }
-    if (!y355_launch_pair4(p, h->stream)) return 0;
-    HIPCHK(hipGetLastError());
-    h->kev_set[4] = p.ev_start != nullptr;
-    h->l4_batch = 0;
-    return 1;
-}
-
 // enqueue one forward on `s` (refresh_layer must have run)
 static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int flags, float *boxes_dev, float *scores_dev,
                            int32_t *cls_dev, int32_t *count_dev, bool prof) {
-    HIPCHK((hipError_t)y355_zero_counters(h->ctr_dev, 10, h->stream));
+    bool need_zero = false;
+    h->ctr_dev = h->ctrs.begin(&need_zero);          // steady state: zeroed by the previous forward's front end, no launch here
+    if (need_zero) HIPCHK((hipError_t)y355_zero_counters(h->ctr_dev, 10, h->stream));
     const int guard = (flags & Y355_F_GUARD) ? 1 : 0;
     // the fused front end covers the 32-bit epilogue without the head-room guard; conv2's packed weights must be the
     // resident-weight layout (one n-block of 32 channels), which they are for this network
     const bool fused = h->fuse_front && !guard && y355_front_eligible(h->L[0].rq, h->L[1].rq) && h->L[1].cout_pad == 32;
-    bool pair3 = false, pair4 = false;
+    bool pair3 = false;
     for (int k = 0; k < 10; ++k) {
         if (prof) HIPCHK(hipEventRecord(h->ev[k], h->stream));
         if (fused && k == 0) {
@@ -796,13 +852,6 @@ static int enqueue_forward(y355_engine *h, const float *x_dev, int batch, int fl
             if (pair3) continue;
         }
         if (pair3 && k == 3) continue;
-        if (k == 4 && h->fuse_pairs == 2 && !guard) {     // (measured no faster than the two launches: off unless asked for)          // conv4_1 -> conv4_2 + pool4 in one launch; slot 5 then reads ~0
-            const int rc = launch_pair4(h, batch);
-            if (rc < 0) return rc;
-            pair4 = rc == 1;
-            if (pair4) continue;
-        }
-        if (pair4 && k == 5) continue;
         if (int rc = launch_layer(h, k, batch, 0, guard, x_dev)) return rc;
     }
     if (prof) HIPCHK(hipEventRecord(h->ev[10], h->stream));
@@ -821,55 +870,12 @@ extern "C" int y355_forward(y355_engine *h, const float *x_dev, int batch, int f
     if (!h || !x_dev || !boxes_dev || !scores_dev || !cls_dev || !count_dev) return fail(Y355_EINVAL, "null argument");
     if (batch < 1 || batch > h->cfg.max_batch) return fail(Y355_EINVAL, "batch out of range");
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    bool changed = false;
-    for (int k = 0; k < 10; ++k) {
-        changed = changed || h->L[k].bias_dirty;
+    for (int k = 0; k < 10; ++k)
         if (int rc = refresh_layer(h, k, true)) return rc;
-    }
     const bool prof = h->profile != 0;
-#ifdef Y355_EXPERIMENTS
-    static const bool use_graph = getenv("Y355_GRAPH") != nullptr;     // hipGraph replay of the launches: measured, no gain
-#else
-    constexpr bool use_graph = false;
-#endif
-    if (!use_graph || prof) return enqueue_forward(h, x_dev, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, prof);
-    // ---- the 14 launches of a step replayed as one hipGraph (same pointers, batch, thresholds)
-    if (changed) {
-        for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-        h->graphs.clear();
-    }
-    GraphKey key{x_dev, boxes_dev, scores_dev, cls_dev, count_dev, batch, flags, h->cfg.conf_thresh, h->cfg.nms_thresh};
-    for (auto &g : h->graphs)
-        if (!memcmp(&g.key, &key, sizeof key)) {
-            HIPCHK(hipGraphLaunch(g.exec, h->stream));
-            return 0;
-        }
-    if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-    hipStream_t user = h->stream;
-    h->stream = h->cap_stream;
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
-    int rc = 0;
-    if (e == hipSuccess) {
-        rc = enqueue_forward(h, x_dev, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, false);
-        e = hipStreamEndCapture(h->cap_stream, &graph);
-    }
-    h->stream = user;
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(Y355_EHIP, std::string("graph capture: ") + hipGetErrorString(e));
-    GraphEntry ge{};
-    memset(&ge.key, 0, sizeof ge.key);
-    ge.key = key;
-    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) return fail(Y355_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-    if (h->graphs.size() >= 8) {
-        (void)hipGraphExecDestroy(h->graphs.front().exec);
-        h->graphs.erase(h->graphs.begin());
-    }
-    h->graphs.push_back(ge);
-    HIPCHK(hipGraphLaunch(ge.exec, h->stream));
-    return 0;
+    // (rounds 2-5 carried a hipGraph replay of the step's launches behind -DY355_EXPERIMENTS: measured, no gain; removed with the
+    // alternating counter sets, which a captured graph would freeze)
+    return enqueue_forward(h, x_dev, batch, flags, boxes_dev, scores_dev, cls_dev, count_dev, prof);
 }
 
 // BaseTransform constants of the uint8 path, in the reference's BGR order (data/__init__.py:50)
@@ -1117,6 +1123,8 @@ extern "C" int y355_debug_nms_stamps(unsigned long long *out_host) {
     HIPCHK(hipMemcpy(out_host, y355_nms_stamps_dev, 8 * 8 * 256 * 4, hipMemcpyDeviceToHost));
     return 0;
 }
+
+extern "C" void *y355_stream(y355_engine *h) { return h ? (void *)h->stream : nullptr; }
 
 extern "C" int y355_sync(y355_engine *h) {
     if (!h) return fail(Y355_EINVAL, "null engine");

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     int qr0 = 4 * wave + g;                            // row of item k: qr0 + 16 k
     int qj = li;
     const int G_ = gridDim.x;
+    if (p.zero_next != nullptr && blockIdx.x == 0)          // the next forward's counters (CounterSets, y355_common.h): idle until this launch is done
+        for (int i = tid; i < p.zero_n; i += 256) p.zero_next[i] = 0ull;
     int tile = y355_xcd_remap(blockIdx.x, G_);
     if (tile >= total_tiles) return;
     int nstamp = 0;

@@ -436,7 +436,8 @@ struct y355_net {
     int sa_in = 0;
     bool sa_ok = false;
     std::vector<int> sa;
-    Counters *ctr_dev = nullptr;      // [nops + 1]
+    Counters *ctr_dev = nullptr;      // [nops + 1]: the set the last forward counted into (one of ctrs' two)
+    CounterSets ctrs;
     // int8 nets whose graph starts with conv(3 -> 16) + pool, conv(16 -> 32) + pool (SlimYOLOv2, YOLOv3tiny:
     // models/slim_yolo_v2.py:549-575, backbone/darknet.py:216-220): both layers in ONE launch of the q_bf engine's fused front
     // end (front.hip) when their epilogues are exact in fp32 (y355_front_eligible); tap forwards run the layers one by one
@@ -595,7 +596,10 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     }
     const size_t cap = Y355_NMS_CAP;
     if (!rc) rc = nmalloc(h, (void **)&h->absmax_dev, 16, true);
-    if (!rc) rc = nmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * (A.nops + 1), true);
+    if (!rc) rc = nmalloc(h, (void **)&h->ctr_dev, sizeof(Counters) * 2 * (A.nops + 1), true);
+    h->ctrs.base = h->ctr_dev;
+    h->ctrs.n = A.nops + 1;
+    h->ctrs.clean[0] = h->ctrs.clean[1] = true;
     if (!rc) rc = nmalloc(h, &h->ws.cbox, sizeof(float) * 4 * cap * B, false);
     if (!rc) rc = nmalloc(h, &h->ws.cscore, sizeof(float) * cap * B, false);
     if (!rc) rc = nmalloc(h, &h->ws.ccls, sizeof(int) * cap * B, false);
@@ -1192,7 +1196,9 @@ extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int 
     const int nops = h->arch->nops;
     if (!h->bf) {
         if (int rc = refresh_i8(h)) return rc;
-        HIPCHK((hipError_t)y355_zero_counters(h->ctr_dev, nops + 1, h->stream));
+        bool need_zero = false;
+        h->ctr_dev = h->ctrs.begin(&need_zero);        // steady state: zeroed by the previous forward's fused front end
+        if (need_zero) HIPCHK((hipError_t)y355_zero_counters(h->ctr_dev, nops + 1, h->stream));
     }
     // tap forwards (parity tests read every tensor) run the first two layers one by one: the fused launch does not write conv1's map
     const bool fuse_front = h->front_graph && (h->bf || h->front_ok) && !(flags & Y355_F_TAP);
@@ -1229,6 +1235,8 @@ extern "C" int y355_net_forward(y355_net *h, const float *x_dev, int batch, int 
                 fp.bias1 = h->fb1_dev;
                 fp.bias2 = h->fb2_dev;
                 fp.ctr = h->ctr_dev;                                // [0] conv1 (+ input), [1] conv2: the two ops' own counters
+                fp.zero_next = (unsigned long long *)h->ctrs.other_zeroed_by_front();
+                fp.zero_n = (nops + 1) * (int)(sizeof(Counters) / 8);
                 fp.B = batch;
                 fp.H = h->cfg.height;
                 fp.W = h->cfg.width;

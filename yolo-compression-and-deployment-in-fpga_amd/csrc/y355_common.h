@@ -84,7 +84,32 @@ struct Counters {
     unsigned long long guard; // head-room violations
 };
 
+int y355_cu_count(void);       // engine.hip: compute units of the current device (cached per device), 256 on an MI355X in SPX mode
 int y355_zero_counters(Counters *c, int n, hipStream_t s);    // engine.hip: a kernel launch, not hipMemsetAsync; returns the launch status (hipError_t)
+
+// Two sets of per-forward counters used alternately: the fused front end of forward i (the first launch of a step) zeroes the
+// set forward i + 1 will count into, so the steady state has NO counter-reset launch (round 5: a one-wave kernel per step,
+// 4.5 us of a 298 us one-stream step).  Every launch of a stream runs behind the previous one, so the set being zeroed is idle:
+// forward i - 1 (its last user) is complete, forward i counts into the other one, and a host read of "the last forward's
+// counters" happens before the next forward is enqueued.  A forward without the fused front end zeroes its own set by a launch.
+struct CounterSets {
+    Counters *base = nullptr;     // [2][n]
+    int n = 0, cur = 0;
+    bool clean[2] = {false, false};
+    Counters *set(int i) const { return base + (size_t)i * n; }
+    // start a forward: the set it counts into; *need_zero: not zeroed by the previous forward's front end
+    Counters *begin(bool *need_zero) {
+        cur ^= 1;
+        *need_zero = !clean[cur];
+        clean[cur] = false;
+        return set(cur);
+    }
+    // this forward's front end zeroes the other set (call when that launch is enqueued)
+    Counters *other_zeroed_by_front() {
+        clean[cur ^ 1] = true;
+        return set(cur ^ 1);
+    }
+};
 
 struct ConvParams {
     const int8_t *in;     // int8 NHWC with halo  [B][H+2][W+2][CIN]
@@ -137,6 +162,8 @@ struct FrontParams {
     const int *bias1;     // [16]
     const int *bias2;     // [32]
     Counters *ctr;        // [0] conv1, [1] conv2
+    unsigned long long *zero_next;   // or null: zero_n 64-bit words the first workgroup clears (the NEXT forward's counters, CounterSets)
+    int zero_n;
     int B, H, W;
     int tiles_x, tiles_y;
     float in_scale;       // 2^sa[0]
@@ -253,7 +280,7 @@ bool y355_pack_px(int kid, const int8_t *q_w, int cout, int cin, int8_t *dst);
 struct PairParams {
     const int8_t *in;     // conv3_1's input: int8 NHWC32 with halo [B][H+2][W+2][32]
     int8_t *out;          // conv3_2's pooled output: int8 NHWC64 with halo [B][H/2+2][W/2+2][64]
-    const int8_t *w1;     // conv3_1's weights: variant 0 y355_pack_pair3 layout, variant 1 y355_pack_px(Y355_K_CONV3_1) layout
+    const int8_t *w1;     // conv3_1's weights, y355_pack_px(Y355_K_CONV3_1) layout
     const int8_t *w2;     // conv3_2's weights, y355_pack_px(Y355_K_CONV3_2) layout
     const int *bias1;     // [64]
     const int *bias2;     // [64]
@@ -263,19 +290,10 @@ struct PairParams {
     void *ev_start, *ev_stop;     // host side only: see ConvParams
     int grid_limit;       // host side only: persistent workgroups per launch (0 = one per CU)
     unsigned long long *stamps;   // diagnostic builds only (-DPAIR_DIAG=1)
-    int variant;          // 0: every wave runs both layers, phase by phase; 1: conv3_1 and conv3_2 on different waves of every SIMD
 };
 bool y355_pair3_eligible(const Requant &rq1, const Requant &rq2, int H, int W);
 bool y355_launch_pair3(const PairParams &p, hipStream_t s);      // false: not eligible, run the two layers' own launches
 int y355_prepare_pair3(void);
-size_t y355_pair3_packed_bytes(void);
-void y355_pack_pair3(const int8_t *q_w /*[64][32][3][3]*/, int8_t *dst);
-// conv4_1 -> conv4_2 + pool4 (PairParams: in = [B][H+2][W+2][64], out = [B][H/2+2][W/2+2][128], w1 = y355_pack_pair4, w2 = y355_pack_px(Y355_K_CONV4_2))
-bool y355_pair4_eligible(const Requant &rq1, const Requant &rq2, int H, int W);
-bool y355_launch_pair4(const PairParams &p, hipStream_t s);
-int y355_prepare_pair4(void);
-size_t y355_pair4_packed_bytes(void);
-void y355_pack_pair4(const int8_t *q_w /*[128][64][3][3]*/, int8_t *dst);
 // deep-prefetch ring kernels (conv3x3_ring.hip), layers with >= 64 input channels
 bool y355_launch_conv_ring(int kid, const ConvParams &p, hipStream_t s);
 int y355_prepare_conv_ring(void);

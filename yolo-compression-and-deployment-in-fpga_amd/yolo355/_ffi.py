@@ -15,6 +15,7 @@ MAX_ANCHORS = 16
 NUM_TIMERS = 12
 NUM_KERNEL_TIMERS = 14
 F_GUARD, F_TAP = 1, 2
+PIPE_AFTER_STREAM = 0x100
 OP_LEAKY, OP_POOL, OP_RELU = 1, 2, 4
 OPT_FUSE_FRONT = 1
 OPT_RING_WORKGROUPS = 2
@@ -116,6 +117,39 @@ _SIGS = {
     "y355_pack_dets_capped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y355_allgather_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y355_unpack_dets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_set_trackers": (C.c_int, [C.c_void_p, P(C.c_float), P(C.c_int32)]),
+    "y355_get_trackers": (C.c_int, [C.c_void_p, P(C.c_float), P(C.c_int32)]),
+    "y355_calibrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, P(C.c_int32), P(C.c_float)]),
+    "y355_tracker_step": (C.c_int, [P(C.c_float), P(C.c_int32), C.c_float, C.c_int, C.c_double, P(C.c_int32)]),
+    "y355_pipeline_create": (C.c_int, [P(Config), C.c_int, C.c_int, P(C.c_void_p)]),
+    "y355_pipeline_create_on": (C.c_int, [P(Config), C.c_int, C.c_int, P(C.c_void_p), P(C.c_void_p)]),
+    "y355_pipeline_destroy": (None, [C.c_void_p]),
+    "y355_pipeline_handles": (C.c_int, [C.c_void_p]),
+    "y355_pipeline_depth": (C.c_int, [C.c_void_p]),
+    "y355_pipeline_max_det": (C.c_int, [C.c_void_p]),
+    "y355_pipeline_engine": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "y355_pipeline_stream": (C.c_void_p, [C.c_void_p, C.c_longlong]),
+    "y355_pipeline_load_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y355_pipeline_set_act_exponents": (C.c_int, [C.c_void_p, P(C.c_int32)]),
+    "y355_pipeline_set_retune": (C.c_int, [C.c_void_p, P(C.c_int32)]),
+    "y355_pipeline_set_thresholds": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "y355_pipeline_set_normalization": (C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
+    "y355_pipeline_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "y355_pipeline_set_trackers": (C.c_int, [C.c_void_p, P(C.c_float), P(C.c_int32)]),
+    "y355_pipeline_get_trackers": (C.c_int, [C.c_void_p, P(C.c_float), P(C.c_int32)]),
+    "y355_pipeline_calibrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, P(C.c_int32), P(C.c_float)]),
+    "y355_pipeline_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, P(C.c_longlong)]),
+    "y355_pipeline_submit_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, P(C.c_longlong)]),
+    "y355_pipeline_wait": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "y355_pipeline_outputs": (C.c_int, [C.c_void_p, C.c_longlong, P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(C.c_int)]),
+    "y355_pipeline_release": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
+    "y355_pipeline_fetch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y355_pipeline_scale_boxes": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
+    "y355_pipeline_counters": (C.c_int, [C.c_void_p, P(C.c_int64), P(C.c_int64)]),
+    "y355_pipeline_sync": (C.c_int, [C.c_void_p]),
+    "y355_stream": (C.c_void_p, [C.c_void_p]),
     "y355_sync": (C.c_int, [C.c_void_p]),
     "y355_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "y355_profile_get": (C.c_int, [C.c_void_p, P(C.c_float)]),

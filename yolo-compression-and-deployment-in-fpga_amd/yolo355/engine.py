@@ -4,7 +4,9 @@ The engine is the batched, integer implementation of
 SlimYOLOv2_quantize_bnfuse.forward(x, quantization=True) (models/slim_yolo_v2.py:212-358).
 PyTorch is used only for device memory and the stream; all compute is in libyolo355.so.
 """
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -14,6 +16,22 @@ from .prep import RETUNE, RangeTracker
 
 NUM_LAYERS = 10
 LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5", "conv6", "conv7", "pred"]
+
+
+# Handles that own HIP streams / events must be destroyed while the HIP runtime is still alive: at interpreter shutdown the
+# order of module teardown is arbitrary, and a __del__ that reaches hipStreamDestroy after the runtime's own atexit handlers
+# have run crashes the process.  Every live Engine / Pipeline is closed from one atexit hook registered at import (i.e. after
+# torch's and before its teardown, atexit being LIFO).
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    for o in list(_live):
+        try:
+            o.close()
+        except Exception:
+            pass
 
 
 def _require_gpu(device):
@@ -54,14 +72,31 @@ class Engine:
             _ffi.check(lib.y355_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self._lib = lib
+        self._owned = True
+        _live.add(self)
         self.max_det = lib.y355_max_det(h)
         self.num_anchors_total = lib.y355_num_anchors_total(h)
         self.conf_thresh, self.nms_thresh = float(conf_thresh), float(nms_thresh)
         self._out = None
 
+    @classmethod
+    def _borrowed(cls, handle, like, stream):
+        """Engine view of a handle somebody else owns (a pipeline's handle i): the taps / statistics / profiling calls of the
+        engine ABI on it.  `like` supplies the configuration; the view launches on the handle's own stream."""
+        e = cls.__new__(cls)
+        e._h, e._lib, e._owned = handle, like._lib, False
+        e.device, e.input_size, e.num_classes, e.anchors = like.device, like.input_size, like.num_classes, like.anchors
+        e.max_batch, e.max_det = like.max_batch, like.max_det
+        e.num_anchors_total = e._lib.y355_num_anchors_total(handle)
+        e.conf_thresh, e.nms_thresh = like.conf_thresh, like.nms_thresh
+        e._stream = stream
+        e._out = None
+        return e
+
     def close(self):
         if self._h is not None:
-            self._lib.y355_destroy(self._h)
+            if self._owned:
+                self._lib.y355_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -132,30 +167,15 @@ class Engine:
 
     # ------------------------------------------------------------------ calibration
     def calibrate(self, x, trackers, freeze=True):
-        """Run the tracker semantics of models/slim_yolo_v2.py:16-38 layer by layer on the GPU.
-        trackers: 11 prep.RangeTracker (input, conv1..conv7, pred), updated in place
-        (first call: scale = 127/max; frozen: unchanged; else EMA).  Leaves the engine's
-        feature maps and exponents as the reference's forward would.  Returns the exponents."""
+        """One calibration step: the tracker semantics of models/slim_yolo_v2.py:16-38 layer by layer on the GPU, in ONE call
+        of the C ABI (y355_calibrate: the state machine and its float32 arithmetic live in the library).
+        trackers: 11 prep.RangeTracker (input, conv1..conv7, pred) -- the checkpoint buffers scale / first_a; they are handed
+        to the handle, updated there (first call: scale = 127/max; frozen: unchanged; else EMA) and read back in place.
+        Leaves the engine's feature maps and exponents as the reference's forward would.  Returns the exponents."""
         xd = self._dev_input(x)
-        B = xd.shape[0]
-        lib, h = self._lib, self._h
-        m = C.c_float()
-        self._enter()                                     # the calls below synchronise the engine's stream themselves
-        _ffi.check(lib.y355_input_absmax(h, xd.data_ptr(), B, C.byref(m)))
-        sa = [trackers[0].update(m.value, freeze)]
-        self.calib_max = [float(m.value)]                 # max|.| seen by each tracker in this calibration
-        _ffi.check(lib.y355_set_act_exponent(h, 0, sa[0]))
-        st = _ffi.LayerStats()
-        for k in range(NUM_LAYERS):
-            xp = xd.data_ptr() if k == 0 else None
-            _ffi.check(lib.y355_run_layer(h, k, B, 1, xp))
-            _ffi.check(lib.y355_layer_stats_get(h, k, C.byref(st)))
-            # max|y| as the fp32 value the reference's activation.abs().max() returns
-            ymax = np.float32(st.absmax_t) * np.float32(2.0 ** (-st.frac_bits))
-            sa.append(trackers[k + 1].update(ymax, freeze))
-            self.calib_max.append(float(ymax))
-            _ffi.check(lib.y355_set_act_exponent(h, k + 1, sa[-1]))
-            _ffi.check(lib.y355_run_layer(h, k, B, 0, xp))
+        sa, mx = _calibrate_call(self._lib.y355_set_trackers, self._lib.y355_get_trackers, self._lib.y355_calibrate, self._h,
+                                 xd, trackers, freeze, self._enter)
+        self.calib_max = mx                               # max|.| seen by each tracker in this calibration
         return sa
 
     def layer_stats(self, idx):
@@ -347,6 +367,255 @@ class Engine:
         arr = (C.c_float * _ffi.NUM_KERNEL_TIMERS)()
         _ffi.check(self._lib.y355_profile_kernels_get(self._h, arr))
         return list(arr)
+
+
+def _calibrate_call(set_fn, get_fn, cal_fn, handle, xd, trackers, freeze, enter):
+    """push the 11 tracker states into the handle, run the C calibration step, read the states back into `trackers`"""
+    if len(trackers) != 11:
+        raise ValueError("expected 11 trackers (input, conv1..conv7, pred)")
+    moms = {float(t.momentum) for t in trackers}
+    if len(moms) != 1:
+        raise ValueError("the 11 trackers must share one momentum")
+    scale = (C.c_float * 11)(*[float(t.scale.reshape(-1)[0].item()) for t in trackers])
+    first = (C.c_int32 * 11)(*[int(t.first_a) for t in trackers])
+    _ffi.check(set_fn(handle, scale, first))
+    sa = (C.c_int32 * 11)()
+    mx = (C.c_float * 11)()
+    enter()                                               # the call synchronises the engine's stream itself
+    _ffi.check(cal_fn(handle, xd.data_ptr(), int(xd.shape[0]), 1 if freeze else 0, moms.pop(), sa, mx))
+    _ffi.check(get_fn(handle, scale, first))
+    for i, t in enumerate(trackers):
+        t.scale = torch.tensor([scale[i]], dtype=torch.float32)
+        t.first_a = int(first[i])
+    return list(sa), [float(v) for v in mx]
+
+
+class Pipeline:
+    """The throughput regime behind the API (y355_pipeline, include/yolo355.h): `handles` engines on as many HIP streams, the
+    submitted batches dealt to them round-robin, so that the head / NMS of one batch runs beside the convolutions of the next.
+
+        pipe = Pipeline([416, 416], 2, ANCHOR_SIZE_MASK, max_batch=64)
+        pipe.load_quantized(qlayers); pipe.calibrate(x0, trackers)
+        t = pipe.submit(x_cuda)               # asynchronous; up to pipe.depth tickets in flight
+        boxes, scores, cls, count = pipe.outputs(t)     # device tensors, valid after pipe.wait(t)
+        dets = pipe.fetch(t)                  # or: the reference's per-image (bboxes, scores, cls_inds) lists on the host
+
+    Results equal a stand-alone Engine's bit for bit (tests/test_pipeline.py).  forward(x) takes any batch size: chunks of
+    max_batch in flight, results in order -- what models.SlimYOLOv2_quantize_bnfuse.forward_batch and the batched evaluators run."""
+
+    def __init__(self, input_size, num_classes, anchors, conf_thresh=0.01, nms_thresh=0.5, max_batch=64, max_det=0,
+                 device=None, handles=0, ring_workgroups=-1):
+        self._h = None
+        lib = _ffi.lib()
+        self.device = _require_gpu(device)
+        self.input_size = [int(input_size[0]), int(input_size[1])]
+        self.num_classes = int(num_classes)
+        self.anchors = [[float(a), float(b)] for a, b in anchors]
+        self.max_batch = int(max_batch)
+        cfg = _ffi.Config()
+        cfg.device_id = self.device.index
+        cfg.height, cfg.width = self.input_size
+        cfg.num_classes = self.num_classes
+        cfg.num_anchors = len(self.anchors)
+        for i, (w, h) in enumerate(self.anchors):
+            cfg.anchors[2 * i], cfg.anchors[2 * i + 1] = w, h
+        cfg.conf_thresh, cfg.nms_thresh = float(conf_thresh), float(nms_thresh)
+        cfg.max_batch, cfg.max_det = self.max_batch, int(max_det)
+        h = C.c_void_p()
+        nh = 3 if int(handles) == 0 else int(handles)     # the C ABI's default; the streams below must match in number
+        # the handles run on torch streams: PyTorch's allocator tracks memory per stream, so torch must own (and outlive)
+        # every stream its tensors are used on -- y355_pipeline_create_on
+        self._tstreams = [torch.cuda.Stream(device=self.device) for _ in range(max(nh, 1))]
+        sp = (C.c_void_p * len(self._tstreams))(*[st.cuda_stream for st in self._tstreams])
+        with torch.cuda.device(self.device):
+            _ffi.check(lib.y355_pipeline_create_on(C.byref(cfg), nh, int(ring_workgroups), sp, C.byref(h)))
+        self._h, self._lib = h, lib
+        _live.add(self)
+        self.handles = lib.y355_pipeline_handles(h)
+        self.depth = lib.y355_pipeline_depth(h)
+        self.max_det = lib.y355_pipeline_max_det(h)
+        self.conf_thresh, self.nms_thresh = float(conf_thresh), float(nms_thresh)
+        self._bufs = [None] * self.depth                  # torch-owned output buffers, one set per ticket slot
+        self._next = 0
+
+    def close(self):
+        if self._h is not None:
+            self._lib.y355_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ configuration (every handle)
+    def load_layer(self, idx, q_w, q_b, e_w, e_b):
+        qw = np.ascontiguousarray(q_w, dtype=np.int8)
+        qb = np.ascontiguousarray(q_b, dtype=np.int32)
+        if np.abs(np.asarray(q_w)).max() > 127:
+            raise ValueError("|q_w| > 127")
+        _ffi.check(self._lib.y355_pipeline_load_layer(self._h, idx, qw.ctypes.data, qb.ctypes.data, qw.shape[0], qw.shape[1],
+                                                      int(e_w), int(e_b)))
+
+    def load_quantized(self, qlayers):
+        for i, L in enumerate(qlayers):
+            self.load_layer(i, L["q_w"], L["q_b"], L["e_w"], L["e_b"])
+
+    def set_act_exponents(self, sa):
+        _ffi.check(self._lib.y355_pipeline_set_act_exponents(self._h, (C.c_int32 * 11)(*[int(v) for v in sa])))
+
+    def set_retune(self, retune=RETUNE):
+        _ffi.check(self._lib.y355_pipeline_set_retune(self._h, (C.c_int32 * 10)(*[int(v) for v in retune])))
+
+    def set_thresholds(self, conf_thresh, nms_thresh):
+        self.conf_thresh, self.nms_thresh = float(conf_thresh), float(nms_thresh)
+        _ffi.check(self._lib.y355_pipeline_set_thresholds(self._h, self.conf_thresh, self.nms_thresh))
+
+    def set_option(self, option, value):
+        _ffi.check(self._lib.y355_pipeline_set_option(self._h, int(option), int(value)))
+
+    def set_normalization(self, mean_bgr, std_bgr):
+        _ffi.check(self._lib.y355_pipeline_set_normalization(self._h, (C.c_float * 3)(*[float(v) for v in mean_bgr]),
+                                                             (C.c_float * 3)(*[float(v) for v in std_bgr])))
+
+    def calibrate(self, x, trackers, freeze=True):
+        """Engine.calibrate on handle 0 (y355_pipeline_calibrate); every handle gets the resulting trackers and exponents."""
+        xd = self._dev_input(x)
+        sa, mx = _calibrate_call(self._lib.y355_pipeline_set_trackers, self._lib.y355_pipeline_get_trackers,
+                                 self._lib.y355_pipeline_calibrate, self._h, xd, trackers, freeze,
+                                 lambda: torch.cuda.current_stream(self.device).synchronize())
+        self.calib_max = mx
+        return sa
+
+    # ------------------------------------------------------------------ the hot path
+    def _dev_input(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        if x.dim() != 4 or x.shape[1] != 3 or list(x.shape[2:]) != self.input_size:
+            raise ValueError("expected [B,3,%d,%d], got %s" % (self.input_size[0], self.input_size[1], tuple(x.shape)))
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _slot_bufs(self, slot):
+        if self._bufs[slot] is None:
+            md, B = self.max_det, self.max_batch
+            self._bufs[slot] = (torch.empty((B, md, 4), dtype=torch.float32, device=self.device),
+                                torch.empty((B, md), dtype=torch.float32, device=self.device),
+                                torch.empty((B, md), dtype=torch.int32, device=self.device),
+                                torch.zeros((B,), dtype=torch.int32, device=self.device))
+        return self._bufs[slot]
+
+    def submit(self, xd, flags=0, out=None, frames=False, ordered=True):
+        """Enqueue one forward; returns the ticket.  xd: CUDA float32 [B,3,H,W] contiguous (frames=True: uint8 [B,H,W,3] BGR at
+        the network size).  out: (boxes, scores, cls int32, count int32) device tensors (default: the pipeline's buffer set of
+        the ticket's slot, reused `depth` submits later).  ordered=True: the forward starts behind whatever torch's current
+        stream has queued (the input's producer); False: the caller guarantees the input is complete."""
+        B = int(xd.shape[0])
+        if B > self.max_batch:
+            raise ValueError("batch %d > max_batch %d" % (B, self.max_batch))
+        slot = self._next % self.depth
+        ob, os_, oc, on = out if out is not None else self._slot_bufs(slot)
+        t = C.c_longlong()
+        cur = torch.cuda.current_stream(self.device).cuda_stream if ordered else 0
+        fn = self._lib.y355_pipeline_submit_u8 if frames else self._lib.y355_pipeline_submit
+        _ffi.check(fn(self._h, xd.data_ptr(), B, int(flags) | (_ffi.PIPE_AFTER_STREAM if ordered else 0), cur,
+                      ob.data_ptr(), os_.data_ptr(), oc.data_ptr(), on.data_ptr(), C.byref(t)))
+        self._next = t.value + 1
+        self._live = getattr(self, "_live", {})
+        self._live[t.value % self.depth] = (t.value, B, (ob, os_, oc, on), xd)      # keeps the input alive until its slot is reused
+        return t.value
+
+    def outputs(self, ticket):
+        """(boxes [max_batch,max_det,4], scores, cls, count) device tensors of the ticket; rows >= B / entries >= count[b] undefined.
+        Read them after wait(ticket)."""
+        rec = getattr(self, "_live", {}).get(ticket % self.depth)
+        if rec is None or rec[0] != ticket:
+            raise _ffi.Y355Error(_ffi.ENOTREADY, "ticket %d is gone (a ticket lives for %d more submits)" % (ticket, self.depth))
+        return rec[2]
+
+    def wait(self, ticket, host=False):
+        """host=False: torch's current stream waits for the ticket (no host block); True: the host blocks until it is done."""
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        _ffi.check(self._lib.y355_pipeline_wait(self._h, int(ticket), 0 if host else 1, cur))
+
+    def release(self, ticket):
+        """the work queued on torch's current stream so far is the last reader of the ticket's outputs"""
+        _ffi.check(self._lib.y355_pipeline_release(self._h, int(ticket), torch.cuda.current_stream(self.device).cuda_stream))
+
+    def stream(self, ticket):
+        """torch view of the HIP stream of the handle that runs `ticket` (for work that must follow it without an event)"""
+        return self._tstreams[int(ticket) % self.handles]
+
+    def engine(self, i):
+        """Engine view of handle i (not owning): taps, statistics, profiling, options.  Do not run forwards on it while tickets
+        are in flight."""
+        if not 0 <= i < self.handles:
+            raise IndexError(i)
+        return Engine._borrowed(C.c_void_p(self._lib.y355_pipeline_engine(self._h, i)), self, self._tstreams[i])
+
+    @property
+    def next_ticket(self):
+        return self._next
+
+    def scale_boxes(self, ticket, wh_dev):
+        _ffi.check(self._lib.y355_pipeline_scale_boxes(self._h, int(ticket), wh_dev.data_ptr()))
+
+    def fetch(self, ticket):
+        """The reference's eval-mode return for every image of the ticket's batch: list of (bboxes float32 [n,4], scores
+        float32 [n], cls_inds int64 [n]), anchor-index order (models/slim_yolo_v2.py:205-210)."""
+        rec = getattr(self, "_live", {}).get(ticket % self.depth)
+        if rec is None or rec[0] != ticket:
+            raise _ffi.Y355Error(_ffi.ENOTREADY, "ticket %d is gone (a ticket lives for %d more submits)" % (ticket, self.depth))
+        B, md = rec[1], self.max_det
+        b = np.empty((B, md, 4), np.float32)
+        s = np.empty((B, md), np.float32)
+        c = np.empty((B, md), np.int32)
+        n = np.empty((B,), np.int32)
+        _ffi.check(self._lib.y355_pipeline_fetch(self._h, int(ticket), b.ctypes.data, s.ctypes.data, c.ctypes.data, n.ctypes.data))
+        return [(b[i, :n[i]].copy(), s[i, :n[i]].copy(), c[i, :n[i]].astype(np.int64)) for i in range(B)]
+
+    def counters(self):
+        s, g = C.c_int64(), C.c_int64()
+        _ffi.check(self._lib.y355_pipeline_counters(self._h, C.byref(s), C.byref(g)))
+        return s.value, g.value
+
+    def forward(self, x, find=False, sizes_wh=None, frames=False):
+        """Any number of images: chunks of max_batch submitted back to back (up to `depth` in flight), results in order.
+        sizes_wh [B,2]: the evaluators' `bboxes *= [[w, h, w, h]]` on the GPU.  find=True: the 2^15 head-room guard."""
+        if frames:
+            xd = (torch.from_numpy(x) if isinstance(x, np.ndarray) else x).to(self.device).contiguous()
+        else:
+            xd = self._dev_input(x)
+        n = int(xd.shape[0])
+        wh = None
+        if sizes_wh is not None:
+            wh = torch.as_tensor(np.asarray(sizes_wh, np.float32).reshape(-1, 2)).to(self.device)
+            if wh.shape[0] != n:
+                raise ValueError("sizes_wh has %d rows for a batch of %d" % (wh.shape[0], n))
+        flags = _ffi.F_GUARD if find else 0
+        res, tickets = [], []
+        guard = 0
+        for i0 in range(0, n, self.max_batch):
+            if len(tickets) == self.depth:                # the oldest ticket's slot is about to be reused: take its result first
+                res.extend(self.fetch(tickets.pop(0)))
+            t = self.submit(xd[i0:i0 + self.max_batch], flags, frames=frames)
+            if wh is not None:
+                self.scale_boxes(t, wh[i0:i0 + self.max_batch])
+            tickets.append(t)
+            if find:                                      # the guard count of THIS forward: its handle's counters, read before the next
+                sat, g = C.c_int64(), C.c_int64()
+                eh = C.c_void_p(self._lib.y355_pipeline_engine(self._h, t % self.handles))
+                _ffi.check(self._lib.y355_forward_counters(eh, C.byref(sat), C.byref(g)))
+                guard += g.value
+        for t in tickets:
+            res.extend(self.fetch(t))
+        if find and guard:
+            print("too high!!!")
+            raise AssertionError("conv output exceeds the 16-bit head-room (find=True): %d positions" % guard)
+        return res
+
+    def sync(self):
+        _ffi.check(self._lib.y355_pipeline_sync(self._h))
 
 
 def mfma_peak_i8(device_id=0, ms_target=50.0):

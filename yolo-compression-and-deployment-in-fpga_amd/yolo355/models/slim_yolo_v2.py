@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import prep
-from ..engine import Engine
+from ..engine import Engine, Pipeline
 from ..netengine import Net
 from ..utils import Conv2d, Conv2d_fuse
 from ..utils.modules import folded_f32
@@ -89,6 +89,11 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
         self._engine_key = None
         self._loaded_version = None
         self._loaded_find = None
+        self._pipe = None               # y355_pipeline: batches larger than PIPELINE_CHUNK and the asynchronous submit / collect
+        self._pipe_key = None
+        self._pipe_loaded = None
+
+    PIPELINE_CHUNK = 64                 # images per ticket of the pipeline (BASELINE.json's batch: the kernels' tuned regime)
 
     # ------------------------------------------------------------------ reference API
     def set_grid(self, input_size):
@@ -120,20 +125,63 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
                 wh = np.asarray(sizes_wh, np.float32).reshape(-1, 2)
                 dets = [(b * np.array([[w, h, w, h]], np.float32), s, c) for (b, s, c), (w, h) in zip(dets, wh)]
             return dets
-        eng = self._get_engine(int(x.shape[0]), find)
+        B = int(x.shape[0])
         trackers = self._tracker_states()
         freeze = not self.trainable
         if any(t.first_a == 0 for t in trackers) or not freeze:
-            # first call ever (:25-27) calibrates every tracker on this input, layer by layer
+            # first call ever (:25-27) calibrates every tracker on this input, layer by layer, on ONE handle holding the whole batch
+            eng = self._get_engine(B, find)
             sa = eng.calibrate(x, trackers, freeze=freeze)
             self._store_trackers(trackers)
         else:
             sa = [t.exponent() for t in trackers]
+        if B > self.PIPELINE_CHUNK:
+            # more than one batch-64 forward: chunks in flight on the pipeline's handles (y355_pipeline), results in order
+            pipe = self._get_pipeline(find)
+            pipe.set_act_exponents(sa)
+            pipe.set_thresholds(self.conf_thresh, self.nms_thresh)
+            return pipe.forward(x, find=find, sizes_wh=sizes_wh)
+        eng = self._get_engine(B, find)
         eng.set_act_exponents(sa)
         eng.set_thresholds(self.conf_thresh, self.nms_thresh)
         if sizes_wh is not None:
             return eng.forward_scaled(x, sizes_wh, find=find)
         return eng.forward(x, find=find)
+
+    def submit_batch(self, x, quantization=True, find=False, sizes_wh=None):
+        """Asynchronous forward_batch for callers that have host work per batch (the evaluator loops,
+        utils/vocapi_evaluator_mask.py:57-82): enqueue the batch on the pipeline and return a token at once; collect_batch(token)
+        gives what forward_batch would have returned.  Up to `pipeline depth` (6) chunks of PIPELINE_CHUNK images may be
+        outstanding; the trackers must be calibrated (one forward(x, quantization=True) before)."""
+        if not quantization or self.trainable:
+            raise NotImplementedError("submit_batch runs the int8 path (quantization=True, eval)")
+        trackers = self._tracker_states()
+        if any(t.first_a == 0 for t in trackers):
+            raise RuntimeError("yolo355: calibrate the trackers with one forward(x, quantization=True) first")
+        pipe = self._get_pipeline(find)
+        pipe.set_act_exponents([t.exponent() for t in trackers])
+        pipe.set_thresholds(self.conf_thresh, self.nms_thresh)
+        xd = pipe._dev_input(x)
+        n = int(xd.shape[0])
+        if n > pipe.depth * pipe.max_batch:
+            raise ValueError("submit_batch takes at most %d images at a time" % (pipe.depth * pipe.max_batch))
+        wh = None
+        if sizes_wh is not None:
+            wh = torch.as_tensor(np.asarray(sizes_wh, np.float32).reshape(-1, 2)).to(pipe.device)
+        tickets = []
+        for i0 in range(0, n, pipe.max_batch):
+            t = pipe.submit(xd[i0:i0 + pipe.max_batch], 0)
+            if wh is not None:
+                pipe.scale_boxes(t, wh[i0:i0 + pipe.max_batch])
+            tickets.append(t)
+        return (pipe, tickets, wh)
+
+    def collect_batch(self, token):
+        pipe, tickets, _ = token
+        out = []
+        for t in tickets:
+            out.extend(pipe.fetch(t))
+        return out
 
     def calibrate(self, x, freeze=False, find=False):
         """One calibration step on a batch, the tracker side of the reference's calibration loop
@@ -180,17 +228,37 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
             self._loaded_version = None
         ver = self._weights_version()
         if self._loaded_version != ver or self._loaded_find != find:
-            mods = [getattr(self, n).convs[0] for n in _CONVS] + [self.pred]
-            for i, m in enumerate(mods):
-                q_w, e_w = prep.as_dyadic_int8(m.weight)
-                q_b, e_b = prep.as_dyadic_int8(m.bias)
-                # find=True: the checkpoint holds W * 2^r and the reference divides the conv output
-                # by 2^r (:222-227): same values as exponents e + r
-                r = prep.RETUNE[i] if find else 0
-                self._engine.load_layer(i, q_w, q_b, e_w + r, e_b + r)
-            self._engine.set_retune(prep.RETUNE)
+            self._load_into(self._engine, find)
             self._loaded_version, self._loaded_find = ver, find
         return self._engine
+
+    def _load_into(self, target, find):
+        """the ten dyadic layers of this model into an Engine or a Pipeline"""
+        mods = [getattr(self, n).convs[0] for n in _CONVS] + [self.pred]
+        for i, m in enumerate(mods):
+            q_w, e_w = prep.as_dyadic_int8(m.weight)
+            q_b, e_b = prep.as_dyadic_int8(m.bias)
+            # find=True: the checkpoint holds W * 2^r and the reference divides the conv output
+            # by 2^r (:222-227): same values as exponents e + r
+            r = prep.RETUNE[i] if find else 0
+            target.load_layer(i, q_w, q_b, e_w + r, e_b + r)
+        target.set_retune(prep.RETUNE)
+
+    def _get_pipeline(self, find):
+        key = (tuple(self.input_size), self.num_classes, tuple(map(tuple, self.anchor_size.tolist())))
+        if self._pipe is None or self._pipe_key != key:
+            if self._pipe is not None:
+                self._pipe.close()
+            dev = self.device if isinstance(self.device, (str, torch.device)) else "cuda:0"
+            self._pipe = Pipeline(self.input_size, self.num_classes, self.anchor_size.tolist(), self.conf_thresh, self.nms_thresh,
+                                  max_batch=self.PIPELINE_CHUNK, device=dev)
+            self._pipe_key, self._pipe_loaded = key, None
+        ver = (self._weights_version(), bool(find))
+        if self._pipe_loaded != ver:
+            self._pipe.sync()
+            self._load_into(self._pipe, find)
+            self._pipe_loaded = ver
+        return self._pipe
 
     def _get_f32_net(self, batch, find):
         """y355_net (Y355_ARCH_SLIM_V2, bf16) loaded with this model's conv weights and biases as they are."""

@@ -9,6 +9,9 @@ boxes on the host.  These helpers produce the same data structures with batched 
 
     # utils/cocoapi_evaluator.py:66-98
     + ids, data_dict = coco_data_dict(model, self.dataset, self.transform, batch_size=64)
+
+Both helpers are software-pipelined over the y355_pipeline behind a calibrated q_bf model (`_submit`): batch k + 1 is submitted
+before batch k is unpacked, so the GPU runs while the host loads images and builds the evaluator's lists.
 """
 import numpy as np
 import torch
@@ -47,19 +50,24 @@ def _run(net, x, sizes_wh, **kw):
     return res
 
 
+def _submit(net, x, sizes_wh, **kw):
+    """Start one batch and return a zero-argument function that delivers its detections.  A calibrated q_bf model
+    (quantization=True, no guard) goes through submit_batch / collect_batch -- the y355_pipeline behind the model: the GPU works
+    on this batch while the caller loads the next one and unpacks the previous one; everything else runs synchronously in _run."""
+    if (kw.get("quantization") and not kw.get("find") and hasattr(net, "submit_batch") and hasattr(net, "_tracker_states")
+            and all(t.first_a != 0 for t in net._tracker_states()) and int(x.shape[0]) <= 6 * getattr(net, "PIPELINE_CHUNK", 0)):
+        token = net.submit_batch(x, quantization=True, find=False, sizes_wh=sizes_wh)
+        return lambda: net.collect_batch(token)
+    dets = _run(net, x, sizes_wh, **kw)
+    return lambda: dets
+
+
 def voc_all_boxes(net, dataset, num_classes, batch_size=64, quantization=False, find=False, num_images=None):
     """all_boxes[cls][image] = N x 5 float32 (x1, y1, x2, y2, score) exactly as the loop of
     utils/vocapi_evaluator_mask.py:57-82 builds it; dataset.pull_item(i) -> (im [3,H,W] tensor, gt, h, w)."""
     n = len(dataset) if num_images is None else int(num_images)
     all_boxes = [[[] for _ in range(n)] for _ in range(num_classes)]
-    for i0, i1 in _batches(n, batch_size):
-        ims, sizes = [], []
-        for i in range(i0, i1):
-            im, gt, h, w = dataset.pull_item(i)
-            ims.append(torch.as_tensor(im))
-            sizes.append((w, h))
-        x = torch.stack(ims).float()
-        dets = _run(net, x, np.asarray(sizes, np.float32), quantization=quantization, find=find)
+    def unpack(i0, dets):
         for k, (bboxes, scores, cls_inds) in enumerate(dets):
             i = i0 + k
             for j in range(num_classes):
@@ -68,6 +76,20 @@ def voc_all_boxes(net, dataset, num_classes, batch_size=64, quantization=False, 
                     all_boxes[j][i] = np.empty([0, 5], dtype=np.float32)
                     continue
                 all_boxes[j][i] = np.hstack((bboxes[inds], scores[inds][:, np.newaxis])).astype(np.float32, copy=False)
+    pending = None                                      # (first image, deliver) of the batch the GPU is working on
+    for i0, i1 in _batches(n, batch_size):
+        ims, sizes = [], []
+        for i in range(i0, i1):
+            im, gt, h, w = dataset.pull_item(i)
+            ims.append(torch.as_tensor(im))
+            sizes.append((w, h))
+        x = torch.stack(ims).float()
+        deliver = _submit(net, x, np.asarray(sizes, np.float32), quantization=quantization, find=find)
+        if pending is not None:
+            unpack(pending[0], pending[1]())
+        pending = (i0, deliver)
+    if pending is not None:
+        unpack(pending[0], pending[1]())
     return all_boxes
 
 
@@ -76,6 +98,14 @@ def coco_data_dict(net, dataset, transform, batch_size=64, num_images=None, **kw
     id); transform(img)[0] -> HWC float image at the network size; dataset.class_ids maps class index -> COCO id."""
     n = len(dataset) if num_images is None else int(num_images)
     ids, data_dict = [], []
+    def unpack(bids, dets):
+        for id_, (bboxes, scores, cls_inds) in zip(bids, dets):
+            ids.append(id_)
+            for k, box in enumerate(bboxes):
+                x1, y1, x2, y2 = float(box[0]), float(box[1]), float(box[2]), float(box[3])
+                data_dict.append({"image_id": id_, "category_id": dataset.class_ids[int(cls_inds[k])],
+                                  "bbox": [x1, y1, x2 - x1, y2 - y1], "score": float(scores[k])})
+    pending = None
     for i0, i1 in _batches(n, batch_size):
         xs, sizes, bids = [], [], []
         for i in range(i0, i1):
@@ -83,11 +113,10 @@ def coco_data_dict(net, dataset, transform, batch_size=64, num_images=None, **kw
             xs.append(torch.from_numpy(np.ascontiguousarray(transform(img)[0][:, :, (2, 1, 0)])).permute(2, 0, 1))
             sizes.append((img.shape[1], img.shape[0]))
             bids.append(int(id_))
-        dets = _run(net, torch.stack(xs).float(), np.asarray(sizes, np.float32), **kw)
-        for id_, (bboxes, scores, cls_inds) in zip(bids, dets):
-            ids.append(id_)
-            for k, box in enumerate(bboxes):
-                x1, y1, x2, y2 = float(box[0]), float(box[1]), float(box[2]), float(box[3])
-                data_dict.append({"image_id": id_, "category_id": dataset.class_ids[int(cls_inds[k])],
-                                  "bbox": [x1, y1, x2 - x1, y2 - y1], "score": float(scores[k])})
+        deliver = _submit(net, torch.stack(xs).float(), np.asarray(sizes, np.float32), **kw)
+        if pending is not None:
+            unpack(pending[0], pending[1]())
+        pending = (bids, deliver)
+    if pending is not None:
+        unpack(pending[0], pending[1]())
     return ids, data_dict
