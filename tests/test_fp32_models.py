@@ -22,7 +22,7 @@ import pytest
 import torch
 
 from cases import FP32_CASES, fp32_setup
-from helpers import dets_close, dets_match
+from helpers import explain_detection_differences, dets_close, dets_match
 from oracle import fp32_oracle as F
 from oracle import yolo_oracle as O
 from yolo355 import synth
@@ -161,6 +161,11 @@ def test_engine_vs_oracle(case, gold):
             fr, fg = dets_close(ref, out[bi], 0.5, 0.2)
             assert fr >= 0.9 and fg >= 0.9, "%s image %d: loosely matched %.3f / %.3f" % (tag, bi, fr, fg)
             assert abs(len(out[bi][1]) - len(ref[1])) <= max(0.03 * len(ref[1]), 5)
+        # every difference between the two lists has a per-anchor cause inside the tolerances above
+        ex = explain_detection_differences(r["box"][bi], best[bi], r["cls_scores"][bi].argmax(axis=1), cb[bi], cs[bi], cc[bi], 0.01, 0.5)
+        assert ex["n_got"] == len(out[bi][1]) and abs(ex["n_ref"] - len(r["dets"][bi][1])) <= 2
+        assert ex["unexplained"] == [], "%s image %d: %d list differences without a per-anchor cause" % (tag, bi, len(ex["unexplained"]))
+        assert ex["root_score_dev"] <= 0.04 and ex["root_box_dev"] <= 0.08, ex
     net.close()
 
 

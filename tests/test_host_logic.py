@@ -104,3 +104,34 @@ def test_split_product_requant_is_exact():
             got = (A + (1 << (s - 1)) - 1 + ((((m2 & 255) + 255) >> 8) | ((A >> s) & 1))) >> s
             assert np.abs(A).max() < 2 ** 31 or nm == 2047                                         # the host's bound for 205 / 2048
             assert np.array_equal(got, ref), (nm, sh)
+
+
+def test_detection_difference_attribution_separates_noise_from_a_wrong_nms():
+    """helpers.explain_detection_differences (the floating-point configs' list-level evidence): per-anchor noise inside a
+    tolerance leaves no unexplained difference; an NMS with another threshold on one side does."""
+    import helpers
+    rng = np.random.default_rng(0)
+    N = 1500
+    c, wh = rng.uniform(0.1, 0.9, (N, 2)), rng.uniform(0.02, 0.3, (N, 2))
+    box = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    score, cls = rng.uniform(0, 0.6, N).astype(np.float32), rng.integers(0, 2, N)
+    gb = (box + rng.normal(0, 0.004, box.shape)).astype(np.float32)
+    gs = (score + rng.normal(0, 0.005, N)).astype(np.float32)
+    gc = cls.copy()
+    gc[::97] ^= 1                                          # a few best-class flips
+    r = helpers.explain_detection_differences(box, score, cls, gb, gs, gc, 0.01, 0.5)
+    assert r["differ"] > 50 and r["unexplained"] == [] and min(r["causes"].values()) > 0, r
+    assert r["root_score_dev"] <= 0.03 and r["root_box_dev"] <= 0.03
+    same = helpers.explain_detection_differences(box, score, cls, box, score, cls, 0.01, 0.5)
+    assert same["differ"] == 0 and same["n_ref"] == same["n_got"]
+    orig, calls = helpers._nms_replay, [0]
+
+    def wrong(b, s, k, ct, nt):                            # the second side suppresses at IoU 0.6
+        calls[0] += 1
+        return orig(b, s, k, ct, 0.6 if calls[0] == 2 else nt)
+    helpers._nms_replay = wrong
+    try:
+        bad = helpers.explain_detection_differences(box, score, cls, gb, gs, cls, 0.01, 0.5)
+    finally:
+        helpers._nms_replay = orig
+    assert len(bad["unexplained"]) > 50

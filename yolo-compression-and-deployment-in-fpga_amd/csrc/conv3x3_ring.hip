@@ -16,6 +16,9 @@
 //     slot that just died (in two passes where it is larger than a slot), not in its own buffer.
 // Same math, tile geometry, weight packing and epilogue arithmetic as conv3x3.hip.
 #include "y355_common.h"
+#ifndef Y355_RING_XCD_SHARE
+#define Y355_RING_XCD_SHARE 1              // 0: plain work-item order (A/B builds)
+#endif
 #include <type_traits>
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -173,6 +176,19 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const 
     const int ppy0 = pix0 / PWL, ppx0 = min(pix0 % PWL, PW - 1);     // pitch padding re-reads column PW-1
     const int pwithin = ((lane & 3) ^ ((lane >> 3) & 3)) << 4;
     auto decode = [&](int tile, int &b, int &y0, int &x0, int &nb) {
+        // Workgroups are dealt round-robin over the 8 XCDs (workgroup w runs on XCD w % 8), each XCD with its own L2.  The plain
+        // order puts the work items that read the SAME input -- the n-blocks of a tile (the same slab), the tiles of an image
+        // (each other's halo rows) -- on neighbouring XCDs: the slab is fetched into several L2s.  Within every group of
+        // 8 x share consecutive items the walk is permuted so that the `share` items of one input go to workgroups w, w + 8, ..
+        // -- one XCD, dispatched together: the later readers find the slab in L2 (conv6 / conv7: 32.6 -> 18.5 MB fetched per
+        // launch, profiles/r06_notes.md).  share = 2^xcd_share_log2 is the launcher's (0: plain order).
+        if (p.xcd_share_log2 > 0) {
+            const int gs = 8 << p.xcd_share_log2;
+            if (tile < (total_tiles & ~(gs - 1))) {
+                const int j = tile & (gs - 1);
+                tile = (tile & ~(gs - 1)) | ((j & 7) << p.xcd_share_log2) | (j >> 3);
+            }
+        }
         nb = tile % p.nblk;
         tile /= p.nblk;
         x0 = (tile % p.tiles_x) * TW;
@@ -687,6 +703,10 @@ struct ConvInstR {
         p.tiles_x = (p.W + TW - 1) / TW;
         p.tiles_y = (p.H + TH - 1) / TH;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
+        {   // items that read one image's input and are few enough to sit on one XCD together: 2 or 4 (see `decode`)
+            const int per_image = p.tiles_x * p.tiles_y * p.nblk;
+            p.xcd_share_log2 = !Y355_RING_XCD_SHARE ? 0 : per_image == 4 ? 2 : (per_image == 2 || p.nblk == 2) ? 1 : 0;
+        }
         int grid = 256;                                        // one persistent workgroup per CU
         if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;   // fewer, each walking more tiles (throughput mode)
         if (grid > total) grid = total;

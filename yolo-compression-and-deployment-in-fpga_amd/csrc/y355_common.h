@@ -132,6 +132,7 @@ struct ConvParams {
     // events (hipExtLaunchKernelGGL) -- the duration rocprofv3 reports, without the gap to the neighbouring launches
     void *ev_start, *ev_stop;
     int grid_limit;       // host side only: persistent workgroups of a ring launch (0 = one per CU), Y355_OPT_RING_WORKGROUPS
+    int xcd_share_log2;   // ring kernels: work items that read one input are walked by workgroups of one XCD (set by the launcher)
 };
 
 struct Conv1Params {
