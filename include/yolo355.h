@@ -227,6 +227,33 @@ int y355_conv2d_bf16(int device_id, const float *x, const float *w, const float 
                      int batch, int cin, int cout, int height, int width, int ksize, int stride, float neg_slope,
                      int out_fp32, float *out);
 int y355_maxpool2x2_f32(int device_id, const float *in, int batch, int channels, int height, int width, float *out);
+/* --- device-resident operator forms: the same operators for callers whose tensors already live on the GPU (the drop-in
+ * modules called on CUDA tensors).  Device pointers (fp32 NCHW), launched on `stream` behind what it holds, asynchronous, no
+ * host copy of any tensor.
+ *   y355_reorg_f32_dev / y355_spp_f32_dev / y355_maxpool2x2_f32_dev / y355_upsample2x_f32_dev: the operators above, one launch
+ *   y355_conv_op: a convolution whose weights are packed onto the device once.
+ *     create_bf16 (w fp32 [cout][cin][k][k], bias or NULL, BN folded by the caller; host pointers) + y355_conv_op_forward =
+ *       y355_conv2d_bf16's arithmetic (utils.modules.Conv2d, backbone.darknet.Conv_BN_LeakyReLU, resblock branch)
+ *     create_i8 (q_w int8 [cout][cin][3][3], q_b int32 [cout], exponents; flags Y355_OP_LEAKY / Y355_OP_RELU) +
+ *       y355_conv_op_forward_i8 = y355_conv3x3_i8_raw's: Conv2d_fuse on a DYADIC x (values q / 2^e, |q| <= 127; utils/modules.py:20-29
+ *       on the fake-quantised operands of the quantized path), exact.  The input's exponent (-> *sa_in) and the verdict whether x
+ *       is such a tensor (-> *exact; 0: out_dev untouched, take the bf16 route) are decided on the host: two 4-byte read-backs
+ *       per call; no tensor leaves the device.
+ *   One y355_conv_op is single-threaded; it owns its packed weights and growable workspaces. */
+typedef struct y355_conv_op y355_conv_op;
+int y355_reorg_f32_dev(const float *x_dev, int batch, int channels, int height, int width, int stride, float *out_dev, void *stream);
+int y355_spp_f32_dev(const float *x_dev, int batch, int channels, int height, int width, float *out_dev, void *stream);
+int y355_maxpool2x2_f32_dev(const float *in_dev, int batch, int channels, int height, int width, float *out_dev, void *stream);
+int y355_upsample2x_f32_dev(const float *in_dev, int batch, int channels, int height, int width, float *out_dev, void *stream);
+int y355_conv_op_create_bf16(int device_id, const float *w, const float *bias, int cin, int cout, int ksize, int stride, float neg_slope,
+                             y355_conv_op **out);
+int y355_conv_op_create_i8(int device_id, const int8_t *q_w, const int32_t *q_b, int cin, int cout, int e_w, int e_b, int flags,
+                           y355_conv_op **out);
+void y355_conv_op_destroy(y355_conv_op *op);
+int y355_conv_op_forward(y355_conv_op *op, const float *x_dev, const float *residual_dev, int batch, int height, int width, int out_fp32,
+                         float *out_dev, void *stream);
+int y355_conv_op_forward_i8(y355_conv_op *op, const float *x_dev, int batch, int height, int width, float *out_dev, void *stream,
+                            int32_t *sa_in, int32_t *exact);
 /* F.interpolate(x, scale_factor=2.0, mode='bilinear', align_corners=True) (models/yolo_v3.py:211,215) on fp32:
  * [B][C][H][W] -> [B][C][2H][2W]; fp32 arithmetic (within 1e-6 of torch's) */
 int y355_upsample2x_f32(int device_id, const float *in, int batch, int channels, int height, int width, float *out);

@@ -79,10 +79,22 @@ def test_dropin_modules_match_reference(case):
     tag, kind, prm = case
     d = ops_inputs(tag, kind, prm)
     m = _module_for(kind, prm, d)
+    xd = torch.from_numpy(d["x"]).cuda()
     with torch.no_grad():
-        y = m(torch.from_numpy(d["x"]).cuda())
-    assert y.is_cuda and y.dtype == torch.float32
+        y = m(xd)
+        # device-resident: a second call (weights already packed on the GPU) must not synchronise the host
+        # from torch's side -- no .cpu() / .item() / host copy of a tensor inside forward
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            y2 = m(xd)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert torch.equal(y, y2)
+        ycpu = m(torch.from_numpy(d["x"]))               # a CPU tensor takes the host-pointer entry points: same kernels, same bits
+    assert y.is_cuda and y.dtype == torch.float32 and not ycpu.is_cuda
     got = y.cpu().numpy()
+    assert np.array_equal(got, ycpu.numpy())
     ref = GOLD[tag]
     assert got.shape == ref.shape
     if kind in ("reorg", "spp"):
@@ -337,3 +349,47 @@ def test_wider_models_keep_the_reference_state_dict_layout():
         assert len(convs) == nconv and len({id(c) for c in convs}) == nconv
         import torch.nn as nn
         assert sum(isinstance(x, nn.Conv2d) for x in m.modules()) == nconv
+
+
+@pytest.mark.gpu
+def test_device_resident_operators_equal_the_host_pointer_forms():
+    """y355_*_dev / y355_conv_op against the host-pointer entry points they shadow: same kernels, identical bits; ConvOp re-used
+    across batch sizes and map sizes (workspaces grow, halos re-zeroed), the int8 form on dyadic and on non-dyadic inputs."""
+    import torch
+    from yolo355 import engine as E, synth
+    dev = torch.device("cuda", 0)
+    rng = synth.uniform_pm1
+    x = rng(1, (3, 24, 20, 28)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    assert np.array_equal(E.reorg_f32_dev(xd, 2).cpu().numpy(), E.reorg_f32(x, 2))
+    assert np.array_equal(E.spp_f32_dev(xd).cpu().numpy(), E.spp_f32(x))
+    assert np.array_equal(E.maxpool2x2_f32_dev(xd).cpu().numpy(), E.maxpool2x2_f32(x))
+    assert np.array_equal(E.upsample2x_f32_dev(xd).cpu().numpy(), E.upsample2x_f32(x))
+    # bf16 convolutions: 3x3, 3x3 stride 2 with a residual, 1x1 with fp32 output; one operator object, several geometries
+    for k, s, res, f32 in ((3, 1, False, False), (3, 2, True, False), (1, 1, False, True)):
+        w = rng(10 + k + s, (40, 24, k, k)).astype(np.float32) * 0.2
+        b = rng(20 + k, (40,)).astype(np.float32)
+        op = E.ConvOp.bf16(w, b, stride=s, neg_slope=0.1, device=dev)
+        for shape in ((3, 24, 20, 28), (1, 24, 9, 11), (5, 24, 20, 28), (2, 24, 33, 17)):
+            xs = rng(30 + shape[0] + shape[2], shape).astype(np.float32)
+            Ho, Wo = ((shape[2] + 1) // 2, (shape[3] + 1) // 2) if s == 2 else shape[2:]
+            r = rng(40 + shape[2], (shape[0], 40, Ho, Wo)).astype(np.float32) if res else None
+            want = E.conv2d_bf16(xs, w, b, residual=r, stride=s, neg_slope=0.1, out_fp32=f32)
+            got = op.forward(torch.from_numpy(xs).to(dev), None if r is None else torch.from_numpy(r).to(dev), out_fp32=f32)
+            assert np.array_equal(got.cpu().numpy(), want), (k, s, shape)
+        op.close()
+    # int8: Conv2d_fuse on dyadic operands
+    qw = (synth.uniform_u8(5, (48, 32, 3, 3)).astype(np.int32) - 128).clip(-127, 127)
+    qb = (synth.uniform_u8(6, (48,)).astype(np.int32) - 128).clip(-127, 127)
+    op = E.ConvOp.int8(qw, qb, 9, 6, leaky=True, device=dev)
+    for shape, sa in (((2, 32, 16, 24), 4), ((1, 32, 7, 9), 6), ((3, 32, 16, 24), 2)):
+        q = (synth.uniform_u8(7 + sa, shape).astype(np.int32) - 128).clip(-127, 127)
+        q.flat[0] = 127                                    # the tensor's exponent is then exactly sa
+        xq = (q.astype(np.float32) * np.float32(2.0 ** -sa))
+        t, frac = E.conv3x3_i8_raw(q, qw, qb, sa, 9, 6, leaky=True)
+        want = t.astype(np.float32) * np.float32(2.0 ** -frac)
+        got = op.forward_i8(torch.from_numpy(xq).to(dev))
+        assert got is not None and np.array_equal(got.cpu().numpy(), want), shape
+    assert op.forward_i8(torch.from_numpy(rng(9, (2, 32, 16, 24)).astype(np.float32)).to(dev)) is None      # not dyadic: the caller's bf16 route
+    assert op.forward_i8(torch.zeros((1, 32, 8, 8), device=dev)) is None
+    op.close()

@@ -159,6 +159,12 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
 }
 }  // namespace
 
+// the integer epilogue of one stand-alone layer without requantisation (the operator objects of ops.hip)
+int y355_op_requant(int cin, int sa_in, int e_w, int e_b, int act, const int32_t *q_b, int cout, int cout_pad, Requant *rq,
+                    int *frac_bits, std::vector<int32_t> *bias_t, std::vector<long long> *bias_w) {
+    return make_requant(cin, sa_in, e_w, e_b, 0, false, act, 10, q_b, cout, cout_pad, rq, frac_bits, bias_t, bias_w);
+}
+
 struct y355_engine {
     y355_config cfg{};
     hipStream_t stream = nullptr;

@@ -27,6 +27,7 @@
 #include "y355_common.h"
 #include <type_traits>
 #include <cstring>
+#include <cmath>
 #ifndef FRONT_OCC
 #define FRONT_OCC 4
 #endif
@@ -70,11 +71,6 @@ __device__ __forceinline__ float vmax(float a, float b) {
 __device__ __forceinline__ float vmax3abs(float a, float b, float c) {      // max(a, |b|, |c|)
     float d;
     asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ float vmaxabs(float a, float b) {               // max(a, |b|)
-    float d;
-    asm("v_max_f32 %0, %1, |%2|" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
@@ -156,7 +152,8 @@ __device__ __forceinline__ void max_to_byte(unsigned int &w, float a, float b) {
 // The epilogue of four pooled accumulators of one lane -> packed int8 word.
 //   hot (CLAMP = false): unclamped low bytes; ymx / ymn track the branches that can leave [-127, 127] (two ops per four outputs each)
 //   CLAMP: clamped bytes; nbad = outputs that were clamped
-template <bool FOLD, bool CLAMP>
+//   NEGSAFE (y355_launch_front: no accumulator the weights allow can drive the negative branch below -127): ymn is not tracked
+template <bool FOLD, bool CLAMP, bool NEGSAFE>
 __device__ __forceinline__ unsigned int rq_word(const int (&m)[4], const float (&biasf)[4], const RqF &r, const RqV &v, float &ymx,
                                                 float &ymn, unsigned int &nbad) {
     float pos[4], neg[4];
@@ -165,7 +162,7 @@ __device__ __forceinline__ unsigned int rq_word(const int (&m)[4], const float (
     unsigned int w;
     if constexpr (!CLAMP) {
         ymx = vmax3(vmax3(ymx, pos[0], pos[1]), pos[2], pos[3]);
-        ymn = vmin3(vmin3(ymn, neg[0], neg[1]), neg[2], neg[3]);
+        if constexpr (!NEGSAFE) ymn = vmin3(vmin3(ymn, neg[0], neg[1]), neg[2], neg[3]);
         max_to_byte<0>(w, pos[0], neg[0]);
         max_to_byte<1>(w, pos[1], neg[1]);
         max_to_byte<2>(w, pos[2], neg[2]);
@@ -184,7 +181,7 @@ __device__ __forceinline__ unsigned int rq_word(const int (&m)[4], const float (
 }
 }  // namespace
 
-template <bool U8, bool FOLD>
+template <bool U8, bool FOLD, bool NEGSAFE>
 __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams p, const int total_tiles) {
     // separate LDS objects: the compiler then knows that the writes of one phase do not alias the reads of the same phase
     __shared__ __attribute__((aligned(16))) unsigned int patch[PH0 * P0];
@@ -201,7 +198,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     const int Hp = H >> 1, Wp = W >> 1, Ho = H >> 2, Wo = W >> 2;
     const size_t plane = (size_t)H * W;
     const float sc = p.in_scale;
-    const float in_thr = 127.5f / sc;                  // |x| >= thr  <=>  rne(|x| * 2^sa0) > 127 (sc is a power of two)
+    const float in_thr = p.in_thr;                     // 127.5 / sc: |x| >= thr  <=>  rne(|x| * 2^sa0) > 127 (sc is a power of two)
 
     // ---- nothing but a few constants stays in registers across phases: the weight fragments and biases (16 KiB + 192 B,
     // L2-resident) are re-read per tile just ahead of the phase that uses them (128 registers per lane at four workgroups per CU)
@@ -254,9 +251,8 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     float4 vf[U8 ? 1 : QITEMS][3];
     uint3 vu[U8 ? QITEMS : 1];
     // SAFE: every row / 4-pixel group the loads touch lies inside the image (interior tiles): no clamps, no zero padding
-    auto load_input = [&](int t, auto safec) {
+    auto load_input = [&](int tx, int ty, int b, auto safec) {
         constexpr bool SAFE = decltype(safec)::value;
-        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
         const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
         // wave-uniform bases (SGPR pairs) + 32-bit lane offsets: the loads take the saddr form, no 64-bit vector arithmetic
         const char *bu8 = (const char *)p.x_u8 + (size_t)b * plane * 3;
@@ -282,21 +278,24 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
     using TT = std::true_type;
     using FF = std::false_type;
 
+    // tile -> (tx, ty, b) ONCE; every further tile of this workgroup is G_ tiles on, and the host has split G_ into the same
+    // mixed radix (p.step_x / step_y / step_b): three carries per tile instead of three integer divisions by run-time values
+    // (round 6: the divisions and what hung off them were ~85 vector + ~175 scalar instructions per tile and wave, 13 % of the
+    // kernel's issue time -- profiles/r06_notes.md)
+    int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
     for (int trip = 0;; tile += G_, ++trip) {
         // the per-thread bases are made opaque once per tile: otherwise every address derived from them is hoisted
         // out of the tile loop as a loop invariant and held in registers
         int li_ = li, g_ = g, lane_ = lane, tid_ = tid;
         asm volatile("" : "+v"(qr0), "+v"(qj), "+v"(li_), "+v"(g_), "+v"(lane_), "+v"(tid_));
-        int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
-        const int b = tile / (p.tiles_x * p.tiles_y);
         const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
         const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
         // the loads of all QITEMS items (rows y0p .. y0p + 63, columns x0p .. x0p + 63) stay inside the image
         const bool qsafe = y0p >= 0 && x0p >= 0 && y0p + 16 * QITEMS <= H && x0p + 64 <= W;
         stamp();
 
-        if (qsafe) load_input(tile, TT{});
-        else load_input(tile, FF{});
+        if (qsafe) load_input(tx, ty, b, TT{});
+        else load_input(tx, ty, b, FF{});
 #if FRONT_DIAG
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp();
@@ -333,6 +332,13 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                         w[px] = e & 0x00ffffffu;
                     }
                 } else {
+                    if constexpr (!CLAMP) {                          // max |x| of the item's twelve values: two per instruction
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            am = vmax3abs(am, vf[k][c].x, vf[k][c].y);
+                            am = vmax3abs(am, vf[k][c].z, vf[k][c].w);
+                        }
+                    }
 #pragma unroll
                     for (int px = 0; px < 4; ++px) {
                         const float xr = px == 0 ? vf[k][0].x : px == 1 ? vf[k][0].y : px == 2 ? vf[k][0].z : vf[k][0].w;
@@ -343,9 +349,6 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                             yr = __builtin_amdgcn_fmed3f(yr, QLO, QHI);
                             yg = __builtin_amdgcn_fmed3f(yg, QLO, QHI);
                             yb = __builtin_amdgcn_fmed3f(yb, QLO, QHI);
-                        } else {
-                            am = vmax3abs(am, xr, xg);
-                            am = vmaxabs(am, xb);
                         }
                         w[px] = pack3(yr, yg, yb);
                     }
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
         };
         const bool qsat = qsafe ? quantise(FF{}, TT{}) : quantise(FF{}, FF{});
         if (__builtin_amdgcn_ballot_w64(qsat) != 0ull) {
-            load_input(tile, FF{});                           // cold: the input registers were given up after the hot pass
+            load_input(tx, ty, b, FF{});                      // cold: the input registers were given up after the hot pass
             (void)quantise(TT{}, FF{});
         }
         // conv1: weight variant (dy, dx) = v >> 1, v & 1 and the biases as the MFMAs' C operand (accumulator register r of lane
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m[r] = max(max(a0[r], a1[r]), max(a2[r], a3[r]));
                 unsigned int nbad = 0;
-                unsigned int word = rq_word<FOLD, CLAMP>(m, bf1, f1, v1, ymx, ymn, nbad);
+                unsigned int word = rq_word<FOLD, CLAMP, NEGSAFE>(m, bf1, f1, v1, ymx, ymn, nbad);
                 if constexpr (!COLD) {
                     if constexpr (!FRONT_HOTCOLD) satx += nbad;
                 } else {
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                     for (int bx = 0; bx < BW1; ++bx) body(r2, bx);
                 }
             }
-            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || (!NEGSAFE && ymn < QLO)) ? 1u : 0u;
             return satx;
         };
         if (__builtin_amdgcn_ballot_w64(c1(FF{}) != 0) != 0ull) nsat1 += c1(TT{});
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                     int m[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m[r] = max(max(acc[0][0][r], acc[0][1][r]), max(acc[1][0][r], acc[1][1][r]));
-                    word[n] = rq_word<FOLD, CLAMP>(m, bf2[n], f2, v2, ymx, ymn, nbad);
+                    word[n] = rq_word<FOLD, CLAMP, NEGSAFE>(m, bf2[n], f2, v2, ymx, ymn, nbad);
                 }
                 if constexpr (!COLD) {
                     if constexpr (!FRONT_HOTCOLD) satx += nbad;
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
                 }
                 if constexpr (WRITE) *(uint2 *)(stg + wraw * 32 + 8 * g_) = make_uint2(word[0], word[1]);
             }
-            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || ymn < QLO) ? 1u : 0u;
+            if constexpr (!COLD && FRONT_HOTCOLD) satx = (ymx > QHI || (!NEGSAFE && ymn < QLO)) ? 1u : 0u;
             return satx;
         };
         if (__builtin_amdgcn_ballot_w64(c2(FF{}) != 0) != 0ull) nsat2 += c2(TT{});
@@ -603,6 +606,11 @@ __global__ __launch_bounds__(256, FRONT_OCC) void front_kernel(const FrontParams
             }
         }
         if (tile + G_ >= total_tiles) break;
+        tx += p.step_x;
+        if (tx >= p.tiles_x) { tx -= p.tiles_x; ++ty; }
+        ty += p.step_y;
+        if (ty >= p.tiles_y) { ty -= p.tiles_y; ++b; }
+        b += p.step_b;
         // the next tile's Q phase writes `patch` (last read before B2) and its C1 writes `p1` (last read before B3):
         // both are behind a barrier every wave has passed; `stg` is rewritten only after B2 of the next tile
     }
@@ -663,11 +671,22 @@ void y355_launch_front(const FrontParams &p, hipStream_t s) {
     const bool fold = foldable(p.rq1) && foldable(p.rq2);
     FrontParams q = p;
     q.ev_start = q.ev_stop = nullptr;
+    q.in_thr = 127.5f / p.in_scale;
+    q.step_x = grid % p.tiles_x;                       // the walk's stride (one grid) in the tile index's mixed radix
+    q.step_y = (grid / p.tiles_x) % p.tiles_y;
+    q.step_b = grid / (p.tiles_x * p.tiles_y);
+    // no accumulator these weights allow (|t| < 2^tmax_log2, Requant) takes the LeakyReLU's negative branch below -127.5: the hot
+    // passes then do not track its minimum (2 of the 24 vector instructions per four outputs; the positive branch, 8 x steeper,
+    // is always tracked).  True for conv1 / conv2 of the benchmark fixture and of the reference's trained exponents.
+    auto negsafe = [](const Requant &rq) { return std::ldexp((double)rq.neg_mul, rq.tmax_log2) <= std::ldexp(127.0, rq.sh); };
+    const bool ns = negsafe(p.rq1) && negsafe(p.rq2);
+#define FRONT_GO(U8_, FOLD_, NS_) Y355_LAUNCH((front_kernel<U8_, FOLD_, NS_>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total)
     if (p.x) {
-        if (fold) Y355_LAUNCH((front_kernel<false, true>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
-        else Y355_LAUNCH((front_kernel<false, false>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+        if (fold) { if (ns) FRONT_GO(false, true, true); else FRONT_GO(false, true, false); }
+        else { if (ns) FRONT_GO(false, false, true); else FRONT_GO(false, false, false); }
     } else {
-        if (fold) Y355_LAUNCH((front_kernel<true, true>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
-        else Y355_LAUNCH((front_kernel<true, false>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total);
+        if (fold) { if (ns) FRONT_GO(true, true, true); else FRONT_GO(true, true, false); }
+        else { if (ns) FRONT_GO(true, false, true); else FRONT_GO(true, false, false); }
     }
+#undef FRONT_GO
 }

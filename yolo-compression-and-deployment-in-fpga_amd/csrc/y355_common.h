@@ -168,6 +168,8 @@ struct FrontParams {
     int B, H, W;
     int tiles_x, tiles_y;
     float in_scale;       // 2^sa[0]
+    float in_thr;         // set by the launcher: 127.5 / in_scale
+    int step_x, step_y, step_b;   // set by the launcher: the grid size split as (tiles_x, tiles_y, batch) digits (front.hip's tile walk)
     Requant rq1, rq2;
     unsigned long long *stamps;   // diagnostic builds only (-DFRONT_DIAG=1)
     void *ev_start, *ev_stop;     // host side only: see ConvParams

@@ -625,6 +625,104 @@ def mfma_peak_i8(device_id=0, ms_target=50.0):
     return float(t.value), float(c.value)
 
 
+class ConvOp:
+    """A convolution whose weights live packed on the GPU (y355_conv_op, include/yolo355.h): the device-resident form of
+    conv2d_bf16 / conv3x3_i8_raw for callers whose tensors are CUDA tensors -- forward takes and returns CUDA tensors on
+    torch's current stream, no tensor crosses to the host."""
+
+    def __init__(self, handle, kind, cout, stride, device):
+        self._h, self.kind, self.cout, self.stride, self.device = handle, kind, int(cout), int(stride), device
+        self._lib = _ffi.lib()
+        _live.add(self)
+
+    @classmethod
+    def bf16(cls, w, bias, stride=1, neg_slope=1.0, device=None):
+        dev = _require_gpu(device)
+        wi = np.ascontiguousarray(w, dtype=np.float32)
+        cout, cin, k, k2 = wi.shape
+        if k != k2:
+            raise ValueError("square kernels only")
+        bi = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().y355_conv_op_create_bf16(dev.index, wi.ctypes.data, None if bi is None else bi.ctypes.data, cin, cout, k,
+                                                       int(stride), float(neg_slope), C.byref(h)))
+        return cls(h, "bf16", cout, stride, dev)
+
+    @classmethod
+    def int8(cls, q_w, q_b, e_w, e_b, leaky=True, relu=False, device=None):
+        dev = _require_gpu(device)
+        qw = np.ascontiguousarray(q_w, dtype=np.int8)
+        qb = np.ascontiguousarray(q_b, dtype=np.int32)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().y355_conv_op_create_i8(dev.index, qw.ctypes.data, qb.ctypes.data, qw.shape[1], qw.shape[0], int(e_w), int(e_b),
+                                                     _act_flag(leaky, relu), C.byref(h)))
+        return cls(h, "int8", qw.shape[0], 1, dev)
+
+    def close(self):
+        if self._h is not None:
+            self._lib.y355_conv_op_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, x, residual=None, out_fp32=False):
+        """bf16 form: x CUDA float32 [B,cin,H,W] -> CUDA float32 [B,cout,Ho,Wo] (asynchronous, torch's current stream)."""
+        x = x.detach().to(dtype=torch.float32).contiguous()
+        B, _, H, W = x.shape
+        Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if self.stride == 2 else (H, W)
+        out = torch.empty((B, self.cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        r = None if residual is None else residual.detach().to(dtype=torch.float32).contiguous()
+        if r is not None and tuple(r.shape) != tuple(out.shape):
+            raise ValueError("residual shape %s, expected %s" % (tuple(r.shape), tuple(out.shape)))
+        _ffi.check(self._lib.y355_conv_op_forward(self._h, x.data_ptr(), None if r is None else r.data_ptr(), B, H, W, 1 if out_fp32 else 0,
+                                                  out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
+    def forward_i8(self, x):
+        """int8 form: Conv2d_fuse on a dyadic CUDA tensor, exact; returns None when x is not a dyadic int8 tensor."""
+        x = x.detach().to(dtype=torch.float32).contiguous()
+        B, _, H, W = x.shape
+        out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=x.device)
+        sa, exact = C.c_int32(), C.c_int32()
+        _ffi.check(self._lib.y355_conv_op_forward_i8(self._h, x.data_ptr(), B, H, W, out.data_ptr(),
+                                                     torch.cuda.current_stream(x.device).cuda_stream, C.byref(sa), C.byref(exact)))
+        return out if exact.value else None
+
+
+def _dev_unary(fn_name, x, out_shape, *args):
+    """one of the y355_*_f32_dev operators on a CUDA tensor, on torch's current stream"""
+    x = x.detach().to(dtype=torch.float32).contiguous()
+    out = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+    B, Cc, H, W = x.shape
+    _ffi.check(getattr(_ffi.lib(), fn_name)(x.data_ptr(), B, Cc, H, W, *args, out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+    return out
+
+
+def reorg_f32_dev(x, stride):
+    B, Cc, H, W = x.shape
+    s = int(stride)
+    return _dev_unary("y355_reorg_f32_dev", x, (B, Cc * s * s, H // s, W // s), s)
+
+
+def spp_f32_dev(x):
+    B, Cc, H, W = x.shape
+    return _dev_unary("y355_spp_f32_dev", x, (B, 4 * Cc, H, W))
+
+
+def maxpool2x2_f32_dev(x):
+    B, Cc, H, W = x.shape
+    return _dev_unary("y355_maxpool2x2_f32_dev", x, (B, Cc, H // 2, W // 2))
+
+
+def upsample2x_f32_dev(x):
+    B, Cc, H, W = x.shape
+    return _dev_unary("y355_upsample2x_f32_dev", x, (B, Cc, 2 * H, 2 * W))
+
+
 def _act_flag(leaky, relu):
     if leaky and relu:
         raise ValueError("LeakyReLU and ReLU are exclusive")

@@ -8,12 +8,35 @@ the result is the exact fp32 tensor the reference's nn.Conv2d + LeakyReLU(0.125)
 Operands that are NOT dyadic int8 values (utils/modules.py:28-29 accepts any fp32 tensor) run the same layer on the bf16
 MFMA through y355_conv2d_bf16 (operands and result rounded to bf16, the tolerance of the fp32 model families); training
 raises -- there is no CPU / PyTorch fallback.
+
+Round 6: a CUDA tensor stays on the GPU.  The modules keep their weights packed on the device (engine.ConvOp = y355_conv_op,
+re-packed when a parameter's version changes) and call the device-pointer entry points on torch's current stream; the result is
+a CUDA tensor and no tensor crosses to the host.  (Conv2d_fuse's int8 route reads back eight bytes: the input's exponent and
+the verdict whether it is a dyadic int8 tensor decide the route on the host.)  CPU tensors take the host-pointer entry points.
 """
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import prep
+
+
+def _versions(convs):
+    mods = list(convs) if isinstance(convs, nn.Sequential) else [convs]
+    t = [p for m in mods for p in list(m.parameters()) + list(m.buffers())]
+    return tuple(int(p._version) for p in t) + tuple(p.data_ptr() for p in t)
+
+
+def _cached_op(owner, key, convs, build):
+    """the owner module's device-resident operator for `key`, rebuilt when a parameter or buffer of `convs` changed"""
+    cache = owner.__dict__.setdefault("_y355_ops", {})
+    ver = _versions(convs)
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        if hit is not None:
+            hit[1].close()
+        cache[key] = (ver, build())
+    return cache[key][1]
 
 
 def _int8_operands(module, x):
@@ -32,11 +55,31 @@ def _int8_operands(module, x):
     return q_in, sa_in, q_w, e_w, q_b, e_b
 
 
+class _NoOp:
+    def close(self):
+        pass
+
+
 class _FusedBase(nn.Module):
     leaky = True
 
     def forward(self, x):
-        from ..engine import conv3x3_i8_raw
+        from ..engine import ConvOp, conv3x3_i8_raw
+        if x.is_cuda:
+            conv = self.convs[0]
+            if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or conv.dilation != (1, 1):
+                raise NotImplementedError("yolo355 fused conv: only 3x3 / stride 1 / pad 1 (the slim-YOLOv2 layers)")
+
+            def build():
+                try:
+                    q_w, e_w = prep.as_dyadic_int8(conv.weight)
+                    q_b, e_b = prep.as_dyadic_int8(conv.bias) if conv.bias is not None else (np.zeros(conv.out_channels, np.int32), 0)
+                except ValueError:
+                    return _NoOp()                        # weights that are not dyadic: always the bf16 route
+                return ConvOp.int8(q_w, q_b, e_w, e_b, leaky=self.leaky, relu=not self.leaky, device=x.device)
+            op = _cached_op(self, ("i8", x.device.index), self.convs, build)
+            y = op.forward_i8(x) if not isinstance(op, _NoOp) else None
+            return y if y is not None else _conv_bn_act_forward(self.convs, x)
         ops = _int8_operands(self, x)
         if ops is None:
             # the reference's module takes any fp32 tensor (utils/modules.py:28-29, :39-40): same layer on the bf16 MFMA
@@ -80,6 +123,11 @@ def _conv_bn_act_forward(convs, x, residual=None):
             slope = float(m.negative_slope)
         elif isinstance(m, nn.ReLU):
             slope = 0.0
+    if x.is_cuda:                                         # device-resident: weights packed once, the tensor never leaves the GPU
+        from ..engine import ConvOp
+        op = _cached_op(convs, ("bf16", x.device.index), convs,
+                        lambda: ConvOp.bf16(*folded_f32(convs), stride=conv.stride[0], neg_slope=slope, device=x.device))
+        return op.forward(x, residual)
     w, b = folded_f32(convs)
     dev = x.device
     y = conv2d_bf16(x.detach().float().cpu().numpy(), w, b,
@@ -136,7 +184,9 @@ class reorg_layer(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        from ..engine import reorg_f32
+        from ..engine import reorg_f32, reorg_f32_dev
+        if x.is_cuda:
+            return reorg_f32_dev(x, self.stride)
         y = reorg_f32(x.detach().float().cpu().numpy(), self.stride, device_id=x.device.index if x.is_cuda and x.device.index is not None else 0)
         return torch.from_numpy(y).to(x.device)
 
@@ -146,6 +196,8 @@ class SPP(nn.Module):
     Runs y355_spp_f32: bit-exact."""
 
     def forward(self, x):
-        from ..engine import spp_f32
+        from ..engine import spp_f32, spp_f32_dev
+        if x.is_cuda:
+            return spp_f32_dev(x)
         y = spp_f32(x.detach().float().cpu().numpy(), device_id=x.device.index if x.is_cuda and x.device.index is not None else 0)
         return torch.from_numpy(y).to(x.device)
