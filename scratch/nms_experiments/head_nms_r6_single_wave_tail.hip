@@ -738,6 +738,9 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const HeadParams p, const H
 #ifndef RE_DENSE_AFTER
 #define RE_DENSE_AFTER 3            // rounds over the register slots before the waves pack their live edges (0: never)
 #endif
+#ifndef RE_TAIL
+#define RE_TAIL 512                 // live edges at which ONE wave finishes the rounds alone, without barriers (a multiple of 64)
+#endif
 
 __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, const HeadWork wk, float thr) {
     __shared__ __attribute__((aligned(16))) unsigned int sedge[LDS_EDGE_CAP - RE_REG * 1024];   // edges past the register slots; sort keys of the fallback walk
@@ -746,6 +749,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     __shared__ unsigned int skey[2 * NMS_CAP];        // NMS order key of a candidate: (score bits, ~anchor index); later the emit scratch
     __shared__ unsigned long long keepn[64];          // survivors by anchor index
     __shared__ int pend[3];
+    __shared__ int wcnt[16];
     __shared__ int wbase[64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     NSTAMP(2, blockIdx.x, 0);
@@ -757,38 +761,15 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     const int ne = wk.nedges[b * 2];
     const bool brute = wk.nedges[b * 2 + 1] != 0 || ne > LDS_EDGE_CAP;
     const unsigned int *ge = wk.edges + (size_t)b * EDGE_CAP;
-    // every global operand of this workgroup is requested up front, in one burst: the edges of the register slots, and the
-    // thread's own four candidates (score / anchor index for the NMS order now; box / score / class for the emit at the end,
-    // held in registers through the rounds) -- the rounds in between touch LDS only
-    unsigned int ed[RE_REG];
-#pragma unroll
-    for (int k = 0; k < RE_REG; ++k) {
-        const int e = tid + k * 1024;
-        ed[k] = (!brute && e < ne) ? ge[e] : RE_NONE;
-    }
-    float4 mybox[NMS_CAP / 1024];
-    float myscore[NMS_CAP / 1024];
-    int mycls[NMS_CAP / 1024], myorig[NMS_CAP / 1024];
-#pragma unroll
-    for (int j = 0; j < NMS_CAP / 1024; ++j) {
-        const int pos = tid + 1024 * j;
-        const bool in = pos < M;
-        mybox[j] = in ? *(const float4 *)(cb + (size_t)pos * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        myscore[j] = in ? cs[pos] : 0.f;
-        mycls[j] = in ? cc[pos] : 0;
-        myorig[j] = in ? co[pos] : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < NMS_CAP / 1024; ++j) {
-        const int pos = tid + 1024 * j;
+    for (int pos = tid; pos < NMS_CAP; pos += 1024) {
         state[pos] = (pos < M && brute) ? 0 : 1;          // kept unless it is an endpoint of an edge (below)
         blocked[0][pos] = 0;
         blocked[1][pos] = 0;
         blocked[2][pos] = 0;
         // scores are non-negative floats: their bit patterns order like the values.  Staged once, coalesced: the
         // orientation loop below used to gather cs / co from global memory per edge (15 k cycles of dependent loads)
-        skey[2 * pos] = __float_as_uint(myscore[j]);
-        skey[2 * pos + 1] = (unsigned int)myorig[j];
+        skey[2 * pos] = pos < M ? __float_as_uint(cs[pos]) : 0u;
+        skey[2 * pos + 1] = pos < M ? (unsigned int)co[pos] : 0u;
     }
     if (tid < 64) keepn[tid] = 0ull;
     if (tid < 3) pend[tid] = 0;
@@ -808,6 +789,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
         // blocks its later endpoint.  At the end a candidate is kept unless it is dead.  Same decisions as the two-pass rounds,
         // one round earlier each; measured 39.0 -> 2x.x us on the headline fixture (profiles/r06_notes.md).
         const int kmax = __builtin_amdgcn_readfirstlane((ne + 1023) >> 10);
+        unsigned int ed[RE_REG];
         auto orient = [&](unsigned int pq) {
             // orient the pair by the NMS order (score desc, anchor index asc); both endpoints become undecided, the later one blocked
             const int i = (int)(pq >> 12), q = (int)(pq & 0xfffu);
@@ -818,6 +800,11 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
             blocked[0][i_first ? q : i] = 1;
             return i_first ? pq : (((unsigned int)q << 12) | (unsigned int)i);
         };
+#pragma unroll
+        for (int k = 0; k < RE_REG; ++k) {
+            const int e = tid + k * 1024;
+            ed[k] = e < ne ? ge[e] : RE_NONE;
+        }
 #pragma unroll
         for (int k = 0; k < RE_REG; ++k)
             if (ed[k] != RE_NONE) ed[k] = orient(ed[k]);
@@ -891,7 +878,8 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
             // list in LDS and the remaining rounds walk those lists, re-packing in place: a wave's work per round is then
             // proportional to ITS live edges, and a wave whose list ran empty only meets the barrier.
             if (nround == RE_DENSE_AFTER && kmax <= RE_REG) {
-                unsigned int *mine = sedge + (tid >> 6) * (RE_REG * 64);
+                const int wave = tid >> 6;
+                unsigned int *mine = sedge + wave * (RE_REG * 64);
                 int cnt = 0;
 #pragma unroll
                 for (int k = 0; k < RE_REG; ++k) {
@@ -901,6 +889,7 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
                     if (keep) mine[at] = ed[k];
                     cnt += __popcll(m);
                 }
+                int tot = 0;
                 for (;;) {
                     ++nround;
                     const int pb2 = rb;
@@ -926,14 +915,60 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
                     }
                     cnt = __builtin_amdgcn_readfirstlane(left);
                     *(unsigned int *)&blocked[cb2][4 * tid] = 0u;
-                    if (cnt) pend[rb] = 1;
+                    if (lane == 0) {
+                        wcnt[wave] = cnt;
+                        if (cnt) atomicAdd(&pend[rb], cnt);          // the flag of the rounds above, now the number of live edges
+                    }
                     if (tid == 0) pend[cb2] = 0;
                     __syncthreads();
-                    if (!pend[rb]) break;
+                    tot = pend[rb];
+                    if (tot <= RE_TAIL) break;
                 }
-                // (Round 6 also built a single-wave TAIL -- once <= 512 edges are live one wave takes them into registers and
-                // finishes the rounds without barriers: bit-exact, and SLOWER, resolve 30.8 -> 48.2 us (256 edges: 36.3, 1024: 87):
-                // scratch/nms_experiments/head_nms_r6_single_wave_tail.hip, profiles/r06_notes.md)
+                if (tot > 0) {
+                    // ---- the tail: at most RE_TAIL live edges.  ONE wave takes them all into registers and finishes the rounds without
+                    // a barrier (a round of the whole workgroup costs ~1.6 k cycles before any edge is looked at; the chain of
+                    // decisions still has 6-10 links to go); the other waves wait at the barrier in front of the emit.
+                    if (wave == 0) {
+                        unsigned int *comb = sedge + 16 * (RE_REG * 64);
+                        int off = 0;
+                        for (int w = 0; w < 16; ++w) {
+                            const int n = __builtin_amdgcn_readfirstlane(wcnt[w]);
+                            for (int i = lane; i < n; i += 64) comb[off + i] = sedge[w * (RE_REG * 64) + i];
+                            off += n;
+                        }
+                        unsigned int et[RE_TAIL / 64];
+#pragma unroll
+                        for (int k = 0; k < RE_TAIL / 64; ++k) et[k] = lane + 64 * k < off ? comb[lane + 64 * k] : RE_NONE;
+                        // blocked[rb] holds the marks of the last round (exactly the live edges' later endpoints) and the buffer cleared
+                        // in that round is clean: those two alternate from here on, every round wiping the marks it consumed
+                        // (offsets into the LDS array, not pointers: a swapped pointer loses its address space and every access
+                        // becomes a flat one -- measured: the tail 18 us slower than no tail at all)
+                        unsigned char *const bl0 = &blocked[0][0];
+                        int X = rb * NMS_CAP, Y = (rb == 2 ? 0 : rb + 1) * NMS_CAP;
+                        for (;;) {
+                            int sa[RE_TAIL / 64], ba[RE_TAIL / 64];
+#pragma unroll
+                            for (int k = 0; k < RE_TAIL / 64; ++k) {
+                                sa[k] = state[et[k] >> 12];
+                                ba[k] = bl0[X + (int)(et[k] >> 12)];
+                            }
+                            bool any = false;
+#pragma unroll
+                            for (int k = 0; k < RE_TAIL / 64; ++k) {
+                                const unsigned int e = et[k];
+                                if (e == RE_NONE) continue;
+                                const int c = (int)(e & 0xfffu);
+                                bl0[X + c] = 0;                                      // the mark this edge set last round: consumed
+                                if (sa[k] == 2) et[k] = RE_NONE;
+                                else if (sa[k] == 1 || ba[k] == 0) { state[c] = 2; et[k] = RE_NONE; }
+                                else { bl0[Y + c] = 1; any = true; }
+                            }
+                            if (__builtin_amdgcn_ballot_w64(any) == 0ull) break;
+                            const int t = X; X = Y; Y = t;
+                        }
+                    }
+                    __syncthreads();                      // the emit below reads every candidate's state
+                }
                 break;
             }
 #endif
@@ -982,10 +1017,11 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     NSTAMP(2, blockIdx.x, 2);
     // (rounds: an endpoint that nobody killed is still "undecided" here -- it is kept)
     // ---- emit: survivors in anchor-index order
-#pragma unroll
-    for (int j = 0; j < NMS_CAP / 1024; ++j) {
-        const int pos = tid + 1024 * j;
-        if (pos < M && state[pos] != 2) atomicOr(&keepn[myorig[j] >> 6], 1ull << (myorig[j] & 63));
+    for (int pos = tid; pos < M; pos += 1024) {
+        if (state[pos] != 2) {
+            const int n = (int)skey[2 * pos + 1];
+            atomicOr(&keepn[n >> 6], 1ull << (n & 63));
+        }
     }
     __syncthreads();
     if (tid < 64) {
@@ -1003,17 +1039,15 @@ __global__ __launch_bounds__(1024) void resolve_emit_kernel(const HeadParams p, 
     float *ob = p.out_box + (size_t)b * p.max_det * 4;
     float *os = p.out_score + (size_t)b * p.max_det;
     int *oc = p.out_cls + (size_t)b * p.max_det;
-#pragma unroll
-    for (int j = 0; j < NMS_CAP / 1024; ++j) {
-        const int pos = tid + 1024 * j;
-        if (pos < M && state[pos] != 2) {
-            const int n = myorig[j];
+    for (int pos = tid; pos < M; pos += 1024) {
+        if (state[pos] != 2) {
+            const int n = (int)skey[2 * pos + 1];
             const unsigned long long bits = keepn[n >> 6];
             const int dst = wbase[n >> 6] + __popcll(bits & ((1ull << (n & 63)) - 1ull));
             if (dst < p.max_det) {
-                *(float4 *)(ob + (size_t)dst * 4) = mybox[j];
-                os[dst] = myscore[j];
-                oc[dst] = mycls[j];
+                *(float4 *)(ob + (size_t)dst * 4) = *(const float4 *)(cb + (size_t)pos * 4);
+                os[dst] = cs[pos];
+                oc[dst] = cc[pos];
             }
         }
     }
