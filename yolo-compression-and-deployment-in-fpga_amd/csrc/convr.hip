@@ -98,6 +98,15 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void convr_kernel(const ConvGParam
     const int ppy0 = pix0 / PWL, ppx0 = min(pix0 % PWL, PW - 1);     // pitch padding re-reads column PW-1
     const int pwithin = ((lane & 3) ^ ((lane >> 3) & 3)) << 4;
     auto decode = [&](int tile, int &b, int &y0, int &x0, int &nb) {
+        // the work items that read one input (the n-blocks of a tile, the tiles of an image) go to workgroups of ONE XCD: the
+        // permutation of conv3x3_ring.hip's walk (see there), share = 2^xcd_share_log2 set by the launcher
+        if (p.xcd_share_log2 > 0) {
+            const int gs = 8 << p.xcd_share_log2;
+            if (tile < (total_tiles & ~(gs - 1))) {
+                const int j = tile & (gs - 1);
+                tile = (tile & ~(gs - 1)) | ((j & 7) << p.xcd_share_log2) | (j >> 3);
+            }
+        }
         nb = tile % p.nblk;
         tile /= p.nblk;
         x0 = (tile % p.tiles_x) * TW;
@@ -518,6 +527,10 @@ struct ConvRInst {
         p.tiles_x = (p.W + TW - 1) / TW;
         p.tiles_y = (p.H + TH - 1) / TH;
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
+        {
+            const int per_image = p.tiles_x * p.tiles_y * p.nblk;
+            p.xcd_share_log2 = per_image == 4 ? 2 : (per_image == 2 || p.nblk == 2) ? 1 : 0;
+        }
         int grid = total < 256 ? total : 256;                  // one persistent workgroup per CU
         if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;     // fewer, each walking more tiles (throughput mode)
         // int8: only the 32-bit epilogue is built here; a layer that needs the 64-bit one (rq.narrow == 0: 96 accumulators plus

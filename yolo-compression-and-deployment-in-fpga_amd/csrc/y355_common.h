@@ -390,6 +390,7 @@ struct ConvGParams {
     const char *res;
     int res_pb, res_off;
     int grid_limit;           // host side only: persistent workgroups of a convr.hip launch (0 = one per CU), Y355_NET_OPT_WORKGROUPS
+    int xcd_share_log2;       // convr.hip: work items that read one input are walked by workgroups of one XCD (set by the launcher)
 };
 
 struct Conv1FParams {
