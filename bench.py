@@ -254,7 +254,7 @@ def measure_net(args):
         folded.append((w.astype(np.float32), b.astype(np.float32)))
     # `--streams` handles on as many HIP streams, steps alternating (as the headline): the head / NMS of batch i runs beside
     # the convolutions of batch i + 1.  The one-stream figure (latency of a batch) is reported next to it.
-    ns = max(1, args.streams)
+    ns = args.streams if args.streams > 0 else 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
     quant = prep.quantize_folded(folded) if dtype == "int8" else None
     sa_in = sa = None
@@ -543,7 +543,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[2] / configs[3] measurements")
     ap.add_argument("--no-fuse-front", action="store_true",
                     help="A/B: one launch per layer for conv1 / conv2 instead of the fused front-end kernel (same results)")
-    ap.add_argument("--streams", type=int, default=3, help="engine handles (HIP streams) per GPU; steps alternate")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="engine handles (HIP streams) per GPU; 0 = the measured optimum: 4 for the headline's pipeline (the C ABI's default, "
+                         "scratch/r6_sweep.sh), 3 for the y355_net workloads (138.1 k / 196.5 k images/s at 3 against 137.1 k / 192.7 k at 4)")
     ap.add_argument("--fuse-pairs", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: conv3_1 -> conv3_2 + pool3 (Y355_OPT_FUSE_PAIRS): 0 one launch per layer, 1 fused, the layers on different waves of "
                          "every SIMD (the default); -1 = the engine's default.  Same results")
@@ -610,7 +612,7 @@ def main():
     # stream.  The timed region below calls Pipeline.submit -- the entry point models.SlimYOLOv2_quantize_bnfuse.forward_batch
     # and the batched evaluators run; every step is still one whole pass over one batch of B images and all
     # K steps complete inside the timed region.  `engines` are views of the pipeline's handles for the diagnostic passes.
-    nstreams = max(1, args.streams)
+    nstreams = args.streams if args.streams > 0 else 4
     pipe = Pipeline([H, W], NUM_CLASSES, synth.ANCHOR_SIZE_MASK, conf_thresh=0.01, nms_thresh=0.5, max_batch=B, device=dev,
                     handles=nstreams, ring_workgroups=args.ring_workgroups)
     pipe.load_quantized(quantized_layers(2))

@@ -311,7 +311,8 @@ int y355_unpack_dets(const void *packed_dev, const int32_t *slot_dev, int record
  * batches to them round-robin, so that the detection head / NMS of batch i runs beside the convolutions of batch i + 1
  * (+50 % images/s over one handle on one MI355X, profiles/).  Every ticket's result equals a stand-alone y355_forward's bit
  * for bit.  One pipeline is single-threaded like a handle.
- *   create      handles: 1..8, 0 = the measured optimum (3); ring_workgroups: Y355_OPT_RING_WORKGROUPS of the handles while
+ *   create      handles: 1..8, 0 = Y355_PIPE_DEFAULT_HANDLES, the measured optimum (4: 2 / 3 / 4 / 5 / 6 handles deliver 266 / 320 / 326 /
+ *               256 / 300 k images/s on one MI355X, profiles/r06_notes.md); ring_workgroups: Y355_OPT_RING_WORKGROUPS of the handles while
  *               more than one shares the GPU, < 0 = the measured optimum (128).  cfg->stream / own_stream are ignored: every
  *               handle gets its own non-blocking stream (y355_pipeline_create) or the caller's (y355_pipeline_create_on).
  *   load_layer / set_act_exponents / set_retune / set_thresholds / set_normalization / set_option / set_trackers: the engine
@@ -332,6 +333,7 @@ int y355_unpack_dets(const void *packed_dev, const int32_t *slot_dev, int record
  *   stream      the HIP stream of the handle that runs `ticket` */
 typedef struct y355_pipeline y355_pipeline;
 #define Y355_PIPE_AFTER_STREAM 0x100
+#define Y355_PIPE_DEFAULT_HANDLES 4
 int y355_pipeline_create(const y355_config *cfg, int handles, int ring_workgroups, y355_pipeline **out);
 /* the same on `handles` HIP streams of the caller (streams[i] for handle i; `handles` >= 1 here): for hosts whose allocator tracks
  * memory per stream (PyTorch) and must therefore own, and outlive, every stream its tensors are used on */

@@ -70,7 +70,7 @@ def _weights():
 
 @gpu
 def test_pipeline_256_images_equal_four_stand_alone_forwards():
-    """256 images through Pipeline.forward (four chunks of 64 in flight on three handles) == four Engine.forward calls."""
+    """256 images through Pipeline.forward (four chunks of 64 in flight on four handles) == four Engine.forward calls."""
     import torch
     from yolo355.engine import Engine, Pipeline
     H = W = 416
@@ -81,7 +81,7 @@ def test_pipeline_256_images_equal_four_stand_alone_forwards():
     xc = synth.make_images(1, 1, H, W)
     sa = eng.calibrate(xc, [prep.RangeTracker() for _ in range(11)])
     pipe = Pipeline([H, W], 2, synth.ANCHOR_SIZE_MASK, max_batch=64, device=dev)
-    assert (pipe.handles, pipe.depth) == (3, 6)
+    assert (pipe.handles, pipe.depth) == (_ffi.PIPE_DEFAULT_HANDLES, 2 * _ffi.PIPE_DEFAULT_HANDLES) == (4, 8)
     pipe.load_quantized(ql)
     assert pipe.calibrate(xc, [prep.RangeTracker() for _ in range(11)]) == sa
     x = np.concatenate([synth.make_images(1000 + i, 64, H, W) for i in range(4)])
@@ -92,8 +92,8 @@ def test_pipeline_256_images_equal_four_stand_alone_forwards():
         for i in range(64):
             for a, b in zip(want[i], got[64 * c + i]):
                 assert np.array_equal(a, b), (c, i)
-    # a ragged tail and more chunks than tickets in flight: 7 chunks of <= 40 through a depth of 6
-    pipe2 = Pipeline([H, W], 2, synth.ANCHOR_SIZE_MASK, max_batch=40, device=dev)
+    # a ragged tail and more chunks than tickets in flight: 7 chunks of <= 40 through a depth of 4
+    pipe2 = Pipeline([H, W], 2, synth.ANCHOR_SIZE_MASK, max_batch=40, device=dev, handles=2)
     pipe2.load_quantized(ql)
     pipe2.set_act_exponents(sa)
     got2 = pipe2.forward(x[:250])

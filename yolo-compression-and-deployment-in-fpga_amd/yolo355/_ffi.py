@@ -16,6 +16,7 @@ NUM_TIMERS = 12
 NUM_KERNEL_TIMERS = 14
 F_GUARD, F_TAP = 1, 2
 PIPE_AFTER_STREAM = 0x100
+PIPE_DEFAULT_HANDLES = 4
 OP_LEAKY, OP_POOL, OP_RELU = 1, 2, 4
 OPT_FUSE_FRONT = 1
 OPT_RING_WORKGROUPS = 2

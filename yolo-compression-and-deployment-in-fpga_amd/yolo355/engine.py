@@ -422,7 +422,7 @@ class Pipeline:
         cfg.conf_thresh, cfg.nms_thresh = float(conf_thresh), float(nms_thresh)
         cfg.max_batch, cfg.max_det = self.max_batch, int(max_det)
         h = C.c_void_p()
-        nh = 3 if int(handles) == 0 else int(handles)     # the C ABI's default; the streams below must match in number
+        nh = _ffi.PIPE_DEFAULT_HANDLES if int(handles) == 0 else int(handles)     # the C ABI's default (Y355_PIPE_DEFAULT_HANDLES)
         # the handles run on torch streams: PyTorch's allocator tracks memory per stream, so torch must own (and outlive)
         # every stream its tensors are used on -- y355_pipeline_create_on
         self._tstreams = [torch.cuda.Stream(device=self.device) for _ in range(max(nh, 1))]

@@ -151,7 +151,7 @@ class SlimYOLOv2_quantize_bnfuse(nn.Module):
     def submit_batch(self, x, quantization=True, find=False, sizes_wh=None):
         """Asynchronous forward_batch for callers that have host work per batch (the evaluator loops,
         utils/vocapi_evaluator_mask.py:57-82): enqueue the batch on the pipeline and return a token at once; collect_batch(token)
-        gives what forward_batch would have returned.  Up to `pipeline depth` (6) chunks of PIPELINE_CHUNK images may be
+        gives what forward_batch would have returned.  Up to `pipeline depth` (8) chunks of PIPELINE_CHUNK images may be
         outstanding; the trackers must be calibrated (one forward(x, quantization=True) before)."""
         if not quantization or self.trainable:
             raise NotImplementedError("submit_batch runs the int8 path (quantization=True, eval)")

@@ -16,6 +16,8 @@ before batch k is unpacked, so the GPU runs while the host loads images and buil
 import numpy as np
 import torch
 
+from .. import _ffi
+
 
 def _batches(n, bs):
     for i0 in range(0, n, bs):
@@ -55,7 +57,7 @@ def _submit(net, x, sizes_wh, **kw):
     (quantization=True, no guard) goes through submit_batch / collect_batch -- the y355_pipeline behind the model: the GPU works
     on this batch while the caller loads the next one and unpacks the previous one; everything else runs synchronously in _run."""
     if (kw.get("quantization") and not kw.get("find") and hasattr(net, "submit_batch") and hasattr(net, "_tracker_states")
-            and all(t.first_a != 0 for t in net._tracker_states()) and int(x.shape[0]) <= 6 * getattr(net, "PIPELINE_CHUNK", 0)):
+            and all(t.first_a != 0 for t in net._tracker_states()) and int(x.shape[0]) <= 2 * _ffi.PIPE_DEFAULT_HANDLES * getattr(net, "PIPELINE_CHUNK", 0)):
         token = net.submit_batch(x, quantization=True, find=False, sizes_wh=sizes_wh)
         return lambda: net.collect_batch(token)
     dets = _run(net, x, sizes_wh, **kw)
