@@ -41,8 +41,9 @@ LAYER_NAMES = ["conv1", "conv2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "co
 DOMINANT_KERNEL = "conv3x3_i8_ring_kernel<256, 128, 13, 26, false, 4, 2, 4, false, false"   # prefix: the last template argument selects the epilogue (true = fp32)
 
 
-KERNEL_STATS_FILES = ["r05_kernel_stats_one_stream.csv", "r04_kernel_stats_one_stream.csv"]    # newest first
-TRAFFIC_FILES = ["r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
+PROFILE_ROUND = "r06"       # the round whose kernels this bench.py measures: figures read from an older round's profiles/ files are flagged stale
+KERNEL_STATS_FILES = ["r06_kernel_stats_one_stream.csv", "r05_kernel_stats_one_stream.csv", "r04_kernel_stats_one_stream.csv"]    # newest first
+TRAFFIC_FILES = ["r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_h_pmc_traffic.json"]     # newest first
 N_INPUTS = 4          # distinct input batches rotated through the timed loop: 4 x 133 MB > the 256 MB Infinity Cache
 
 
@@ -980,6 +981,10 @@ def main():
                          "bound": "mfma", "achieved": round(dom_tops, 2), "peak": PEAK_I8_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": round(dom_tops * 1e12 / PEAK_I8_DENSE, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_kernel": traffic_kernel,
+                         # traffic / launch_ms_rocprof are READ from the committed rocprofv3 passes of this workload (PMC counters cannot be
+                         # collected inside a timed run); stale = the newest committed file is from an earlier round than these kernels
+                         "traffic_stale": bool(traffic_src) and ("/" + PROFILE_ROUND + "_") not in traffic_src,
+                         "launch_ms_rocprof_stale": bool(rocprof_launch_ms(DOMINANT_KERNEL)[1]) and ("/" + PROFILE_ROUND + "_") not in rocprof_launch_ms(DOMINANT_KERNEL)[1],
                          "kernel": DOMINANT_KERNEL + ", true> (conv6 and conv7: 2 launches/step, the largest share of "
                                    "the step of any kernel; int8 ops = 2 x 398.72e6 MAC x %d images per launch)" % B,
                          "launch_ms": round(dom_ms, 4),

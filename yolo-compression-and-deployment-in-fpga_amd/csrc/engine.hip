@@ -134,12 +134,15 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     if (sh < 0) lim = std::ldexp((long double)tmax, -sh);
     if (lim >= std::ldexp(1.0L, 62)) return fail(Y355_ERANGE, "fixed-point epilogue exceeds 62 bits");
     rq->wide = lim >= std::ldexp(1.0L, 30) ? 1 : 0;
+    long long negsafe_t0 = 0;
     {
         const long long rowsum = wabs > 0 ? wabs : (long long)127 * 9 * cin_real;
         const long long t0 = (127 * rowsum) * (1ll << shl) + bmax;
         int n = 0;
         while (n < 62 && t0 >= (1ll << n)) ++n;
         rq->tmax_log2 = n;
+        rq->negsafe = 0;
+        negsafe_t0 = t0;
     }
     if (!rq->wide && sh > 31) sh = 31;
     rq->shl = shl;
@@ -147,6 +150,7 @@ int make_requant(int cin_real, int sa_in, int e_w, int e_b, int sa_out, bool hav
     rq->leaky = act ? 1 : 0;
     rq->lk = leaky ? 3 : 0;
     rq->neg_mul = act == 2 ? 0 : 1;
+    rq->negsafe = std::ldexp((long double)negsafe_t0 * rq->neg_mul, -sh) <= 127.0L ? 1 : 0;
     rq->sh_l = sh < 0 ? -sh : 0;
     rq->sh_r = sh > 0 ? sh : 0;
     rq->hm1 = sh > 0 ? (int)((1ll << (sh - 1)) - 1) : 0;

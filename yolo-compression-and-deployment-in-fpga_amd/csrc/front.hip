@@ -678,8 +678,7 @@ void y355_launch_front(const FrontParams &p, hipStream_t s) {
     // no accumulator these weights allow (|t| < 2^tmax_log2, Requant) takes the LeakyReLU's negative branch below -127.5: the hot
     // passes then do not track its minimum (2 of the 24 vector instructions per four outputs; the positive branch, 8 x steeper,
     // is always tracked).  True for conv1 / conv2 of the benchmark fixture and of the reference's trained exponents.
-    auto negsafe = [](const Requant &rq) { return std::ldexp((double)rq.neg_mul, rq.tmax_log2) <= std::ldexp(127.0, rq.sh); };
-    const bool ns = negsafe(p.rq1) && negsafe(p.rq2);
+    const bool ns = p.rq1.negsafe && p.rq2.negsafe;                  // Requant::negsafe: the host's check on the exact bound
 #define FRONT_GO(U8_, FOLD_, NS_) Y355_LAUNCH((front_kernel<U8_, FOLD_, NS_>), dim3(grid), dim3(256), 0, s, p.ev_start, p.ev_stop, q, total)
     if (p.x) {
         if (fold) { if (ns) FRONT_GO(false, true, true); else FRONT_GO(false, true, false); }

@@ -900,6 +900,7 @@ static int refresh_i8(y355_net *h) {
             const long double tb = accmax * std::ldexp(1.0L, shl) + bmax;
             fr.tmax_log2 = 0;
             while (fr.tmax_log2 < 62 && std::ldexp(1.0L, fr.tmax_log2) <= tb) ++fr.tmax_log2;
+            fr.negsafe = std::ldexp(tb * nm, -sh) <= 127.0L ? 1 : 0;
             // the magic-number rounding needs |t * slope| < 2^22 only where it does not saturate, and |sh| moderate
             fr.wide = (fr.tmax_log2 > 24 || bmax >= std::ldexp(1.0L, 24) || sh > 30 || sh - lk < -8 || nm < 1 || nm > (1 << lk)) ? 1 : 0;
             std::vector<int32_t> fb(i == 0 ? 16 : 32, 0);

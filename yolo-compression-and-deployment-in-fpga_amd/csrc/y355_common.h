@@ -44,6 +44,9 @@ struct Requant {
     // gen32 only: 1 = the negative branch's product t * neg_mul does not fit 32 bits but t does; it is taken in two halves
     // (y355_requant_gen32): needs sh >= 9 and (|t| / 256 + 1) * neg_mul + 256 < 2^31 (host-checked)
     int split;
+    // 1: the LeakyReLU's negative branch cannot leave [-127, 127]: |t| * neg_mul * 2^-sh <= 127 for the worst-case |t| of these weights
+    // (host-checked on the exact bound, not on 2^tmax_log2): front.hip's hot passes then do not track that branch's minimum
+    int negsafe;
 };
 
 __device__ __forceinline__ int y355_rne_shift32(int x, int s) {            // s wave-uniform
