@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libyolo355.so does not export %s" % n
     assert set(_ffi._SIGS) <= set(names)
-    assert lib.y355_version() == 1
+    assert lib.y355_version() == 2
 
 
 def test_create_without_gpu_fails_loudly():

@@ -28,7 +28,7 @@ static int fail(int code, const std::string &msg) { return y355_fail(code, msg);
     } while (0)
 
 extern "C" const char *y355_last_error(void) { return g_err.c_str(); }
-extern "C" int y355_version(void) { return 1; }
+extern "C" int y355_version(void) { return 2; }       // 2: round 6 (y355_pipeline_*, y355_calibrate, y355_conv_op, *_dev operators)
 
 namespace {
 struct LayerDef { int cin, cout, pool, leaky, kid; };
