@@ -435,6 +435,11 @@ int y355_net_set_thresholds(y355_net *h, float conf_thresh, float nms_thresh);
  * persistent workgroups per launch of the 3x3 ring kernels (convr.hip) while several handles share the GPU, and the NMS pair walk on
  * one workgroup per image.  Results are identical bit for bit. */
 #define Y355_NET_OPT_WORKGROUPS 1
+/* Y355_NET_OPT_THIN_RESIDENT (default 1): the thin 3x3 layers of the bf16 graphs (SlimYOLOv2's conv3_1, conv3_2 + pool3, conv4_1:
+ * K = 288 .. 576) keep their weights in registers and take the pixels as the MFMA's B operand (csrc/convpxb.hip, the bf16 form of the
+ * q_bf engine's convpx.hip); 0 = the LDS-ring kernels of convr.hip as before.  Same arithmetic up to where the bias enters the fp32
+ * accumulation: the two routes agree within 2 bf16 ulps, not bit for bit. */
+#define Y355_NET_OPT_THIN_RESIDENT 2
 int y355_net_set_option(y355_net *h, int option, int value);
 int y355_net_num_layers(y355_net *h);
 int y355_net_num_tensors(y355_net *h);

@@ -352,3 +352,42 @@ def test_bf16_fused_front_matches_layer_launches(case):
         fr, fg = dets_close(tap[bi], fused[bi], 0.9, 0.02)
         assert fr >= 0.9 and fg >= 0.9
     fnet.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FP32_CASES[:3], ids=IDS[:3])
+def test_convpxb_route_against_the_ring_route(case):
+    """Round 6: SlimYOLOv2's thin 3x3 layers (conv3_1, conv3_2 + pool3, conv4_1) with the weights in registers (csrc/convpxb.hip, the
+    default) against the LDS-ring kernels they replace (Y355_NET_OPT_THIN_RESIDENT = 0): the same bf16 operands and fp32
+    accumulation, the bias entering the sum first instead of last -- every element within 2 bf16 ulps, 99.9 % identical or 1 ulp
+    apart; sizes: 416 x 416, a non-square map with edge groups (320 x 416), maps narrower than two DMA pieces (96 x 160), B = 1 / 2."""
+    from yolo355 import _ffi
+    tag, arch, size, classes = case[:4]
+    net, layers, anchors, x = _load_net(case, len(case[5]))
+    B = x.shape[0]
+    net.forward(x, tap=True)
+    new = [net.get_tensor(k, B).copy() for k in range(net.num_tensors)]
+    net.set_option(_ffi.NET_OPT_THIN_RESIDENT, 0)
+    net.forward(x, tap=True)
+    old = [net.get_tensor(k, B).copy() for k in range(net.num_tensors)]
+    # tensors of the graph: 0 conv1 + pool, 1 conv2 + pool, 2 conv3_1, 3 conv3_2 + pool, 4 conv4_1, 5 conv4_2 + pool, 6..8 conv5..7, 9 pred
+    def ulps(a, b):                                       # bf16 values held in fp32: one ulp of max(|a|, |b|) is 2^(exponent - 7)
+        m = np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-30)
+        return np.abs(a.astype(np.float64) - b) / np.ldexp(1.0, np.floor(np.log2(m)).astype(np.int64) - 7)
+    for k in (0, 1):
+        assert np.array_equal(new[k], old[k]), k          # in front of the thin layers: the same launches
+    d = ulps(new[2], old[2])                              # conv3_1: identical inputs on both routes
+    # within 2 bf16 ulps of the value -- or, where the sum cancels to almost nothing, within 2^-10 of the map's r.m.s. (the fp32
+    # accumulation orders differ by ~1e-7 of the terms' magnitude, which is many "ulps" of a result near zero)
+    rms = float(np.sqrt((old[2].astype(np.float64) ** 2).mean()))
+    small = np.abs(new[2].astype(np.float64) - old[2]) <= rms * 2.0 ** -10
+    assert ((d <= 2.0) | small).all() and (d <= 1.0).mean() >= 0.999, (float(d[~small].max()) if (~small).any() else 0.0, float((d <= 1.0).mean()))
+    assert (d > 0).any(), "the option did not change the route"
+    for k in range(3, len(new)):                          # behind it the one-ulp differences propagate: relative L2, and most values untouched
+        rel = np.sqrt(((new[k].astype(np.float64) - old[k]) ** 2).sum() / max((old[k].astype(np.float64) ** 2).sum(), 1e-30))
+        assert rel <= (3e-3 if k < len(new) - 1 else 5e-3), (k, rel)
+        if k in (3, 4):
+            assert (ulps(new[k], old[k]) <= 1.0).mean() >= 0.99, k
+    with pytest.raises(_ffi.Y355Error):
+        net.set_option(_ffi.NET_OPT_THIN_RESIDENT, 2)
+    net.close()

@@ -28,7 +28,7 @@ def signatures(build):
         for line in open(f, errors="replace"):
             m = re.match(r"^(_Z\w+):", line)
             if m:
-                name = m.group(1) if any(g in m.group(1) for g in ("conv3x3_i8_ring_kernel", "convpx_kernel", "convr_kernel", "pxpair3r_kernel")) else None
+                name = m.group(1) if any(g in m.group(1) for g in ("conv3x3_i8_ring_kernel", "convpx_kernel", "convr_kernel", "pxpair3r_kernel", "convpxb_kernel")) else None
                 if name:
                     out[name] = {"lds_dma": 0, "stores": 0, "mfma": 0, "vmcnt": {}}
                 continue
@@ -53,7 +53,7 @@ def signatures(build):
                     out[name]["vmcnt"][m.group(1)] = out[name]["vmcnt"].get(m.group(1), 0) + 1
     return out
 
-GUARDED = ("conv3x3_i8_ring_kernel", "conv1_fast_kernel", "front_kernel", "convpx_kernel", "convr_kernel", "pxpair")
+GUARDED = ("conv3x3_i8_ring_kernel", "conv1_fast_kernel", "front_kernel", "convpx_kernel", "convr_kernel", "pxpair", "convpxb_kernel")
 
 
 def main(build):

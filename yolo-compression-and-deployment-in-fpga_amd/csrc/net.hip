@@ -236,6 +236,9 @@ struct NLayer {
     int rid = -1;
     char *wr_dev = nullptr;
     size_t wr_bytes = 0;
+    // bf16 thin 3x3 layers with the weights in registers (convpxb.hip): its id and the weights in its fragment order
+    int pbid = -1;
+    char *wpb_dev = nullptr;
 };
 
 __global__ void pool_bf16_kernel(const char *in, char *out, int B, int Hin, int Win, int in_pb, int cbytes, int Ho, int Wo,
@@ -414,6 +417,9 @@ __global__ void absmax_bf16_kernel(const char *t, size_t n_elems, unsigned int *
 }
 }  // namespace
 
+#ifndef Y355_USE_CONVPXB
+#define Y355_USE_CONVPXB 1          // 0 (A/B builds): no convpxb.hip instantiation is ever selected
+#endif
 #ifndef Y355_USE_CONVR
 #define Y355_USE_CONVR 1            // 0 (A/B builds): every layer of the generic nets on convg.hip
 #endif
@@ -446,6 +452,7 @@ struct y355_net {
     int8_t *wf_dev = nullptr;         // 16 KiB of front-end weight fragments (y355_pack_front)
     int *fb1_dev = nullptr, *fb2_dev = nullptr;   // pre-shifted int32 biases of the two layers
     Requant frq1{}, frq2{};
+    int no_pxb = 0;                   // Y355_NET_OPT_THIN_RESIDENT = 0: the thin 3x3 layers of the bf16 graphs on convr.hip instead of convpxb.hip
     int tput_wgs = 0;                 // Y355_NET_OPT_WORKGROUPS: persistent workgroups per convr launch while several handles share the GPU (0 = one per CU)
     int profile = 0;
     std::vector<hipEvent_t> ev;
@@ -499,6 +506,7 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
     HIPCHK(hipSetDevice(cfg->device_id));
     if (int e = y355_prepare_kernels()) return e;
     if (y355_prepare_convr(cfg->device_id)) return y355_fail(Y355_EHIP, "hipFuncSetAttribute(convr) / sink allocation failed");
+    if (y355_prepare_convpxb()) return y355_fail(Y355_EHIP, "hipFuncSetAttribute(convpxb) failed");
     y355_net *h = new y355_net();
     h->cfg = *cfg;
     h->arch = &A;
@@ -567,6 +575,11 @@ extern "C" int y355_net_create(const y355_net_config *cfg, y355_net **out) {
                 L.rid = -2;
                 L.wr_bytes = (size_t)(in_kbytes(h, o) / 64) * (L.cout_pad / 16) * 1024;
                 rc = nmalloc(h, (void **)&L.wr_dev, L.wr_bytes, true);
+            }
+            if (!rc && h->bf && o.ksize == 3 && !o.stride2 && !o.res1 && !h->T[o.out].pred && Y355_USE_CONVPXB) {
+                L.pbid = y355_convpxb_select(in_kbytes(h, o), L.cout, o.pool);
+                if (L.pbid >= 0 && ((int)ti.pb != in_kbytes(h, o) || L.cout_pad != L.cout)) L.pbid = -1;     // whole-pixel inputs only
+                if (L.pbid >= 0) rc = nmalloc(h, (void **)&L.wpb_dev, y355_convpxb_packed_bytes(L.pbid), true);
             }
             if (!rc && o.ksize == 3 && !o.stride2 && !o.res1 && Y355_USE_CONVR) {
                 L.rid = y355_convr_select(h->bf ? 1 : 0, in_kbytes(h, o), L.cout_pad, o.pool, ti.H, ti.W);
@@ -648,6 +661,11 @@ extern "C" int y355_net_set_option(y355_net *h, int option, int value) {
         h->tput_wgs = value;
         return 0;
     }
+    if (option == Y355_NET_OPT_THIN_RESIDENT) {
+        if (value != 0 && value != 1) return y355_fail(Y355_EINVAL, "Y355_NET_OPT_THIN_RESIDENT takes 0 or 1");
+        h->no_pxb = !value;
+        return 0;
+    }
     return y355_fail(Y355_EINVAL, "unknown option");
 }
 
@@ -707,6 +725,11 @@ extern "C" int y355_net_load_layer_f32(y355_net *h, int idx, const float *w, con
             std::vector<char> pr(L.wr_bytes);
             y355_convg_pack(kr, w, nullptr, cout, cin, ksize, in_kbytes(h, o), L.cout_pad, pr.data());
             HIPCHK(hipMemcpy(L.wr_dev, pr.data(), pr.size(), hipMemcpyHostToDevice));
+        }
+        if (L.pbid >= 0) {                                     // ... and in convpxb.hip's (weights stay in registers)
+            std::vector<char> pb(y355_convpxb_packed_bytes(L.pbid));
+            if (y355_convpxb_pack(L.pbid, w, cout, cin, pb.data())) HIPCHK(hipMemcpy(L.wpb_dev, pb.data(), pb.size(), hipMemcpyHostToDevice));
+            else L.pbid = -1;
         }
     }
     if (h->front_graph && (L.op == 0 || L.op == 1)) {         // the same weights as the bf16 front end's fragments (frontb.hip)
@@ -1086,6 +1109,14 @@ static int run_op(y355_net *h, int i, int B, const float *x_dev) {
             q.w = L.wr_dev;
             q.nblk = L.cout_pad / 64;
             if (y355_launch_pw_i8(q, s)) {
+                HIPCHK(hipGetLastError());
+                return 0;
+            }
+        }
+        if (L.pbid >= 0 && !h->no_pxb) {                        // bf16 thin 3x3: weights in registers, pixels as the B operand (convpxb.hip)
+            ConvGParams q = p;
+            q.w = L.wpb_dev;
+            if (y355_launch_convpxb(L.pbid, q, s)) {
                 HIPCHK(hipGetLastError());
                 return 0;
             }

@@ -420,6 +420,12 @@ int y355_convg_ksteps(const ConvGInfo &ki, int in_pb, int taps);
 size_t y355_convg_packed_bytes(const ConvGInfo &ki, int in_pb, int taps, int cout_pad);
 void y355_convg_pack(const ConvGInfo &ki, const float *w_f, const int8_t *w_q, int cout, int cin, int ksize,
                      int in_pb, int cout_pad, char *dst);
+// thin 3x3 layers of the bf16 nets with the weights in registers (convpxb.hip): id from select (-1: none), weights fp32 [cout][cin][3][3]
+int y355_prepare_convpxb(void);
+int y355_convpxb_select(int in_pb, int cout, int pool);
+size_t y355_convpxb_packed_bytes(int id);
+bool y355_convpxb_pack(int id, const float *w, int cout, int cin, char *dst);
+bool y355_launch_convpxb(int id, const ConvGParams &p, hipStream_t s);      // false: not available for this launch
 // 3x3 layers of the generic nets on the LDS-DMA ring discipline (convr.hip); weights in y355_convg_pack order for (bn, wn, nt) below
 struct Y355ConvRInfo { int bf, cinb, bn, th, tw, pool, wn, nt; };
 int y355_prepare_convr(int device);

@@ -22,6 +22,7 @@ OPT_FUSE_FRONT = 1
 OPT_RING_WORKGROUPS = 2
 OPT_FUSE_PAIRS = 3
 NET_OPT_WORKGROUPS = 1
+NET_OPT_THIN_RESIDENT = 2
 EINVAL, EHIP, ENOTREADY = -1, -2, -3
 
 
