@@ -43,6 +43,13 @@ __device__ __forceinline__ void fb_barrier() {
 __device__ __forceinline__ unsigned int row_next(unsigned int v) {        // lane i of each row of 16 lanes gets lane i + 1's value
     return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
 }
+// bare instructions: hipcc canonicalises (quiets) both operands of fmaxf chains and turns `m >= 0 ? m : m * s` into a compare + select
+// (v_cndmask on vcc: 22 cycles back to back, profiles/r04_notes.md section 9)
+__device__ __forceinline__ float fb_max(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ unsigned int pk_bf16(float a, float b) {       // (a, b) -> two bf16 (RNE), a in the low half
     typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     const v2bf v = {(__bf16)a, (__bf16)b};
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(512, 4) void frontb_kernel(const FrontBParams p, co
     const int H = p.H, W = p.W;
     const int Hp = H >> 1, Wp = W >> 1, Ho = H >> 2, Wo = W >> 2;
     const size_t plane = (size_t)H * W;
-    const float slope1 = p.slope1, slope2 = p.slope2;
+    const float slope1 = p.slope1, slope2 = p.slope2;      // 0 <= slope <= 1 (y355_launch_frontb's callers): LeakyReLU(m) = max(m, m * slope)
 
     int tile = y355_xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= total_tiles) return;
@@ -87,10 +94,12 @@ __global__ __launch_bounds__(512, 4) void frontb_kernel(const FrontBParams p, co
     // Q: wave-item q = wave + 8 k covers patch rows 4 q .. 4 q + 3; lane = 16 * (row in the item) + 4-pixel group j (j = 15 idle)
     const int qr0 = 4 * wave + g, qj = li;
 
+    // tile -> (tx, ty, b) once; the next tile of this workgroup is one grid further: three carries (step_* = the grid size in the
+    // tile index's mixed radix, from the launcher) instead of three integer divisions by run-time values per tile (front.hip, round 6)
+    int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
     for (;; tile += G_) {
         int li_ = li, g_ = g, tid_ = tid;
         asm volatile("" : "+v"(li_), "+v"(g_), "+v"(tid_));          // per-tile copies: derived addresses are not hoisted out of the loop
-        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
         const int y0p = 4 * TOY * ty - 3, x0p = 4 * TOX * tx - 4;
         const bool border = ty == 0 || tx == 0 || ty == p.tiles_y - 1 || tx == p.tiles_x - 1;
 
@@ -112,15 +121,22 @@ __global__ __launch_bounds__(512, 4) void frontb_kernel(const FrontBParams p, co
             for (int k = 0; k < 2; ++k) {
                 const int r = qr0 + 32 * k;
                 const int gy = y0p + r, gx = x0p + 4 * qj;
-                const bool zero = border && !((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W);    // conv1's zero padding
                 unsigned int lo[4], hi[4];
                 const float xr[4] = {vf[k][0].x, vf[k][0].y, vf[k][0].z, vf[k][0].w};
                 const float xg[4] = {vf[k][1].x, vf[k][1].y, vf[k][1].z, vf[k][1].w};
                 const float xbv[4] = {vf[k][2].x, vf[k][2].y, vf[k][2].z, vf[k][2].w};
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
-                    lo[px] = zero ? 0u : pk_bf16(xr[px], xg[px]);
-                    hi[px] = zero ? 0u : pk_bf16(xbv[px], 0.f);
+                    lo[px] = pk_bf16(xr[px], xg[px]);
+                    hi[px] = pk_bf16(xbv[px], 0.f);
+                }
+                if (border) {                                 // wave-uniform: interior tiles (36 of 64) have no padding to select
+                    const bool zero = !((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W);          // conv1's zero padding
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        lo[px] = zero ? 0u : lo[px];
+                        hi[px] = zero ? 0u : hi[px];
+                    }
                 }
                 const v4i a = {(int)lo[1], (int)hi[1], (int)lo[2], (int)hi[2]};
                 const v4i c = {(int)lo[3], (int)hi[3], (int)row_next(lo[0]), (int)row_next(hi[0])};
@@ -155,8 +171,10 @@ __global__ __launch_bounds__(512, 4) void frontb_kernel(const FrontBParams p, co
                 float y[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // (the pool stays C++: an inline-asm read of an MFMA result gets no hazard wait states from the compiler -- the first
+                    // version of this line read accumulators the matrix pipe had not written yet, and two forwards of one input differed)
                     const float m = fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r])) + b1[r];
-                    y[r] = m >= 0.f ? m : m * slope1;
+                    y[r] = fb_max(m, m * slope1);
                 }
                 uint2 o = make_uint2(pk_bf16(y[0], y[1]), pk_bf16(y[2], y[3]));
                 if (border) {                                 // windows outside the image: conv2's zero padding
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(512, 4) void frontb_kernel(const FrontBParams p, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float m = fmaxf(fmaxf(acc[0][0][r], acc[0][1][r]), fmaxf(acc[1][0][r], acc[1][1][r])) + b2[r];
-                    y[r] = m >= 0.f ? m : m * slope2;
+                    y[r] = fb_max(m, m * slope2);
                 }
                 *(uint2 *)(stg + wraw * 64 + 16 * g_ + 8 * npass) = make_uint2(pk_bf16(y[0], y[1]), pk_bf16(y[2], y[3]));
             }
@@ -222,6 +240,11 @@ __global__ __launch_bounds__(512, 4) void frontb_kernel(const FrontBParams p, co
             }
         }
         if (tile + G_ >= total_tiles) break;
+        tx += p.step_x;
+        if (tx >= p.tiles_x) { tx -= p.tiles_x; ++ty; }
+        ty += p.step_y;
+        if (ty >= p.tiles_y) { ty -= p.tiles_y; ++b; }
+        b += p.step_b;
         fb_barrier();                                       // B4: the staged tile (= the patch) has been read out
     }
 }
@@ -282,5 +305,9 @@ void y355_launch_frontb(const FrontBParams &p, hipStream_t s) {
     const int total = p.tiles_x * p.tiles_y * p.B;
     int grid = 256 * 2;                                    // two persistent workgroups per CU
     if (grid > total) grid = total;
-    hipLaunchKernelGGL(frontb_kernel, dim3(grid), dim3(NTHR), 0, s, p, total);
+    FrontBParams q = p;
+    q.step_x = grid % p.tiles_x;                           // the walk's stride (one grid) in the tile index's mixed radix
+    q.step_y = (grid / p.tiles_x) % p.tiles_y;
+    q.step_b = grid / (p.tiles_x * p.tiles_y);
+    hipLaunchKernelGGL(frontb_kernel, dim3(grid), dim3(NTHR), 0, s, q, total);
 }

@@ -187,7 +187,8 @@ struct FrontBParams {
     const float *bias2;   // [32]
     int B, H, W;
     int tiles_x, tiles_y;
-    float slope1, slope2; // LeakyReLU slopes of the two layers
+    float slope1, slope2; // LeakyReLU slopes of the two layers, each in [0, 1] (the kernel takes max(m, m * slope))
+    int step_x, step_y, step_b;   // set by the launcher: the grid size split as (tiles_x, tiles_y, batch) digits (the tile walk)
 };
 void y355_frontb_tiles(int H, int W, int *tx, int *ty);
 void y355_pack_frontb(const float *w1 /*[16][3][3][3] or null*/, const float *w2 /*[32][16][3][3] or null*/, char *dst /*32768*/);
