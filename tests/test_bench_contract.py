@@ -51,6 +51,10 @@ def test_bench_line_carries_the_contract_fields():
     assert rf["launch_ms_rocprof"] is None or rf["launch_ms_rocprof"] > 0
     assert 3000 < rf["peak_measured"] < 5200                  # measured in this run, not a constant
     assert "gather_verified" not in d
+    # round 6: the timed region goes through the product entry point, and the hand-scheduled figure is beside it
+    assert "y355_pipeline_submit" in d["config"]["entry_point"] and d["config"]["streams_per_gpu"] == 4
+    assert d["hand_scheduled"]["value"] > 0 and d["value"] >= 0.6 * d["hand_scheduled"]["value"]       # 4-step regions: noisy; the 50-step figures differ by 1-2 %
+    assert rf["traffic_stale"] is False and rf["launch_ms_rocprof_stale"] is False       # profiles/ holds this round's passes
 
 
 def _free_port():
