@@ -72,6 +72,7 @@ extern "C" void y355_pipeline_destroy(y355_pipeline *p) {
 extern "C" int y355_pipeline_create_on(const y355_config *cfg, int handles, int ring_workgroups, void *const *streams,
                                        y355_pipeline **out) {
     if (!cfg || !out) return pfail(Y355_EINVAL, "null argument");
+    if (streams && handles < 1) return pfail(Y355_EINVAL, "caller streams: say how many (handles >= 1)");
     if (handles == 0) handles = Y355_PIPE_DEFAULT_HANDLES;      // the measured optimum on one MI355X (profiles/r06_notes.md: 2 .. 6 handles)
     if (handles < 1 || handles > 8) return pfail(Y355_EINVAL, "handles must be 1..8 (0 = default)");
     if (ring_workgroups < 0) ring_workgroups = handles > 1 ? 128 : 0;      // same sweep: 96 / 128 / 160 / 192 workgroups per launch

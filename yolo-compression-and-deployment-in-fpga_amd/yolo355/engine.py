@@ -436,6 +436,7 @@ class Pipeline:
         self.max_det = lib.y355_pipeline_max_det(h)
         self.conf_thresh, self.nms_thresh = float(conf_thresh), float(nms_thresh)
         self._bufs = [None] * self.depth                  # torch-owned output buffers, one set per ticket slot
+        self._tickets = {}                                # slot -> (ticket, batch, outputs, input) of the ticket that holds it
         self._next = 0
 
     def close(self):
@@ -521,14 +522,13 @@ class Pipeline:
         _ffi.check(fn(self._h, xd.data_ptr(), B, int(flags) | (_ffi.PIPE_AFTER_STREAM if ordered else 0), cur,
                       ob.data_ptr(), os_.data_ptr(), oc.data_ptr(), on.data_ptr(), C.byref(t)))
         self._next = t.value + 1
-        self._live = getattr(self, "_live", {})
-        self._live[t.value % self.depth] = (t.value, B, (ob, os_, oc, on), xd)      # keeps the input alive until its slot is reused
+        self._tickets[t.value % self.depth] = (t.value, B, (ob, os_, oc, on), xd)   # keeps the input alive until its slot is reused
         return t.value
 
     def outputs(self, ticket):
         """(boxes [max_batch,max_det,4], scores, cls, count) device tensors of the ticket; rows >= B / entries >= count[b] undefined.
         Read them after wait(ticket)."""
-        rec = getattr(self, "_live", {}).get(ticket % self.depth)
+        rec = self._tickets.get(ticket % self.depth)
         if rec is None or rec[0] != ticket:
             raise _ffi.Y355Error(_ffi.ENOTREADY, "ticket %d is gone (a ticket lives for %d more submits)" % (ticket, self.depth))
         return rec[2]
@@ -563,7 +563,7 @@ class Pipeline:
     def fetch(self, ticket):
         """The reference's eval-mode return for every image of the ticket's batch: list of (bboxes float32 [n,4], scores
         float32 [n], cls_inds int64 [n]), anchor-index order (models/slim_yolo_v2.py:205-210)."""
-        rec = getattr(self, "_live", {}).get(ticket % self.depth)
+        rec = self._tickets.get(ticket % self.depth)
         if rec is None or rec[0] != ticket:
             raise _ffi.Y355Error(_ffi.ENOTREADY, "ticket %d is gone (a ticket lives for %d more submits)" % (ticket, self.depth))
         B, md = rec[1], self.max_det
