@@ -135,3 +135,34 @@ def test_detection_difference_attribution_separates_noise_from_a_wrong_nms():
     finally:
         helpers._nms_replay = orig
     assert len(bad["unexplained"]) > 50
+
+
+def test_round6_entry_points_reject_bad_arguments_without_a_gpu():
+    """argument checks of the round-6 C ABI (pipeline, calibration, device-resident operators) come before any HIP call"""
+    import ctypes as C
+    from yolo355 import _ffi
+    lib = _ffi.lib()
+    h = C.c_void_p()
+    assert lib.y355_pipeline_create(None, 0, -1, C.byref(h)) == _ffi.EINVAL
+    cfg = _ffi.Config()
+    cfg.height = cfg.width = 416
+    cfg.num_classes, cfg.num_anchors, cfg.max_batch = 2, 5, 1
+    assert lib.y355_pipeline_create(C.byref(cfg), 9, -1, C.byref(h)) == _ffi.EINVAL and b"handles" in lib.y355_last_error()
+    assert lib.y355_pipeline_create(C.byref(cfg), 2, 5000, C.byref(h)) == _ffi.EINVAL
+    streams = (C.c_void_p * 2)()
+    assert lib.y355_pipeline_create_on(C.byref(cfg), 0, -1, streams, C.byref(h)) == _ffi.EINVAL      # caller streams need a count
+    t = C.c_longlong()
+    assert lib.y355_pipeline_submit(None, None, 1, 0, None, None, None, None, None, C.byref(t)) == _ffi.EINVAL
+    assert lib.y355_pipeline_wait(None, 0, 0, None) == _ffi.EINVAL and lib.y355_pipeline_handles(None) == _ffi.EINVAL
+    assert lib.y355_pipeline_engine(None, 0) is None and lib.y355_pipeline_stream(None, 0) is None
+    assert lib.y355_calibrate(None, None, 1, 1, 0.1, None, None) == _ffi.EINVAL
+    assert lib.y355_set_trackers(None, None, None) == _ffi.EINVAL and lib.y355_get_trackers(None, None, None) == _ffi.EINVAL
+    assert lib.y355_conv_op_create_bf16(0, None, None, 3, 8, 3, 1, 0.1, C.byref(h)) == _ffi.EINVAL
+    assert lib.y355_conv_op_create_i8(0, None, None, 3, 8, 0, 0, 0, C.byref(h)) == _ffi.EINVAL
+    assert lib.y355_conv_op_forward(None, None, None, 1, 8, 8, 0, None, None) == _ffi.EINVAL
+    e = C.c_int32()
+    assert lib.y355_conv_op_forward_i8(None, None, 1, 8, 8, None, None, None, C.byref(e)) == _ffi.EINVAL
+    assert lib.y355_reorg_f32_dev(None, 1, 1, 4, 4, 2, None, None) == _ffi.EINVAL
+    assert lib.y355_spp_f32_dev(None, 1, 1, 4, 4, None, None) == _ffi.EINVAL
+    lib.y355_pipeline_destroy(None)                       # no-ops on null
+    lib.y355_conv_op_destroy(None)
