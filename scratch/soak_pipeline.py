@@ -35,12 +35,14 @@ print("reference saturation counts (fp32 x1, u8 x1, fp32 x1.8, u8):", sats)
 bufs = [tuple(torch.zeros_like(t) for t in eng._buffers(B)) for _ in range(6)]
 bad = 0
 t0 = time.time()
+last = {}                                                 # handle -> reference index of the last forward it ran
 for it in range(rounds):
     what = []
     for i in range(6):
         k, route = (it + i) % 2, (it // 2 + i) % 2
         what.append(2 * k + route)
-        pipe.submit(frames[k] if route else xs[k], 0, out=bufs[i], frames=bool(route), ordered=False)
+        t = pipe.submit(frames[k] if route else xs[k], 0, out=bufs[i], frames=bool(route), ordered=False)
+        last[t % pipe.handles] = 2 * k + route
     pipe.sync()
     for i in range(6):
         r = refs[what[i]]
@@ -54,9 +56,8 @@ for it in range(rounds):
             bad += 1
             print("MISMATCH round", it, "ticket", i)
     if it % 50 == 0:
-        # each handle's last forward was tickets 3, 4, 5 of this round
-        got = pipe.counters()[0]
-        want = sum(sats[what[i]] for i in (3, 4, 5))
+        got = pipe.counters()[0]                          # summed over the handles' LAST forwards
+        want = sum(sats[v] for v in last.values())
         if got != want:
             bad += 1
             print("COUNTER MISMATCH round", it, got, want)
