@@ -30,6 +30,9 @@ static int fail(int code, const std::string &msg) { return y355_fail(code, msg);
 extern "C" const char *y355_last_error(void) { return g_err.c_str(); }
 extern "C" int y355_version(void) { return 2; }       // 2: round 6 (y355_pipeline_*, y355_calibrate, y355_conv_op, *_dev operators)
 
+#ifndef Y355_TPUT_PAIRS_WGS
+#define Y355_TPUT_PAIRS_WGS 1       // workgroups per image of the NMS pair walk while several handles share the GPU (alone: 2)
+#endif
 namespace {
 struct LayerDef { int cin, cout, pool, leaky, kid; };
 const LayerDef kLayers[10] = {
@@ -745,7 +748,7 @@ static HeadParams head_params(y355_engine *h, int sa_pred, float *ob, float *os,
     // int8 logits keep exp(tw) in a narrow range: the anchor is a good size class (measured: pairs 52 us
     // vs 80 us with area octaves on the benchmark batch)
     p.group_by_area = 0;
-    p.pairs_wgs = h->ring_wgs > 0 ? 1 : 0;    // throughput mode (Y355_OPT_RING_WORKGROUPS set): the pair walk holds one CU per image
+    p.pairs_wgs = h->ring_wgs > 0 ? Y355_TPUT_PAIRS_WGS : 0;    // throughput mode (Y355_OPT_RING_WORKGROUPS set): the pair walk holds one CU per image
     p.Hb = h->Hs;
     p.Wb = h->Ws;
     p.in_w = (float)h->cfg.width;

@@ -665,7 +665,10 @@ bool y355_front_eligible(const Requant &rq1, const Requant &rq2) {
 
 void y355_launch_front(const FrontParams &p, hipStream_t s) {
     const int total = p.tiles_x * p.tiles_y * p.B;
-    int grid = 256 * FRONT_OCC;
+#ifndef FRONT_GRID
+#define FRONT_GRID (256 * FRONT_OCC)
+#endif
+    int grid = FRONT_GRID;
     if (grid > total) grid = total;
     auto foldable = [](const Requant &rq) { return rq.shl == 0 && rq.tmax_log2 <= 22 && rq.sh <= 22 && rq.sh - rq.lk >= -8; };
     const bool fold = foldable(p.rq1) && foldable(p.rq2);
