@@ -113,7 +113,7 @@ constexpr int ring_sp(int lo, int hi, int ppw, bool prev) {
 // something at least as large and saturates either way).  The biases come from a 1 KiB LDS copy that the prologue's first
 // LDS-DMA makes (oldest in the vmcnt stream: every later wait covers it; no global load in the epilogue).
 template <int CIN, int BN, int TH, int TW, bool POOL, int WM, int WN, int PF, bool ROLL, bool DIRECT_REQ, bool FPE = false>
-__global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void conv3x3_i8_ring_kernel(const ConvParams p, const int total_tiles) {
     constexpr int NW = WM * WN;
     constexpr int NTHR = NW * 64;
     constexpr int NCH = CIN / 64, SPC = 9, KS = NCH * SPC;
@@ -705,10 +705,11 @@ struct ConvInstR {
         const int total = p.tiles_x * p.tiles_y * p.nblk * p.B;
         {   // items that read one image's input and are few enough to sit on one XCD together: 2 or 4 (see `decode`)
             const int per_image = p.tiles_x * p.tiles_y * p.nblk;
-            p.xcd_share_log2 = !Y355_RING_XCD_SHARE ? 0 : per_image == 4 ? 2 : (per_image == 2 || p.nblk == 2) ? 1 : 0;
+            p.xcd_share_log2 = !Y355_RING_XCD_SHARE ? 0 : (per_image == 8 && WM * WN == 4) ? 3 : per_image == 4 ? 2 : (per_image == 2 || p.nblk == 2) ? 1 : 0;
         }
-        int grid = 256;                                        // one persistent workgroup per CU
-        if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;   // fewer, each walking more tiles (throughput mode)
+        constexpr int PER_CU = (WM * WN == 4) ? 2 : 1;                     // four-wave instantiations: two workgroups share a CU
+        int grid = y355_cu_count() * PER_CU;                               // one persistent 8-wave workgroup per CU
+        if (p.grid_limit > 0 && p.grid_limit * PER_CU < grid) grid = p.grid_limit * PER_CU;   // fewer, each walking more tiles (throughput mode)
         if (grid > total) grid = total;
         if (p.ev_start && p.ev_stop) {
             hipEvent_t e0 = (hipEvent_t)p.ev_start, e1 = (hipEvent_t)p.ev_stop;
@@ -729,7 +730,11 @@ struct RSet {
     using C4_1 = ConvInstR<64, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
     using C4_2 = ConvInstR<128, 64, 26, 26, true, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
     using C5 = ConvInstR<128, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
+#if Y355_RING_C67_SMALL
+    using C67 = ConvInstR<256, 128, 13, 13, false, 2, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;   // experiment: two 4-wave workgroups per CU
+#else
     using C67 = ConvInstR<256, 128, 13, 26, false, 4, 2, Y355_RING_PF, ROLL, DIRECT, FPE>;
+#endif
     using PRED = ConvInstR<256, 64, 13, 13, false, 8, 1, Y355_RING_PF, ROLL, DIRECT, FPE>;
     // pred in the throughput mode (several handles share the GPU: p.grid_limit > 0): 13 x 26 tiles = 128 work items at B = 64, same
     // weight packing.  A launch then holds 128 CUs for ~15 us instead of 256 for ~12 (the launch is mostly start-up and drain,

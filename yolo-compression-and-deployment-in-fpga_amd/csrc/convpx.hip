@@ -516,7 +516,7 @@ struct PxInst {
     static void launch_(const ConvParams &p_in, const PxArgs &a, hipStream_t s) {
         ConvParams p = p_in;
         p.ev_start = p.ev_stop = nullptr;
-        int grid = 256;                                            // one NW-wave workgroup per CU
+        int grid = y355_cu_count();                                           // one NW-wave workgroup per CU
         // throughput mode (Y355_OPT_RING_WORKGROUPS: several handles share the GPU): fewer workgroups, each walking a longer share of
         // the groups -- the weights-into-registers prologue (up to 288 KB per workgroup) is paid half as often and the launch leaves
         // CUs to the other handles' kernels: 64 / 96 / 128 / 160 / 256 workgroups -> 272.7 / 286.2 / 293.5 / 289.2 / 285.8 k img/s

@@ -531,7 +531,7 @@ struct ConvRInst {
             const int per_image = p.tiles_x * p.tiles_y * p.nblk;
             p.xcd_share_log2 = per_image == 4 ? 2 : (per_image == 2 || p.nblk == 2) ? 1 : 0;
         }
-        int grid = total < 256 ? total : 256;                  // one persistent workgroup per CU
+        const int cus = y355_cu_count(); int grid = total < cus ? total : cus;                 // one persistent workgroup per CU
         if (p.grid_limit > 0 && p.grid_limit < grid) grid = p.grid_limit;     // fewer, each walking more tiles (throughput mode)
         // int8: only the 32-bit epilogue is built here; a layer that needs the 64-bit one (rq.narrow == 0: 96 accumulators plus
         // 64-bit temporaries spill 1.2 KB per lane and the launch is 2.4x slower than convg8's, profiles/r03_notes.md) stays on convg.hip

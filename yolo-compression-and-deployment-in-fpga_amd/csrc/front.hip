@@ -666,7 +666,7 @@ bool y355_front_eligible(const Requant &rq1, const Requant &rq2) {
 void y355_launch_front(const FrontParams &p, hipStream_t s) {
     const int total = p.tiles_x * p.tiles_y * p.B;
 #ifndef FRONT_GRID
-#define FRONT_GRID (256 * FRONT_OCC)
+#define FRONT_GRID (y355_cu_count() * FRONT_OCC)
 #endif
     int grid = FRONT_GRID;
     if (grid > total) grid = total;

@@ -303,7 +303,7 @@ void y355_pack_frontb(const float *w1 /*[16][3][3][3]*/, const float *w2 /*[32][
 
 void y355_launch_frontb(const FrontBParams &p, hipStream_t s) {
     const int total = p.tiles_x * p.tiles_y * p.B;
-    int grid = 256 * 2;                                    // two persistent workgroups per CU
+    int grid = y355_cu_count() * 2;                                   // two persistent workgroups per CU
     if (grid > total) grid = total;
     FrontBParams q = p;
     q.step_x = grid % p.tiles_x;                           // the walk's stride (one grid) in the tile index's mixed radix
