@@ -77,8 +77,7 @@ extern "C" int y355_pipeline_create_on(const y355_config *cfg, int handles, int 
     if (handles < 1 || handles > 8) return pfail(Y355_EINVAL, "handles must be 1..8 (0 = default)");
     if (ring_workgroups < 0) ring_workgroups = handles > 1 ? 128 : 0;      // same sweep: 96 / 128 / 160 / 192 workgroups per launch
     if (ring_workgroups > 4096) return pfail(Y355_EINVAL, "workgroups per launch out of range");
-    PHIPCHK(hipSetDevice(cfg->device_id));
-    y355_pipeline *p = new y355_pipeline();
+    y355_pipeline *p = new y355_pipeline();                    // y355_create checks the configuration, then selects the device
     p->cfg = *cfg;
     p->ring_wgs = handles > 1 ? ring_workgroups : 0; // a handle that has the GPU to itself wants one workgroup per CU
     y355_config c = *cfg;
