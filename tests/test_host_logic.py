@@ -166,3 +166,24 @@ def test_round6_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.y355_spp_f32_dev(None, 1, 1, 4, 4, None, None) == _ffi.EINVAL
     lib.y355_pipeline_destroy(None)                       # no-ops on null
     lib.y355_conv_op_destroy(None)
+
+
+def test_missing_extension_fails_loudly_everywhere(monkeypatch, tmp_path):
+    """no libyolo355.so -> ImportError from every product entry point; nothing computes on the CPU instead"""
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "libyolo355.so"))
+    from yolo355.engine import Engine, Pipeline, conv3x3_i8_fused
+    from yolo355.utils.modules import Conv2d_fuse
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        Engine([416, 416], 2, synth.ANCHOR_SIZE_MASK)
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        Pipeline([416, 416], 2, synth.ANCHOR_SIZE_MASK)
+    q = np.zeros((1, 16, 4, 4), np.int32)
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        conv3x3_i8_fused(q, np.zeros((16, 16, 3, 3), np.int32), np.zeros(16, np.int32), 5, 8, 6, 3)
+    m = Conv2d_fuse(16, 16, 3, padding=1, leakyReLU=True).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.round(p * 64) / 64)
+        with pytest.raises(ImportError, match="no CPU fallback"):
+            m(torch.round(torch.randn(1, 16, 4, 4) * 8) / 8)
