@@ -30,6 +30,11 @@ static int fail(int code, const std::string &msg) { return y355_fail(code, msg);
 extern "C" const char *y355_last_error(void) { return g_err.c_str(); }
 extern "C" int y355_version(void) { return 2; }       // 2: round 6 (y355_pipeline_*, y355_calibrate, y355_conv_op, *_dev operators)
 
+// throughput mode: a layer's launch runs on Y355_OPT_RING_WORKGROUPS x pct / 100 workgroups (A/B builds: -DY355_GL_TAB="{..10 values..}")
+#ifndef Y355_GL_TAB
+#define Y355_GL_TAB {100, 100, 100, 100, 100, 100, 100, 100, 100, 100}
+#endif
+static const int kGridLimitPct[10] = Y355_GL_TAB;
 #ifndef Y355_TPUT_PAIRS_WGS
 #define Y355_TPUT_PAIRS_WGS 1       // workgroups per image of the NMS pair walk while several handles share the GPU (alone: 2)
 #endif
@@ -534,7 +539,7 @@ static int launch_layer(y355_engine *h, int k, int B, int mode, int guard, const
         p.stamps = (h->stamp_layer == k) ? h->stamps_dev : nullptr;
         h->kev_set[k] = false;
         if (h->profile == 2 && mode == 0) { p.ev_start = h->kev[k][0]; p.ev_stop = h->kev[k][1]; }
-        p.grid_limit = h->ring_wgs;
+        p.grid_limit = h->ring_wgs * kGridLimitPct[k] / 100;
         p.B = B;
         p.H = L.Hin;
         p.W = L.Win;
@@ -828,7 +833,7 @@ static int launch_pair3(y355_engine *h, int B) {
     p.B = B;
     p.H = A.Hin;
     p.W = A.Win;
-    p.grid_limit = h->ring_wgs;
+    p.grid_limit = h->ring_wgs * kGridLimitPct[2] / 100;
     p.stamps = (h->stamp_layer == 2) ? h->stamps_dev : nullptr;
     h->kev_set[2] = h->kev_set[3] = false;
     if (h->profile == 2) { p.ev_start = h->kev[2][0]; p.ev_stop = h->kev[2][1]; }
